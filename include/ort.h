@@ -1,0 +1,193 @@
+/*
+ * ort.h — C ABI of libort_hip.so, the MI355X (gfx950) batched ray-trace engine.
+ *
+ * This is the drop-in boundary for ONE path of Sagnac/OpticalRayTracing.jl: the per-ray
+ * surface-by-surface propagation (skew, meridional, paraxial y-nu) and the ABCD product,
+ * plus the pupil-grid driver of `full_trace`.  The reference has no FFI of its own (it is
+ * pure Julia); every entry point below names the reference method (file:line under
+ * /root/reference) whose batch form it is, and INTEGRATION.md shows the `ccall` stubs.
+ *
+ * Conventions
+ *  - plain C: opaque handles, pointers, sizes.  No C++/torch types cross the boundary.
+ *  - every function returns 0 on success, a negative ORT_E* code on failure;
+ *    ort_last_error() gives the message of the calling thread's last failure.
+ *  - `surfaces` columns follow the reference matrix (R, t, n; src/PupilSampling.jl:36):
+ *    each column is a contiguous double[rows]; a Julia `Matrix` passes
+ *    pointer(M), pointer(M)+rows, pointer(M)+2rows.
+ *  - per-ray arrays are struct-of-arrays.  Per-surface history is surface-major:
+ *    out[s*ld + ray], s = 0 .. rows-2  (the reference's xv[i], yv[i], Q10).
+ *  - buffers are HOST pointers unless ORT_DEVICE_PTRS is set in `flags`, in which case
+ *    every ray/axis/output pointer of that call is a device pointer on the context's GPU
+ *    and the call is asynchronous on the context's stream.
+ *  - NaN sentinels are the reference's: surface miss -> NaN coordinates from that surface
+ *    on (src/PupilSampling.jl:9); skew TIR leaves the ray undeviated (Q1, :25-31);
+ *    meridional TIR -> U = NaN (src/RayTracing.jl:164); paraxial clip -> NaN rows (:136).
+ *  - status[ray] = 1-based loop index of the first surface whose x or y is NaN, or
+ *    rows (= S+1) when the ray reached the last row; bit ORT_STATUS_STOPPED is or-ed in
+ *    when the stop filter of src/PupilSampling.jl:131-132 rejected it.
+ *  - there is NO CPU fallback: without a usable gfx950 device every compute call fails.
+ */
+#ifndef ORT_H
+#define ORT_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define ORT_VERSION 100            /* 0.1.0 */
+#define ORT_MAX_ROWS 64            /* surface-matrix rows per system, object row included */
+#define ORT_MAX_NCOEF 12           /* polynomial coefficients per surface */
+
+/* error codes */
+#define ORT_OK 0
+#define ORT_EINVAL (-1)            /* bad argument (shape, NULL, range) */
+#define ORT_EDOMAIN (-2)           /* the reference would throw DomainError */
+#define ORT_EHIP (-3)              /* HIP runtime failure (no device, launch error, OOM) */
+#define ORT_ENOMEM (-4)
+
+/* flags */
+#define ORT_DEVICE_PTRS   (1u << 0) /* ray/axis/output pointers are device pointers */
+#define ORT_INPUT_SLOPES  (1u << 1) /* U, V arrays hold tan U, tan V already */
+#define ORT_RAYBASIS      (1u << 2) /* per-ray U=(ybar-y)/z0, V=-x/z0 (PupilSampling.jl:124-127) */
+#define ORT_LAYOUT_INPUT  (1u << 3) /* meridional: input was a Layout -> always atan (Q16) */
+#define ORT_CLIP          (1u << 4) /* paraxial: clip = true (RayTracing.jl:135) */
+#define ORT_FAST_MATH     (1u << 5) /* fused/reciprocal arithmetic, |rel err| << 1e-10; default is
+                                       the op-for-op IEEE sequence of the reference loop */
+#define ORT_NO_LDS        (1u << 6) /* read the surface table through scalar loads, not LDS */
+
+#define ORT_STATUS_STOPPED (1 << 16)
+#define ORT_STATUS_INDEX(s) ((s) & 0xffff)
+
+typedef struct ort_ctx ort_ctx;       /* one per (host thread, GPU) */
+typedef struct ort_system ort_system; /* device-resident batch of prescriptions */
+
+/* ---- context ---------------------------------------------------------------------- */
+int ort_version(void);
+const char *ort_last_error(void);
+/* stream: a hipStream_t to launch on, or NULL for a stream owned by the context. */
+int ort_ctx_create(int device, void *stream, ort_ctx **out);
+int ort_ctx_destroy(ort_ctx *ctx);
+int ort_ctx_set_stream(ort_ctx *ctx, void *stream);
+int ort_ctx_synchronize(ort_ctx *ctx);
+/* hipEvent pair on the context's stream; stop returns elapsed milliseconds. */
+int ort_ctx_timer_start(ort_ctx *ctx);
+int ort_ctx_timer_stop(ort_ctx *ctx, float *ms);
+/* device properties the bench reports (name, CU count, clock MHz, total bytes) */
+int ort_ctx_device_info(ort_ctx *ctx, char *name, int name_len, int *cus, int *clock_mhz,
+                        int64_t *mem_bytes);
+
+/* ---- systems ---------------------------------------------------------------------- */
+/* Upload nsys prescriptions of `rows` rows each (host pointers, always).
+ * R, t, n : [nsys][rows]   (reference `surfaces` columns; Types.jl:82-112 Layout.R/t/n)
+ * K       : [nsys][rows] or NULL (zeros)          (Layout.K)
+ * coef    : [nsys][rows][ncoef] or NULL           (Layout.p restricted to a power series,
+ *           p_i(y) = sum_j coef[j] y^j, Horner; an arbitrary Julia closure cannot cross
+ *           a C ABI — SURVEY §7)
+ * Both a Float64 and a Float32 table are built.                                         */
+int ort_system_create(ort_ctx *ctx, int nsys, int rows,
+                      const double *R, const double *t, const double *n,
+                      const double *K, const double *coef, int ncoef,
+                      ort_system **out);
+int ort_system_destroy(ort_system *sys);
+int ort_system_rows(const ort_system *sys);
+int ort_system_count(const ort_system *sys);
+
+/* ---- skew real-ray trace: raytrace(surfaces, y, x, U, V, Vector{RealRay}; K, p) ------
+ * src/PupilSampling.jl:34-65, batch form over explicit ray lists through system `isys`.
+ * y, x, U, V : [nrays]; xv, yv : [rows-1][ld] or NULL; status : [nrays] or NULL.        */
+int ort_trace_skew_f64(ort_ctx *ctx, const ort_system *sys, int isys, int64_t nrays,
+                       const double *y, const double *x, const double *U, const double *V,
+                       double *xv, double *yv, int64_t ld, int32_t *status,
+                       unsigned flags);
+int ort_trace_skew_f32(ort_ctx *ctx, const ort_system *sys, int isys, int64_t nrays,
+                       const float *y, const float *x, const float *U, const float *V,
+                       float *xv, float *yv, int64_t ld, int32_t *status,
+                       unsigned flags);
+
+/* ---- pupil-grid bundles: the hot loop of full_trace, src/PupilSampling.jl:121-138 ----
+ * A bundle is one (system, field) pair: rays are the cartesian grid yaxis (outer) x xaxis
+ * (inner), all sharing the field angles U, V (or the RayBasis rule).  Ray r of bundle b
+ * has global index b*ny*nx + r with r = iy*nx + ix.                                      */
+typedef struct ort_bundle {
+    int32_t system;      /* index into the ort_system batch */
+    int32_t stop;        /* 1-based loop index tested by the stop filter (system.stop); 0 = none */
+    double U, V;         /* field angles; tan() is taken on the host (PupilSampling.jl:38-39) */
+    double a_stop;       /* |system.a[stop]|  (:91) */
+    double hprime;       /* h' subtracted from y_f (:102-109,134) */
+    double ybar, z0;     /* ORT_RAYBASIS only (:106-108) */
+    int64_t yaxis_off;   /* element offsets of this bundle's axes inside `axes` */
+    int64_t xaxis_off;
+} ort_bundle;
+
+/* Outputs of a grid trace; any pointer may be NULL.  N = nb*ny*nx.
+ * xv, yv  : [rows-1][ld]  per-surface history (ld >= N)
+ * xf, yf  : [N] image-row hit (xv[end], yv[end], :129-130)
+ * xs, ys  : [N] hit on the stop row (:131), requires bundle.stop > 0
+ * status  : [N]                                                                          */
+typedef struct ort_grid_out_f64 {
+    double *xv, *yv; int64_t ld;
+    double *xf, *yf, *xs, *ys;
+    int32_t *status;
+} ort_grid_out_f64;
+typedef struct ort_grid_out_f32 {
+    float *xv, *yv; int64_t ld;
+    float *xf, *yf, *xs, *ys;
+    int32_t *status;
+} ort_grid_out_f32;
+
+/* bundles: host array [nb] (always host).  axes: [..] doubles, host or device per flags. */
+int ort_trace_grid_f64(ort_ctx *ctx, const ort_system *sys, int nb, const ort_bundle *bundles,
+                       const double *axes, int64_t axes_len, int ny, int nx,
+                       const ort_grid_out_f64 *out, unsigned flags);
+int ort_trace_grid_f32(ort_ctx *ctx, const ort_system *sys, int nb, const ort_bundle *bundles,
+                       const float *axes, int64_t axes_len, int ny, int nx,
+                       const ort_grid_out_f32 *out, unsigned flags);
+
+/* ---- full_trace: src/PupilSampling.jl:121-146 + sigma :169-173 ------------------------
+ * grid -> trace -> stop filter -> order-preserving append -> mirror -> rho, theta -> RMS,
+ * one RealRayError (Types.jl:184-192) per bundle.  Aiming scalars (y1, y2, y_EP through
+ * the axes; U, h', stop, a_stop through the bundle) are inputs.
+ * ex, ey, rho, theta : [nb][2*ny*nx] (bundle b starts at b*2*ny*nx; count[b] entries valid)
+ * count : [nb] = 2*survivors;  rms : [nb];  traced : [nb] rays traced (may be NULL)      */
+int ort_full_trace_f64(ort_ctx *ctx, const ort_system *sys, int nb, const ort_bundle *bundles,
+                       const double *axes, int64_t axes_len, int ny, int nx,
+                       double *ex, double *ey, double *rho, double *theta,
+                       int64_t *count, double *rms, unsigned flags);
+
+/* ---- meridional real-ray trace: raytrace(surfaces, y, U, RealRay; K, p) ---------------
+ * src/RayTracing.jl:145-169.  y_out, U_out, ts_out : [rows][ld] (row 0 = input ray;
+ * ts_out = per-ray distances whose cumsum is RealRay.z, Types.jl:61-63; may be NULL).    */
+int ort_trace_meridional_f64(ort_ctx *ctx, const ort_system *sys, int isys, int64_t nrays,
+                             const double *y, const double *U,
+                             double *y_out, double *U_out, double *ts_out, int64_t ld,
+                             unsigned flags);
+
+/* ---- paraxial y-nu trace: raytrace(lens, y, ω, a; clip) --------------------------------
+ * src/RayTracing.jl:127-143 (+ transfer/refract :55-69).  nlens lenses of k rows each
+ * (Lens.M columns τ, ϕ: [nlens][k]); a: [nlens][k] or NULL (fill(Inf)); rays_per_lens rays
+ * per lens: y, w : [nlens*rays_per_lens]; rt_y, rt_w : [k+1][ld], ld >= nlens*rays_per_lens. */
+int ort_trace_paraxial_f64(ort_ctx *ctx, int nlens, int k,
+                           const double *tau, const double *phi, const double *a,
+                           int64_t rays_per_lens, const double *y, const double *w,
+                           double *rt_y, double *rt_w, int64_t ld, unsigned flags);
+
+/* ---- ABCD: TransferMatrix(lens), src/TransferMatrix.jl:1-6 ----------------------------
+ * M : [nlens][4] row-major {A, B, C, D}.                                                  */
+int ort_abcd_f64(ort_ctx *ctx, int nlens, int k, const double *tau, const double *phi,
+                 double *M, unsigned flags);
+/* transfer(M, v, τ, τ′) (:8-10): nv vectors through ONE matrix; v, out : [nv][2].
+ * tau, tau_p : [nv] object / image space reduced distances.                              */
+int ort_abcd_transfer_f64(ort_ctx *ctx, const double *M, int64_t nv, const double *v,
+                          const double *tau, const double *tau_p, double *out,
+                          unsigned flags);
+/* reverse_transfer(M, v, τ′, τ) (:13): extend(M, τ, τ′) \ v.                              */
+int ort_abcd_reverse_transfer_f64(ort_ctx *ctx, const double *M, int64_t nv, const double *v,
+                                  const double *tau_p, const double *tau, double *out,
+                                  unsigned flags);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ORT_H */

@@ -1,0 +1,253 @@
+"""ctypes binding of libort_hip.so (include/ort.h) — the only way the host layer computes.
+
+There is no CPU fallback here by design: if the shared library is not built, or no gfx950
+device is usable, every call raises.  The reference has no FFI (it is pure Julia); the
+equivalent `ccall` stubs a maintainer would add are in INTEGRATION.md.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import sys
+from typing import Optional
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "libort_hip.so")
+
+# flags / codes (include/ort.h)
+ORT_DEVICE_PTRS = 1 << 0
+ORT_INPUT_SLOPES = 1 << 1
+ORT_RAYBASIS = 1 << 2
+ORT_LAYOUT_INPUT = 1 << 3
+ORT_CLIP = 1 << 4
+ORT_FAST_MATH = 1 << 5
+ORT_NO_LDS = 1 << 6
+ORT_STATUS_STOPPED = 1 << 16
+ORT_MAX_ROWS = 64
+ORT_MAX_NCOEF = 12
+ORT_EDOMAIN = -2
+
+
+class OrtError(RuntimeError):
+    """A non-zero return code from the C ABI (message from ort_last_error())."""
+
+    def __init__(self, code: int, msg: str):
+        super().__init__(f"[ort {code}] {msg}")
+        self.code = code
+
+
+class ort_bundle(C.Structure):
+    _fields_ = [
+        ("system", C.c_int32), ("stop", C.c_int32),
+        ("U", C.c_double), ("V", C.c_double),
+        ("a_stop", C.c_double), ("hprime", C.c_double),
+        ("ybar", C.c_double), ("z0", C.c_double),
+        ("yaxis_off", C.c_int64), ("xaxis_off", C.c_int64),
+    ]
+
+
+class ort_grid_out_f64(C.Structure):
+    _fields_ = [
+        ("xv", C.c_void_p), ("yv", C.c_void_p), ("ld", C.c_int64),
+        ("xf", C.c_void_p), ("yf", C.c_void_p), ("xs", C.c_void_p), ("ys", C.c_void_p),
+        ("status", C.c_void_p),
+    ]
+
+
+class ort_grid_out_f32(C.Structure):
+    _fields_ = ort_grid_out_f64._fields_
+
+
+_p = C.c_void_p
+_i = C.c_int
+_l = C.c_int64
+_u = C.c_uint
+
+# name -> (restype, argtypes); kept in one table so tests can check it against include/ort.h
+SIGNATURES = {
+    "ort_version": (_i, []),
+    "ort_last_error": (C.c_char_p, []),
+    "ort_ctx_create": (_i, [_i, _p, C.POINTER(_p)]),
+    "ort_ctx_destroy": (_i, [_p]),
+    "ort_ctx_set_stream": (_i, [_p, _p]),
+    "ort_ctx_synchronize": (_i, [_p]),
+    "ort_ctx_timer_start": (_i, [_p]),
+    "ort_ctx_timer_stop": (_i, [_p, C.POINTER(C.c_float)]),
+    "ort_ctx_device_info": (_i, [_p, C.c_char_p, _i, C.POINTER(_i), C.POINTER(_i), C.POINTER(_l)]),
+    "ort_system_create": (_i, [_p, _i, _i, _p, _p, _p, _p, _p, _i, C.POINTER(_p)]),
+    "ort_system_destroy": (_i, [_p]),
+    "ort_system_rows": (_i, [_p]),
+    "ort_system_count": (_i, [_p]),
+    "ort_trace_skew_f64": (_i, [_p, _p, _i, _l, _p, _p, _p, _p, _p, _p, _l, _p, _u]),
+    "ort_trace_skew_f32": (_i, [_p, _p, _i, _l, _p, _p, _p, _p, _p, _p, _l, _p, _u]),
+    "ort_trace_grid_f64": (_i, [_p, _p, _i, C.POINTER(ort_bundle), _p, _l, _i, _i, C.POINTER(ort_grid_out_f64), _u]),
+    "ort_trace_grid_f32": (_i, [_p, _p, _i, C.POINTER(ort_bundle), _p, _l, _i, _i, C.POINTER(ort_grid_out_f32), _u]),
+    "ort_full_trace_f64": (_i, [_p, _p, _i, C.POINTER(ort_bundle), _p, _l, _i, _i, _p, _p, _p, _p, _p, _p, _u]),
+    "ort_trace_meridional_f64": (_i, [_p, _p, _i, _l, _p, _p, _p, _p, _p, _l, _u]),
+    "ort_trace_paraxial_f64": (_i, [_p, _i, _i, _p, _p, _p, _l, _p, _p, _p, _p, _l, _u]),
+    "ort_abcd_f64": (_i, [_p, _i, _i, _p, _p, _p, _u]),
+    "ort_abcd_transfer_f64": (_i, [_p, _p, _l, _p, _p, _p, _p, _u]),
+    "ort_abcd_reverse_transfer_f64": (_i, [_p, _p, _l, _p, _p, _p, _p, _u]),
+}
+
+_lib: Optional[C.CDLL] = None
+
+
+def load() -> C.CDLL:
+    """Load libort_hip.so (once).  Raises if it has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            f"{LIB_PATH} is missing: the HIP extension is not built. Run "
+            "`python -c 'import __graft_entry__ as g; g.build()'` (hipcc, gfx950). "
+            "There is no CPU fallback.")
+    # torch ships its own libamdhip64 with the same SONAME; when both live in one process the
+    # HIP runtime must be loaded once.  Importing torch first makes the dynamic loader reuse
+    # torch's copy for this library (torch is only plumbing: device memory and collectives).
+    if os.environ.get("ORT_NO_TORCH", "0") != "1" and "torch" not in sys.modules:
+        try:
+            import torch  # noqa: F401
+        except Exception:  # torch is optional for the library itself
+            pass
+    lib = C.CDLL(LIB_PATH, mode=C.RTLD_GLOBAL)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def check(rc: int) -> None:
+    if rc != 0:
+        raise OrtError(rc, load().ort_last_error().decode("utf-8", "replace"))
+
+
+def ptr(a) -> Optional[int]:
+    """Address of a numpy array / torch tensor / int / None as a void*."""
+    if a is None:
+        return None
+    if isinstance(a, int):
+        return a
+    if isinstance(a, np.ndarray):
+        return a.ctypes.data
+    if hasattr(a, "data_ptr"):
+        return a.data_ptr()
+    raise TypeError(f"cannot take the address of {type(a)}")
+
+
+def f64(a, shape=None) -> np.ndarray:
+    out = np.ascontiguousarray(a, dtype=np.float64)
+    if shape is not None:
+        out = out.reshape(shape)
+    return out
+
+
+class Context:
+    """ort_ctx: one per (host thread, GPU)."""
+
+    def __init__(self, device: int = 0, stream: Optional[int] = None):
+        self.lib = load()
+        h = C.c_void_p()
+        check(self.lib.ort_ctx_create(int(device), C.c_void_p(stream) if stream else None, C.byref(h)))
+        self.h = h
+        self.device = int(device)
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.lib.ort_ctx_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def synchronize(self):
+        check(self.lib.ort_ctx_synchronize(self.h))
+
+    def set_stream(self, stream: int):
+        check(self.lib.ort_ctx_set_stream(self.h, C.c_void_p(stream)))
+
+    def timer_start(self):
+        check(self.lib.ort_ctx_timer_start(self.h))
+
+    def timer_stop(self) -> float:
+        ms = C.c_float()
+        check(self.lib.ort_ctx_timer_stop(self.h, C.byref(ms)))
+        return float(ms.value)
+
+    def device_info(self) -> dict:
+        name = C.create_string_buffer(256)
+        cus, mhz, mem = C.c_int(), C.c_int(), C.c_int64()
+        check(self.lib.ort_ctx_device_info(self.h, name, 256, C.byref(cus), C.byref(mhz), C.byref(mem)))
+        return {"name": name.value.decode(), "cus": cus.value, "clock_mhz": mhz.value, "mem_bytes": mem.value}
+
+
+class DeviceSystem:
+    """ort_system: device-resident batch of prescriptions (R, t, n, K, coef)."""
+
+    def __init__(self, ctx: Context, R, t, n, K=None, coef=None):
+        R = np.atleast_2d(f64(R))
+        t = np.atleast_2d(f64(t))
+        n = np.atleast_2d(f64(n))
+        nsys, rows = R.shape
+        if t.shape != R.shape or n.shape != R.shape:
+            raise ValueError("R, t, n must have the same shape [nsys][rows]")
+        Kp = None
+        if K is not None:
+            K = np.atleast_2d(f64(K))
+            if K.shape != R.shape:
+                raise ValueError("K must match R")
+            Kp = K
+        ncoef = 0
+        cp = None
+        if coef is not None:
+            coef = f64(coef)
+            if coef.ndim == 2:
+                coef = coef[None, :, :]
+            if coef.shape[:2] != (nsys, rows):
+                raise ValueError("coef must be [nsys][rows][ncoef]")
+            ncoef = coef.shape[2]
+            cp = np.ascontiguousarray(coef)
+        self.ctx = ctx
+        self.nsys, self.rows, self.ncoef = nsys, rows, ncoef
+        self._keep = (R, t, n, Kp, cp)
+        h = C.c_void_p()
+        check(ctx.lib.ort_system_create(ctx.h, nsys, rows, ptr(R), ptr(t), ptr(n), ptr(Kp), ptr(cp), ncoef, C.byref(h)))
+        self.h = h
+
+    def close(self):
+        if getattr(self, "h", None) and getattr(self.ctx, "h", None):
+            self.ctx.lib.ort_system_destroy(self.h)
+        self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def make_bundles(specs) -> "C.Array[ort_bundle]":
+    """specs: iterable of dicts with the ort_bundle fields."""
+    specs = list(specs)
+    arr = (ort_bundle * len(specs))()
+    for i, s in enumerate(specs):
+        b = arr[i]
+        b.system = int(s.get("system", 0))
+        b.stop = int(s.get("stop", 0))
+        b.U = float(s.get("U", 0.0))
+        b.V = float(s.get("V", 0.0))
+        b.a_stop = float(s.get("a_stop", np.inf))
+        b.hprime = float(s.get("hprime", 0.0))
+        b.ybar = float(s.get("ybar", 0.0))
+        b.z0 = float(s.get("z0", 1.0))
+        b.yaxis_off = int(s["yaxis_off"])
+        b.xaxis_off = int(s["xaxis_off"])
+    return arr

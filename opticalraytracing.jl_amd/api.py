@@ -1,0 +1,755 @@
+"""Host-side mirror of the reference's API surface for the ray-trace path.
+
+Same names, argument order and error behaviour as Sagnac/OpticalRayTracing.jl
+(src/OpticalRayTracing.jl:6-50 exports; docstrings src/API.jl), so the parity tests read like
+test/runtests.jl.  Julia dispatches on types; here `raytrace` dispatches on its arguments.
+Everything that is a *trace* (paraxial y-nu, meridional, skew, ABCD, the full_trace grid) is
+executed by an engine on the GPU (engine.HipEngine over the C ABI); what stays here is the
+serial O(rows) host logic the reference also keeps outside its loops: container assembly,
+first-order solve, the Newton drivers of ray aiming.
+
+The reference host language (Julia) is not available in the build container, so this mirror is
+Python; julia/OpticalRayTracingHIP.jl holds the equivalent `ccall` shim.
+All file:line citations are into /root/reference/.
+"""
+from __future__ import annotations
+
+import math
+from dataclasses import dataclass, field
+from fractions import Fraction
+from typing import List, Optional, Sequence, Tuple
+
+import numpy as np
+
+from .engine import Prescription, default_engine
+
+EPS = math.sqrt(np.finfo(np.float64).eps)   # const ϵ = sqrt(eps())      RayTracing.jl:1
+K_RAYS = 22                                 # const k_rays = 22            RayTracing.jl:4
+SPOT_RAYS = 64                              # const spot_rays = 64         RayTracing.jl:7
+LAMBDA = 587.5618e-6                        # const λ                       SeidelAberrations.jl:2
+
+
+class DomainError(ValueError):
+    """Julia's DomainError (PupilSampling.jl:89)."""
+
+
+# marker types (Types.jl:1-19)
+class Tangential: pass
+class Sagittal: pass
+class Skew: pass
+class Marginal: pass
+class Chief: pass
+class Spherical: pass
+class Aspheric: pass
+class RealRay: pass            # also used as the dispatch tag `RealRay`
+class VectorRealRay: pass      # the dispatch tag `Vector{RealRay}`
+
+
+def _eng(engine):
+    return engine if engine is not None else default_engine()
+
+
+# ---------------------------------------------------------------------------------------
+# range: Julia Base `range(a, b, n)` (TwicePrecision) gives the correctly rounded value of
+# a + i (b - a)/(n - 1) with exact end points; exact rational arithmetic restates that.
+# Not pinned at the last ulp by any reference test ("parity unpinned").
+# ---------------------------------------------------------------------------------------
+def linrange(a: float, b: float, n: int) -> np.ndarray:
+    a = float(a); b = float(b)
+    if n == 1:
+        return np.array([a])
+    fa, fb = Fraction(a), Fraction(b)
+    step = (fb - fa) / (n - 1)
+    out = np.array([float(fa + i * step) for i in range(n)], dtype=np.float64)
+    out[0], out[-1] = a, b
+    return out
+
+
+# ---------------------------------------------------------------------------------------
+# containers (Types.jl)
+# ---------------------------------------------------------------------------------------
+class Lens:
+    """Types.jl:77-80; constructor from a surface matrix RayTracing.jl:38-53 (Q19)."""
+
+    def __init__(self, M, n=None):
+        if n is None:
+            surfaces = M
+            Mv = surfaces.M if isinstance(surfaces, Layout) else surfaces
+            if not isinstance(Mv, np.ndarray) or Mv.dtype != np.float64:
+                Mv = np.array(Mv, dtype=np.float64)
+            rows = Mv.shape[0]
+            R, t, nn = Mv[:, 0], Mv[:, 1], Mv[:, 2]
+            t[0] = t[0] if math.isfinite(t[0]) else 0.0          # :42, mutates the input (Q19)
+            L = np.empty((rows, 2))
+            L[:, 0] = t / nn                                      # :43
+            for i in range(rows - 1):
+                L[i, 1] = (nn[i + 1] - nn[i]) / R[i + 1]          # :45
+            if t[-1] == 0.0 or not math.isfinite(t[-1]):          # :47
+                L = L[:-1, :].copy()
+            else:
+                L[-1, 1] = 0.0                                    # :50
+            self.M = L
+            self.n = nn.copy()
+        else:
+            self.M = np.array(M, dtype=np.float64)
+            self.n = np.array(n, dtype=np.float64)
+
+    @property
+    def shape(self):
+        return self.M.shape
+
+    def __getitem__(self, idx):
+        return self.M[idx]
+
+
+class Layout:
+    """Types.jl:82-112.  `p` is a list of coefficient vectors (power series, Horner) or None;
+    an arbitrary closure cannot cross the C ABI."""
+
+    def __init__(self, *args, profile=None, K=None, p=None):
+        if len(args) == 1:
+            M = np.array(args[0].M if isinstance(args[0], Layout) else args[0], dtype=np.float64)
+            if profile is Aspheric and M.shape[1] >= 4:           # Layout{Aspheric}(M) :109
+                R, t, n, Kc = M[:, 0], M[:, 1], M[:, 2], M[:, 3]
+                self._init(R, t, n, Kc, p, Aspheric)
+            else:                                                 # Layout(M) :101-107
+                M = M[:, :3]
+                self._init(M[:, 0], M[:, 1], M[:, 2], np.zeros(M.shape[0]) if K is None else K, p,
+                           Spherical if profile is None else profile)
+        elif len(args) == 3:                                      # Layout(R, t, n) :111-114
+            self._init(*args, np.zeros(len(args[0])), None, Spherical)
+        elif len(args) == 5:                                      # Layout(R, t, n, K, p) :99
+            self._init(*args, Aspheric)
+        else:
+            raise TypeError("Layout(M) | Layout(R, t, n) | Layout(R, t, n, K, p)")
+
+    def _init(self, R, t, n, K, p, profile):
+        self.R = np.array(R, dtype=np.float64)
+        self.t = np.array(t, dtype=np.float64)
+        self.n = np.array(n, dtype=np.float64)
+        self.K = np.zeros(len(self.R)) if K is None or len(K) == 0 else np.array(K, dtype=np.float64)
+        rows = len(self.R)
+        if p is None or len(p) == 0:
+            self.p = [None] * rows                                # fill_poly :27
+        else:
+            self.p = [None if (c is None or len(np.atleast_1d(c)) == 0 or not np.any(np.asarray(c) != 0))
+                      else np.array(c, dtype=np.float64) for c in p]
+        self.profile = profile
+        self.M = np.column_stack([self.R, self.t, self.n, self.K])      # :93
+
+    @property
+    def shape(self):
+        return self.M.shape
+
+    def __getitem__(self, idx):
+        return self.M[idx]
+
+    def coef_table(self) -> Optional[np.ndarray]:
+        nc = max((len(c) for c in self.p if c is not None), default=0)
+        if nc == 0:
+            return None
+        tab = np.zeros((len(self.p), nc))
+        for i, c in enumerate(self.p):
+            if c is not None:
+                tab[i, :len(c)] = c
+        return tab
+
+    def prescription(self) -> Prescription:
+        tab = self.coef_table()
+        return Prescription(self.M[:, 0], self.M[:, 1], self.M[:, 2], self.K,
+                            None if tab is None else tab[None])
+
+
+class TransferMatrix:
+    """Types.jl:73-75; TransferMatrix(lens) TransferMatrix.jl:1-6 (Q20), on the device."""
+
+    def __init__(self, arg, engine=None):
+        if isinstance(arg, Lens):
+            self.M = _eng(engine).abcd(arg.M[:, 0], arg.M[:, 1])[0]
+        else:
+            self.M = np.array(arg, dtype=np.float64).reshape(2, 2)
+
+    def __getitem__(self, idx):
+        return self.M[idx]
+
+    def __matmul__(self, v):
+        return self.M @ np.asarray(v, dtype=np.float64)
+
+
+class ParaxialRay:
+    """Types.jl:29-51."""
+
+    def __init__(self, kind, ynu, tau, n):
+        ynu = np.array(ynu, dtype=np.float64)
+        y, nu = ynu[:, 0].copy(), ynu[:, 1].copy()
+        n = np.append(np.asarray(n, dtype=np.float64), n[-1])          # :39
+        m = min(len(nu), len(n))
+        u = nu[:m] / n[:m]                                             # :40
+        yu = np.column_stack([y[:m], u])
+        tau = np.asarray(tau, dtype=np.float64)
+        nn = n[:-2]
+        mt = min(len(tau), len(nn))
+        t = tau[:mt] * nn[:mt]                                         # :42
+        if kind in (Marginal, Chief):
+            t = np.append(t, -y[-2] / u[-2])                           # :44
+        z = np.cumsum(t)                                               # :46
+        z0 = (z.min() - z.max()) * 0.1 if u[0] == 0.0 else -y[1] / u[0]    # :47
+        self.kind = kind
+        self.y, self.n, self.u, self.yu, self.nu, self.ynu = y, n, u, yu, nu, ynu
+        self.z = np.append(z0, z)
+
+
+class RealRayT:
+    """RealRay{T} (Types.jl:53-63)."""
+
+    def __init__(self, kind, y, u, yu, n, z):
+        self.kind = kind
+        self.y = np.array(y, dtype=np.float64)
+        self.u = np.array(u, dtype=np.float64)
+        self.yu = np.array(yu, dtype=np.float64)
+        self.n = np.array(n, dtype=np.float64)
+        self.z = np.array(z, dtype=np.float64)
+
+    @classmethod
+    def from_trace(cls, kind, yu, t, n):                               # :61-63
+        yu = np.array(yu, dtype=np.float64)
+        return cls(kind, yu[:, 0], yu[:, 1], yu, n, np.cumsum(t))
+
+
+@dataclass
+class Pupil:                                                           # Types.jl:114-117
+    D: float
+    t: float
+
+
+@dataclass
+class RayBasis:                                                        # Types.jl:65-71
+    marginal: ParaxialRay
+    chief: ParaxialRay
+    H: float
+    a: np.ndarray
+    stop: int
+
+    def __iter__(self):
+        return iter((self.marginal, self.chief))
+
+    def __getitem__(self, i):
+        if i > 1:
+            raise IndexError(i)
+        return (self.marginal, self.chief)[i]
+
+
+@dataclass
+class System:                                                          # Types.jl:119-139
+    f: float
+    EBFD: float
+    EFFD: float
+    N: float
+    FOV: float
+    stop: int
+    EP: Pupil
+    XP: Pupil
+    marginal: ParaxialRay
+    chief: ParaxialRay
+    trace: np.ndarray
+    H: float
+    P1: float
+    P2: float
+    PN: float
+    M: TransferMatrix
+    lens: Lens
+    a: np.ndarray
+    layout: Optional[Layout]
+    kind: type = Layout
+
+
+@dataclass
+class RealRayError:                                                    # Types.jl:184-192
+    x: np.ndarray
+    y: np.ndarray
+    nu: float
+    r: np.ndarray
+    t: np.ndarray
+    H: float
+    RMS: float
+
+
+# ---------------------------------------------------------------------------------------
+# helpers
+# ---------------------------------------------------------------------------------------
+def surface_ray(v):                                                    # RayTracing.jl:34-36
+    return v[1:-1]
+
+
+def reduced_thickness(lens: Lens):                                     # RayTracing.jl:14
+    return lens.M[:, 0]
+
+
+def compute_surfaces(lens: Lens) -> np.ndarray:                        # RayTracing.jl:16-32
+    tau, phi, n = lens.M[:, 0], lens.M[:, 1], lens.n
+    k = len(phi)
+    s = np.empty((k + 1, 3))
+    s[0] = (math.inf, 0.0, n[0])
+    for i in range(1, k):
+        ph = phi[i - 1]
+        R = math.inf if ph == 0.0 else (n[i] - n[i - 1]) / ph
+        s[i] = (R, tau[i] * n[i], n[i])
+    s[-1] = ((n[-1] - n[-2]) / phi[-1], 0.0, n[-1])
+    return s
+
+
+def _as_layout(surfaces) -> Tuple[Prescription, bool, np.ndarray]:
+    """(prescription, layout_mode, n column).  layout_mode reproduces Q16: only a
+    Layout{Aspheric} reaches the K/p method (RayTracing.jl:171-173); everything else runs the
+    plain-matrix method with K = zeros, p = zero."""
+    if isinstance(surfaces, Layout):
+        if surfaces.profile is Aspheric:
+            return surfaces.prescription(), True, surfaces.M[:, 2].copy()
+        M = surfaces.M
+        return Prescription(M[:, 0], M[:, 1], M[:, 2]), False, M[:, 2].copy()
+    M = np.asarray(surfaces, dtype=np.float64)
+    return Prescription(M[:, 0], M[:, 1], M[:, 2]), False, M[:, 2].copy()
+
+
+# ---------------------------------------------------------------------------------------
+# raytrace — all methods (docs API.jl:172-204)
+# ---------------------------------------------------------------------------------------
+def raytrace(*args, clip: bool = False, K=None, p=None, engine=None):
+    a0 = args[0]
+    if isinstance(a0, System):                                         # raytrace(system, ȳ, s)
+        return _raytrace_system(a0, args[1], args[2])
+    if len(args) >= 4 and args[3] is RealRay:                          # (surfaces, y, U, RealRay)
+        return _raytrace_real(a0, args[1], args[2], K=K, p=p, engine=engine)
+    if len(args) >= 6 and args[5] is VectorRealRay:                    # (surfaces, y, x, U, V, Vector{RealRay})
+        return _raytrace_skew(a0, args[1], args[2], args[3], args[4], K=K, p=p, engine=engine)
+    if isinstance(a0, Lens):                                           # (lens, y, ω, [a]; clip)
+        a = args[3] if len(args) > 3 else None
+        return _raytrace_paraxial(a0, args[1], args[2], a, clip, engine)
+    a = args[3] if len(args) > 3 else None                             # (surfaces, y, ω, [a]; clip) :175-178
+    return _raytrace_paraxial(Lens(a0), args[1], args[2], a, clip, engine)
+
+
+def _raytrace_paraxial(lens: Lens, y, w, a, clip, engine):             # RayTracing.jl:127-143
+    tau, phi = lens.M[:, 0], lens.M[:, 1]
+    y_arr = np.atleast_1d(np.asarray(y, dtype=np.float64))
+    rt_y, rt_w = _eng(engine).paraxial(tau, phi, y, w, a, clip)
+    if y_arr.size == 1 and np.ndim(y) == 0 and np.ndim(w) == 0:
+        return ParaxialRay(Tangential, np.column_stack([rt_y[:, 0], rt_w[:, 0]]), tau, lens.n)
+    return [ParaxialRay(Tangential, np.column_stack([rt_y[:, j], rt_w[:, j]]), tau, lens.n)
+            for j in range(rt_y.shape[1])]
+
+
+def _user_prescription(surfaces, K, p) -> Tuple[Prescription, bool]:
+    """Plain-matrix call with explicit K / p keywords (RayTracing.jl:145-146)."""
+    M = np.asarray(surfaces.M if isinstance(surfaces, Layout) else surfaces, dtype=np.float64)
+    tab = None
+    if p is not None:
+        lay = Layout(M[:, 0], M[:, 1], M[:, 2], np.zeros(M.shape[0]) if K is None else K, p)
+        tab = lay.coef_table()
+    return Prescription(M[:, 0], M[:, 1], M[:, 2], K, None if tab is None else tab[None]), False
+
+
+def _raytrace_real(surfaces, y, U, K=None, p=None, engine=None):      # RayTracing.jl:145-173
+    if K is not None or p is not None:
+        pres, layout_mode = _user_prescription(surfaces, K, p)
+        ncol = pres.n[0]
+    else:
+        pres, layout_mode, ncol = _as_layout(surfaces)
+    yo, Uo, ts = _eng(engine).meridional(pres, y, U, layout_mode)
+    if np.ndim(y) == 0 and np.ndim(U) == 0:
+        return RealRayT.from_trace(Tangential, np.column_stack([yo[:, 0], Uo[:, 0]]), ts[:, 0], ncol)
+    return [RealRayT.from_trace(Tangential, np.column_stack([yo[:, j], Uo[:, j]]), ts[:, j], ncol)
+            for j in range(yo.shape[1])]
+
+
+def _raytrace_skew(surfaces, y, x, U, V, K=None, p=None, engine=None):   # PupilSampling.jl:34-65
+    if K is not None or p is not None:
+        pres, _ = _user_prescription(surfaces, K, p)
+    elif isinstance(surfaces, Layout):
+        # a Layout passed positionally is an AbstractMatrix: K, p default to zeros / zero (:35)
+        M = surfaces.M
+        pres = Prescription(M[:, 0], M[:, 1], M[:, 2])
+    else:
+        pres = Prescription.from_matrix(surfaces)
+    xv, yv = _eng(engine).skew(pres, y, x, U, V)
+    if all(np.ndim(v) == 0 for v in (y, x, U, V)):
+        return xv[:, 0], yv[:, 0]
+    return xv, yv
+
+
+def _raytrace_system(system: System, ybar, s) -> RayBasis:            # RayTracing.jl:180-200
+    EP, chief, marginal, H, lens = system.EP, system.chief, system.marginal, system.H, system.lens
+    y = marginal.y[0]
+    EP_O = s - EP.t
+    nu = -y / EP_O
+    nub = ybar / EP_O
+    alpha = y * nu / H
+    beta = y * nub / H
+    marginal_ray = marginal.ynu + alpha * chief.ynu
+    chief_ray = beta * chief.ynu
+    H = nub * y
+    marginal_ray[-1, 0] = 0.0
+    chief_ray[-1, 0] = -H / marginal_ray[-1, 1]
+    tau = reduced_thickness(lens)
+    return RayBasis(ParaxialRay(Marginal, marginal_ray, tau, lens.n),
+                    ParaxialRay(Chief, chief_ray, tau, lens.n), H, system.a, system.stop)
+
+
+# ---------------------------------------------------------------------------------------
+# first-order solve (RayTracing.jl:202-335)
+# ---------------------------------------------------------------------------------------
+def _extend(marginal_ray):                                             # :202-206
+    wf = marginal_ray[-1, 1]
+    yf = marginal_ray[-1, 0] if wf == 0.0 else 0.0
+    return np.vstack([marginal_ray, [yf, wf]])
+
+
+def _trace_marginal_paraxial(lens: Lens, a, w=0.0, engine=None):       # :208-221
+    a = np.asarray(a, dtype=np.float64)
+    rt = _raytrace_paraxial(lens, 1.0, w, a, False, engine)
+    marginal_ray = rt.ynu.copy()
+    y, om = rt.y, rt.nu
+    f = -1.0 / om[-1]
+    EBFD = y[-1] * f
+    sv = a / y[1:]
+    stop = int(np.argmin(sv))                                          # findmin: first minimum (Q22)
+    s = sv[stop]
+    marginal_ray = marginal_ray * s
+    marginal_ray = _extend(marginal_ray)
+    return ParaxialRay(Marginal, marginal_ray, reduced_thickness(lens), lens.n), stop + 1, f, EBFD
+
+
+def _trace_chief_paraxial(lens: Lens, stop: int, marginal: ParaxialRay, hp=-0.5, engine=None):   # :246-263
+    y = surface_ray(marginal.y)
+    ynu = surface_ray(marginal.ynu)
+    y_stop = y[stop - 1]
+    rt = _raytrace_paraxial(lens, 0.0, 1.0, None, False, engine)
+    y2 = rt.y[1:]
+    ynu2 = rt.ynu[1:, :]
+    y2_stop = y2[stop - 1]
+    nub = -marginal.nu[-1] * hp / y[0]
+    chief_ray = np.empty(marginal.ynu.shape)
+    chief_ray[1:-1, :] = nub * (ynu2 - ynu * y2_stop / y_stop)
+    chief_ray[0, :] = (0.0, nub)
+    chief_ray[-1, :] = (hp, chief_ray[-2, 1])
+    return ParaxialRay(Chief, chief_ray, reduced_thickness(lens), lens.n)
+
+
+def _solve(lens: Lens, a, hp: float, engine=None):                     # :302-323
+    a = np.asarray(a, dtype=np.float64)
+    marginal_ray, stop, f, EBFD = _trace_marginal_paraxial(lens, a, engine=engine)
+    chief_ray = _trace_chief_paraxial(lens, stop, marginal_ray, hp, engine=engine)
+    yb = chief_ray.y[1]
+    nub = chief_ray.nu[0]
+    ybp = hp
+    nubp = chief_ray.nu[-1]
+    y = marginal_ray.y[0]
+    ybpb = chief_ray.y[-2]
+    dp = EBFD - f
+    d = (ybp - nubp * f - yb) / nub
+    EFFD = d - f
+    PN = (lens.n[-1] - lens.n[0]) * f
+    EP = Pupil(abs(y) * 2, -yb / nub)
+    H = nub * y
+    XP = Pupil(abs(2 * H / nubp), -ybpb / nubp)
+    N = abs(f / EP.D)
+    FOV = 2 * math.degrees(math.atan(abs(chief_ray.u[0])))
+    trace = np.column_stack([marginal_ray.yu, chief_ray.yu])
+    return dict(f=f, EBFD=EBFD, EFFD=EFFD, N=N, FOV=FOV, stop=stop, EP=EP, XP=XP,
+                marginal=marginal_ray, chief=chief_ray, trace=trace, H=H, P1=d, P2=dp, PN=PN,
+                M=TransferMatrix(lens, engine=engine), lens=lens, a=a)
+
+
+def solve(surfaces, a, hp: float = -0.5, engine=None) -> System:      # :325-335
+    if isinstance(surfaces, Lens):
+        return System(**_solve(surfaces, a, float(hp), engine), layout=None, kind=Lens)
+    if isinstance(surfaces, Layout):
+        return System(**_solve(Lens(surfaces), a, float(hp), engine), layout=surfaces, kind=Layout)
+    if not (isinstance(surfaces, np.ndarray) and surfaces.dtype == np.float64):
+        surfaces = np.array(surfaces, dtype=np.float64)
+    parts = _solve(Lens(surfaces), a, float(hp), engine)               # Lens() mutates surfaces (Q19)
+    return System(**parts, layout=Layout(surfaces), kind=Layout)       # convert(Layout, M) BaseMethods.jl:114
+
+
+def incidences(surfaces, system):                                      # :338-353
+    M = np.asarray(surfaces.M if isinstance(surfaces, Layout) else surfaces, dtype=np.float64)
+    R = M[1:, 0]
+    marginal, chief = system.marginal, system.chief
+    n = marginal.n
+    nu, y = marginal.nu, surface_ray(marginal.y)
+    nub, yb = chief.nu, surface_ray(chief.y)
+    m = min(len(nu), len(n), len(y), len(R))
+    ni = nu[:m] + n[:m] * y[:m] / R[:m]
+    nib = nub[:m] + n[:m] * yb[:m] / R[:m]
+    return np.column_stack([ni, nib, ni / n[:m], nib / n[:m]])
+
+
+# ---------------------------------------------------------------------------------------
+# real-ray aiming (RayTracing.jl:117-125, 223-300): FD-Newton drivers around the device
+# meridional trace.  Each iteration's base ray and its +ϵ neighbour go out as ONE launch.
+# ---------------------------------------------------------------------------------------
+def _mer_pair(pres, layout_mode, ncol, ys, Us, engine):
+    yo, Uo, ts = _eng(engine).meridional(pres, ys, Us, layout_mode)
+    return [RealRayT.from_trace(Tangential, np.column_stack([yo[:, j], Uo[:, j]]), ts[:, j], ncol)
+            for j in range(yo.shape[1])]
+
+
+def trace_marginal_ray(*args, atol: float = EPS, engine=None):
+    if isinstance(args[0], Lens):                                      # paraxial method :208
+        return _trace_marginal_paraxial(args[0], args[1], *(args[2:3]), engine=engine)
+    if isinstance(args[0], System) and len(args) == 1:                 # :242-244
+        return trace_marginal_ray(args[0].layout, args[0], atol=atol, engine=engine)
+    surfaces, system = args[0], args[1]                                # :223-240
+    pres, layout_mode, ncol = _as_layout(surfaces)
+    marginal, stop = system.marginal, system.stop
+    y = marginal.y[0]
+    u = 0.0
+    a_stop = system.a[stop - 1]
+    base, pert = _mer_pair(pres, layout_mode, ncol, [y, y + EPS], [u, u], engine)
+    ray, dy_stop = base, base.y[stop] - a_stop                         # stop_loss :117-120
+    it = 0
+    while abs(dy_stop) > atol:
+        d_y = pert.y[stop] - a_stop                                    # :230
+        y -= dy_stop * EPS / (d_y - dy_stop)                           # :231
+        base, pert = _mer_pair(pres, layout_mode, ncol, [y, y + EPS], [u, u], engine)
+        ray, dy_stop = base, base.y[stop] - a_stop                     # :232
+        it += 1
+        if it > 200:
+            raise RuntimeError("trace_marginal_ray did not converge")
+    z = ray.z.copy()
+    z[-1] = z[-2] - ray.y[-1] / math.tan(ray.u[-1])                    # :234
+    z = np.concatenate([[(z.min() - z.max()) * 0.1], z])               # :235
+    yv = np.append(ray.y, 0.0)                                         # :236
+    uv = np.append(ray.u, ray.u[-1])                                   # :237
+    yu = np.vstack([ray.yu, [0.0, ray.u[-1]]])                         # :238
+    return RealRayT(Marginal, yv, uv, yu, ray.n, z)
+
+
+def trace_chief_ray(*args, atol: float = EPS, engine=None):
+    if isinstance(args[0], Lens):                                      # paraxial method :246
+        return _trace_chief_paraxial(*args, engine=engine)
+    if isinstance(args[0], System) and len(args) == 1:                 # :298-300
+        return trace_chief_ray(args[0].layout, args[0], atol=atol, engine=engine)
+    surfaces, system = args[0], args[1]                                # :265-296
+    chief, marginal = system.chief, system.marginal
+    M = np.asarray(surfaces.M if isinstance(surfaces, Layout) else surfaces, dtype=np.float64)
+    rev_R = -np.concatenate([[math.inf], M[:0:-1, 0]])                 # :267
+    rev_t = M[::-1, 1].copy()                                          # :268
+    rev_n = M[::-1, 2].copy()                                          # :269
+    BFD = marginal.z[-1] - marginal.z[-2]                              # :270
+    rev_t[0] = BFD                                                     # :271
+    if isinstance(surfaces, Layout):                                   # :272-274 (Q17: plain reverse of K, p)
+        rev = Layout(rev_R, rev_t, rev_n, surfaces.K[::-1].copy(), list(surfaces.p[::-1]))
+    else:                                                              # :276
+        rev = Layout(np.column_stack([rev_R, rev_t, rev_n]))
+    pres, layout_mode, ncol = _as_layout(rev)
+    stop = len(rev_R) - system.stop                                    # :278
+    ybp = chief.y[-1]                                                  # :279
+    ubp = -chief.u[-1]                                                 # :280
+    base, pert = _mer_pair(pres, layout_mode, ncol, [ybp, ybp], [ubp, ubp + EPS], engine)
+    ray, y_stop = base, base.y[stop]                                   # stop_loss :122-125
+    it = 0
+    while abs(y_stop) > atol:                                          # :282
+        d_y = pert.y[stop]                                             # :283
+        ubp -= y_stop * EPS / (d_y - y_stop)                           # :284
+        base, pert = _mer_pair(pres, layout_mode, ncol, [ybp, ybp], [ubp, ubp + EPS], engine)
+        ray, y_stop = base, base.y[stop]                               # :285
+        it += 1
+        if it > 200:
+            raise RuntimeError("trace_chief_ray did not converge")
+    yb = np.concatenate([[0.0], ray.y[::-1]])                          # :287
+    yb[-1] = ybp                                                       # :288
+    ub = np.concatenate([-ray.u[::-1], [-ray.u[0]]])                   # :289
+    ybub = np.column_stack([yb, ub])                                   # :290
+    n = M[:, 2].copy()                                                 # :291
+    z = ray.z[-1] - ray.z[::-1]                                        # :292
+    z[0] = -yb[1] / math.tan(ub[0]) + z[1]                             # :293
+    z = np.append(z, z[-1] - yb[-2] / math.tan(ub[-2]))                # :294
+    return RealRayT(Chief, yb, ub, ybub, n, z)
+
+
+def _trace_edge_rays(surfaces, y1, y2, U, stop, a_stop, engine=None, atol: float = EPS):
+    """PupilSampling.jl:67-83 minimises |y_stop ∓ a_stop| with Optim.BFGS (third party, not in
+    the tree, default tolerances).  Restated as the same FD-Newton the reference uses for its
+    other aiming loops, on the signed residual — parity unpinned: no reference
+    test checks y1, y2; the only downstream check is the RMS to ±0.07."""
+    pres, layout_mode, ncol = _as_layout(surfaces)
+    out = []
+    for y0, target in ((y1, a_stop), (y2, -a_stop)):
+        y = y0
+        base, pert = _mer_pair(pres, layout_mode, ncol, [y, y + EPS], [U, U], engine)
+        d = base.y[stop] - target
+        it = 0
+        while abs(d) > atol and it < 100:
+            dd = pert.y[stop] - target
+            y -= d * EPS / (dd - d)
+            base, pert = _mer_pair(pres, layout_mode, ncol, [y, y + EPS], [U, U], engine)
+            d = base.y[stop] - target
+            it += 1
+        if not math.isfinite(d):
+            y = y0                       # isnan(Δ) ? Inf : Δ keeps the start point (:72,78)
+        out.append(y)
+    return out[0], out[1]
+
+
+# ---------------------------------------------------------------------------------------
+# full_trace (PupilSampling.jl:85-163)
+# ---------------------------------------------------------------------------------------
+@dataclass
+class Aiming:
+    """The aiming scalars of PupilSampling.jl:88-114 — the inputs of the device grid stage."""
+    H: float
+    U: float
+    V: float
+    y1: float
+    y2: float
+    y_EP: float
+    hprime: float
+    stop: int
+    a_stop: float
+    focus: float
+    nu: float
+    raybasis: bool = False
+    ybar: float = 0.0
+    z0: float = 1.0
+
+
+def full_trace_aim(surfaces: Layout, system, H: float, focus=None, engine=None) -> Aiming:
+    H = abs(float(H))                                                  # :88
+    if not H <= 1.0:
+        raise DomainError(f"DomainError with {H}: Domain: |H| ≤ 1.0")   # :89
+    if focus is None:
+        focus = system.marginal.z[-1] - system.marginal.z[-2]          # :87
+    stop = system.stop                                                 # :90
+    a_stop = abs(system.a[stop - 1])                                   # :91
+    real_chief = trace_chief_ray(surfaces, system, engine=engine)      # :92
+    real_marginal = trace_marginal_ray(surfaces, system, engine=engine)    # :93
+    EP_t = real_chief.z[0]                                             # :94
+    Ub = real_chief.u[0]                                               # :95
+    U = H * Ub                                                         # :96
+    u = math.tan(U)                                                    # :97
+    y_EP = abs(real_marginal.y[0])                                     # :98
+    y1, y2 = (+y_EP - u * EP_t), (-y_EP - u * EP_t)                    # :99
+    y1, y2 = _trace_edge_rays(surfaces, y1, y2, U, stop, a_stop, engine=engine)   # :100
+    aim = Aiming(H=H, U=U, V=0.0, y1=y1, y2=y2, y_EP=y_EP, hprime=0.0, stop=stop, a_stop=a_stop,
+                 focus=float(focus), nu=float(system.marginal.nu[-1]))
+    if isinstance(system, System):
+        aim.hprime = u * system.f                                      # :103 (Q14)
+    else:
+        aim.hprime = system.chief.y[-1]                                # :105
+        aim.z0 = system.marginal.z[0]                                  # :106
+        ub = system.chief.u[0]                                         # :107
+        aim.ybar = system.chief.y[1] + ub * aim.z0                     # :108
+        aim.raybasis = True
+    return aim
+
+
+def extended_prescription(surfaces: Layout, focus: float) -> Prescription:
+    """[surfaces[:,1:3]; Inf 0 1], t[end-1] = focus, K, p extended (PupilSampling.jl:111-114)."""
+    M = surfaces.M
+    R = np.append(M[:, 0], math.inf)
+    t = np.append(M[:, 1], 0.0)
+    n = np.append(M[:, 2], 1.0)
+    t[-2] = focus
+    K = np.append(surfaces.K, 0.0)
+    tab = surfaces.coef_table()
+    if tab is not None:
+        tab = np.vstack([tab, np.zeros((1, tab.shape[1]))])[None]
+    return Prescription(R, t, n, K, tab)
+
+
+def full_trace_grid(surfaces: Layout, aim: Aiming, k_rays: int = SPOT_RAYS, engine=None) -> RealRayError:
+    """The device stage, PupilSampling.jl:115-146: grid, trace, stop filter, order-preserving
+    append, mirror, ρ, θ, σ — from the aiming scalars."""
+    pres = extended_prescription(surfaces, aim.focus)
+    k2 = k_rays // 2                                                   # :116
+    yax = linrange(aim.y1, aim.y2, k_rays)                             # :121
+    xax = linrange(0.0, aim.y_EP, k2)                                  # :122
+    axes = np.concatenate([yax, xax])
+    bundle = dict(system=0, stop=aim.stop, U=aim.U, V=aim.V, a_stop=aim.a_stop, hprime=aim.hprime,
+                  ybar=aim.ybar, z0=aim.z0, yaxis_off=0, xaxis_off=k_rays)
+    res = _eng(engine).full_trace_grid(pres, [bundle], axes, k_rays, k2, raybasis=aim.raybasis)[0]
+    if res["count"] == 0:
+        raise ValueError("reducing over an empty collection is not allowed")   # maximum(r), :142
+    return RealRayError(res["ex"], res["ey"], aim.nu, res["rho"], res["theta"], aim.H, res["rms"])
+
+
+def full_trace(*args, engine=None) -> RealRayError:
+    if isinstance(args[0], System):                                    # :159-163
+        system = args[0]
+        H = args[1]
+        k_rays = args[2] if len(args) > 2 else SPOT_RAYS
+        focus = args[3] if len(args) > 3 else None
+        surfaces = system.layout
+    else:
+        surfaces, system = args[0], args[1]
+        if not isinstance(surfaces, Layout):
+            surfaces = Layout(surfaces)                                # :154-157
+        if isinstance(system, RayBasis):                               # :149-152
+            rest = args[2:]
+            if rest and isinstance(rest[0], float):
+                H, rest = rest[0], rest[1:]
+            else:
+                H = 1.0
+        else:
+            H, rest = args[2], args[3:]
+        k_rays = rest[0] if len(rest) > 0 else SPOT_RAYS
+        focus = rest[1] if len(rest) > 1 else None
+    aim = full_trace_aim(surfaces, system, H, focus, engine=engine)
+    return full_trace_grid(surfaces, aim, int(k_rays), engine=engine)
+
+
+def wavegrad(err: RealRayError, lam: float = LAMBDA):                 # PupilSampling.jl:165-167
+    return err.x * err.nu / lam, err.y * err.nu / lam
+
+
+# ---------------------------------------------------------------------------------------
+# transfer matrix (TransferMatrix.jl)
+# ---------------------------------------------------------------------------------------
+def _mat(M):
+    if isinstance(M, System):
+        return M.M.M
+    if isinstance(M, TransferMatrix):
+        return M.M
+    return np.asarray(M, dtype=np.float64).reshape(2, 2)
+
+
+def transfer(M, v, tau, tau_p, engine=None):                           # :10-11
+    v = np.asarray(v, dtype=np.float64)
+    out = _eng(engine).abcd_transfer(_mat(M), v, tau, tau_p, reverse=False)
+    return out[0] if v.ndim == 1 else out
+
+
+def reverse_transfer(M, v, tau_p, tau, engine=None):                   # :13-17
+    v = np.asarray(v, dtype=np.float64)
+    out = _eng(engine).abcd_transfer(_mat(M), v, tau, tau_p, reverse=True)
+    return out[0] if v.ndim == 1 else out
+
+
+def flatten(M):                                                        # :19-28
+    M = _mat(M)
+    f = -1.0 / M[1, 0]
+    EFFD = -M[1, 1] * f
+    EBFD = M[0, 0] * f
+    return dict(f=f, EFFD=EFFD, EBFD=EBFD, P1=EFFD + f, P2=EBFD - f)
+
+
+# ---------------------------------------------------------------------------------------
+# small real-ray helpers used by the reference's tests (RayTracing.jl:90-115)
+# ---------------------------------------------------------------------------------------
+def sag(*args):
+    if len(args) == 1:                                                 # :91
+        ray = args[0]
+        return ray.z[-2] - ray.z[-1]
+    real, paraxial = args                                              # :93-95
+    return real.z[-2] - paraxial.z[-2]
+
+
+def surface_to_focus(BFD, *x):                                         # :105
+    return BFD - sag(*x)
+
+
+def transfer_real(ray: RealRayT, t):                                   # :107-115
+    if ray.kind in (Marginal, Chief):
+        return ray.y[-2] + math.tan(ray.u[-2]) * t
+    return ray.y[-1] + math.tan(ray.u[-1]) * t

@@ -1,0 +1,782 @@
+// ort_hip.hip — C ABI (include/ort.h) over the gfx950 kernels of ort_kernels.hpp.
+//
+// Host side only marshals: it derives the per-surface records (the wave-uniform part of
+// the reference loop, src/PupilSampling.jl:1-32, hoisted out of the per-ray work), takes
+// tan() of bundle angles (:38-39), sizes the launch and owns device scratch.  There is no
+// CPU compute path: every entry point ends in a kernel launch or fails.
+//
+// Build: hipcc --offload-arch=gfx950 -O3 -ffp-contract=off -fPIC -shared   (see build.py)
+#include "../../include/ort.h"
+#include "ort_kernels.hpp"
+
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <limits>
+#include <new>
+#include <string>
+#include <vector>
+
+using namespace ort;
+
+namespace {
+
+thread_local std::string g_err;
+
+int fail(int code, const char* fmt, ...)
+{
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    g_err = buf;
+    return code;
+}
+
+#define HIP_TRY(expr)                                                                       \
+    do {                                                                                    \
+        hipError_t e_ = (expr);                                                             \
+        if (e_ != hipSuccess)                                                               \
+            return fail(ORT_EHIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_),    \
+                        __FILE__, __LINE__);                                                \
+    } while (0)
+
+// growable device scratch slot
+struct Scratch {
+    void* p = nullptr;
+    size_t cap = 0;
+    int ensure(size_t bytes)
+    {
+        if (bytes <= cap) return ORT_OK;
+        if (p) { hipError_t e = hipFree(p); (void)e; p = nullptr; cap = 0; }
+        size_t want = bytes + bytes / 8 + 256;
+        hipError_t e = hipMalloc(&p, want);
+        if (e != hipSuccess) { p = nullptr; return fail(ORT_ENOMEM, "hipMalloc(%zu) failed: %s", want, hipGetErrorString(e)); }
+        cap = want;
+        return ORT_OK;
+    }
+    void release() { if (p) { hipError_t e = hipFree(p); (void)e; } p = nullptr; cap = 0; }
+};
+
+enum { SL_IN0 = 0, SL_IN1, SL_IN2, SL_IN3, SL_OUT0, SL_OUT1, SL_OUT2, SL_OUT3, SL_OUT4,
+       SL_BUNDLES, SL_AXES, SL_WEX, SL_WEY, SL_WR, SL_WTH, SL_TCNT, SL_TSX, SL_TSY, SL_TRM,
+       SL_TOFF, SL_TSQ, SL_AGG, SL_RES0, SL_RES1, SL_TAB0, SL_TAB1, SL_TAB2, SL_TAB3, SL_COUNT };
+
+}  // namespace
+
+struct ort_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    bool own_stream = false;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    Scratch slot[SL_COUNT];
+    std::vector<unsigned char> bundle_cache;   // last uploaded DevBundle bytes
+};
+
+struct ort_system {
+    ort_ctx* ctx = nullptr;
+    int nsys = 0, rows = 0, ncoef = 0;
+    SurfRec<double>* rec64 = nullptr;
+    SurfRec<float>* rec32 = nullptr;
+    double* coef64 = nullptr;
+    float* coef32 = nullptr;
+    MerSurf* mer = nullptr;        // [nsys][S]
+    std::vector<double> t_last;    // t[rows-1] per system (meridional ts tail)
+};
+
+namespace {
+
+template <typename T> T sgn_of(T R) { return R > 0 ? T(1) : (R < 0 ? T(-1) : R); }
+
+template <typename T>
+void build_records(int nsys, int rows, int ncoef, const double* R, const double* t, const double* n,
+                   const double* K, const double* coef, std::vector<SurfRec<T>>& out, std::vector<T>& cout)
+{
+    const int S = rows - 1;
+    out.resize((size_t)nsys * S);
+    if (coef && ncoef > 0) {
+        cout.resize((size_t)nsys * rows * ncoef);
+        for (size_t i = 0; i < cout.size(); ++i) cout[i] = (T)coef[i];
+    }
+    for (int s = 0; s < nsys; ++s) {
+        const double* Rs = R + (size_t)s * rows;
+        const double* ts = t + (size_t)s * rows;
+        const double* ns = n + (size_t)s * rows;
+        const double* Ks = K ? K + (size_t)s * rows : nullptr;
+        for (int i = 0; i < S; ++i) {
+            SurfRec<T> r;
+            memset(&r, 0, sizeof r);
+            const T Rv = (T)Rs[i + 1];
+            const T Kv = Ks ? (T)Ks[i + 1] : T(0);
+            r.t = (T)ts[i];
+            r.R = Rv;
+            r.R2 = Rv * Rv;
+            r.sgn = sgn_of<T>(Rv);
+            r.opk = T(1) + Kv;
+            r.eta = (T)ns[i] / (T)ns[i + 1];
+            r.eta2 = r.eta * r.eta;
+            r.K = Kv;
+            r.finite = std::isfinite(Rv) ? 1 : 0;
+            r.invR = r.finite ? T(1) / Rv : T(0);
+            int nc = 0;
+            if (coef && ncoef > 0) {
+                const double* c = coef + ((size_t)s * rows + (i + 1)) * ncoef;
+                for (int j = 0; j < ncoef; ++j) if ((T)c[j] != T(0)) nc = ncoef;   // all-zero row == `zero`
+            }
+            r.ncoef = nc;
+            out[(size_t)s * S + i] = r;
+        }
+    }
+}
+
+template <typename T> struct Sel;
+template <> struct Sel<double> {
+    static const SurfRec<double>* rec(const ort_system* s) { return s->rec64; }
+    static const double* coef(const ort_system* s) { return s->coef64; }
+};
+template <> struct Sel<float> {
+    static const SurfRec<float>* rec(const ort_system* s) { return s->rec32; }
+    static const float* coef(const ort_system* s) { return s->coef32; }
+};
+
+// pick the kernel instantiation
+template <typename T, bool GRID, bool HIST, bool SUMM, bool FT>
+int launch_trace(ort_ctx* ctx, const TraceParams<T>& p, int64_t blocks, unsigned flags)
+{
+    if (blocks <= 0) return ORT_OK;
+    if (blocks > 0x7fffffffLL) return fail(ORT_EINVAL, "launch too large: %lld workgroups", (long long)blocks);
+    const bool fast = flags & ORT_FAST_MATH;
+    const bool lds = !(flags & ORT_NO_LDS);
+    dim3 g((unsigned)blocks), b(kBlock);
+    if (!fast && lds)  hipLaunchKernelGGL((k_trace<T, MATH_IEEE, true,  GRID, HIST, SUMM, FT>), g, b, 0, ctx->stream, p);
+    if (!fast && !lds) hipLaunchKernelGGL((k_trace<T, MATH_IEEE, false, GRID, HIST, SUMM, FT>), g, b, 0, ctx->stream, p);
+    if (fast && lds)   hipLaunchKernelGGL((k_trace<T, MATH_FAST, true,  GRID, HIST, SUMM, FT>), g, b, 0, ctx->stream, p);
+    if (fast && !lds)  hipLaunchKernelGGL((k_trace<T, MATH_FAST, false, GRID, HIST, SUMM, FT>), g, b, 0, ctx->stream, p);
+    HIP_TRY(hipGetLastError());
+    return ORT_OK;
+}
+
+template <typename T, bool GRID>
+int launch_trace_modes(ort_ctx* ctx, const TraceParams<T>& p, int64_t blocks, bool hist, bool summ, unsigned flags)
+{
+    if (hist && summ)  return launch_trace<T, GRID, true, true, false>(ctx, p, blocks, flags);
+    if (hist && !summ) return launch_trace<T, GRID, true, false, false>(ctx, p, blocks, flags);
+    if (!hist && summ) return launch_trace<T, GRID, false, true, false>(ctx, p, blocks, flags);
+    return fail(ORT_EINVAL, "no output requested");
+}
+
+int check_ctx(ort_ctx* ctx)
+{
+    if (!ctx) return fail(ORT_EINVAL, "null context");
+    HIP_TRY(hipSetDevice(ctx->device));
+    return ORT_OK;
+}
+
+int check_sys(ort_ctx* ctx, const ort_system* sys)
+{
+    if (!sys) return fail(ORT_EINVAL, "null system");
+    if (sys->ctx != ctx) return fail(ORT_EINVAL, "system belongs to another context");
+    return ORT_OK;
+}
+
+// copy a host array into a scratch slot (synchronous with respect to the host buffer)
+template <typename T>
+int to_device(ort_ctx* ctx, int slot, const T* host, size_t count, const T** dev)
+{
+    int rc = ctx->slot[slot].ensure(count * sizeof(T));
+    if (rc) return rc;
+    HIP_TRY(hipMemcpyAsync(ctx->slot[slot].p, host, count * sizeof(T), hipMemcpyHostToDevice, ctx->stream));
+    *dev = static_cast<const T*>(ctx->slot[slot].p);
+    return ORT_OK;
+}
+
+template <typename T>
+int dev_out(ort_ctx* ctx, int slot, size_t count, T** dev)
+{
+    int rc = ctx->slot[slot].ensure(count * sizeof(T));
+    if (rc) return rc;
+    *dev = static_cast<T*>(ctx->slot[slot].p);
+    return ORT_OK;
+}
+
+template <typename T>
+int from_device(ort_ctx* ctx, T* host, const T* dev, size_t count)
+{
+    HIP_TRY(hipMemcpyAsync(host, dev, count * sizeof(T), hipMemcpyDeviceToHost, ctx->stream));
+    return ORT_OK;
+}
+
+template <typename T>
+int upload_bundles(ort_ctx* ctx, const ort_system* sys, int nb, const ort_bundle* bundles, int ny, int nx,
+                   int64_t axes_len, unsigned flags, const DevBundle<T>** dev)
+{
+    std::vector<DevBundle<T>> hb((size_t)nb);
+    const int S = sys->rows - 1;
+    for (int b = 0; b < nb; ++b) {
+        const ort_bundle& s = bundles[b];
+        if (s.system < 0 || s.system >= sys->nsys) return fail(ORT_EINVAL, "bundle %d: system %d out of range", b, s.system);
+        if (s.stop < 0 || s.stop > S) return fail(ORT_EINVAL, "bundle %d: stop %d out of range 0..%d", b, s.stop, S);
+        if (s.yaxis_off < 0 || s.yaxis_off + ny > axes_len || s.xaxis_off < 0 || s.xaxis_off + nx > axes_len)
+            return fail(ORT_EINVAL, "bundle %d: axis offsets outside the axes buffer", b);
+        DevBundle<T> d;
+        memset(&d, 0, sizeof d);
+        d.system = s.system;
+        d.stop = s.stop - 1;
+        d.u = (T)std::tan(s.U);           // PupilSampling.jl:38
+        d.v = (T)std::tan(s.V);           // :39
+        d.a_stop = (T)s.a_stop;
+        d.hprime = (T)s.hprime;
+        d.ybar = (T)s.ybar;
+        d.z0 = (T)s.z0;
+        d.yoff = s.yaxis_off;
+        d.xoff = s.xaxis_off;
+        hb[b] = d;
+    }
+    (void)flags;
+    const size_t bytes = hb.size() * sizeof(DevBundle<T>);
+    const unsigned char* raw = reinterpret_cast<const unsigned char*>(hb.data());
+    const bool same = ctx->bundle_cache.size() == bytes && ctx->slot[SL_BUNDLES].p &&
+                      memcmp(ctx->bundle_cache.data(), raw, bytes) == 0;
+    if (!same) {
+        int rc = ctx->slot[SL_BUNDLES].ensure(bytes);
+        if (rc) return rc;
+        // the staging vector dies with this frame: finish the copy before returning
+        HIP_TRY(hipMemcpyAsync(ctx->slot[SL_BUNDLES].p, raw, bytes, hipMemcpyHostToDevice, ctx->stream));
+        HIP_TRY(hipStreamSynchronize(ctx->stream));
+        ctx->bundle_cache.assign(raw, raw + bytes);
+    }
+    *dev = static_cast<const DevBundle<T>*>(ctx->slot[SL_BUNDLES].p);
+    return ORT_OK;
+}
+
+template <typename T, typename OUT>
+int trace_grid_impl(ort_ctx* ctx, const ort_system* sys, int nb, const ort_bundle* bundles,
+                    const T* axes, int64_t axes_len, int ny, int nx, const OUT* out, unsigned flags)
+{
+    int rc = check_ctx(ctx); if (rc) return rc;
+    rc = check_sys(ctx, sys); if (rc) return rc;
+    if (nb <= 0 || !bundles || !axes || ny <= 0 || nx <= 0 || !out) return fail(ORT_EINVAL, "bad grid arguments");
+    const int S = sys->rows - 1;
+    const int64_t rpb = (int64_t)ny * nx;
+    const int64_t N = rpb * nb;
+    const bool hist = out->xv && out->yv;
+    const bool summ = out->xf || out->yf || out->xs || out->ys || out->status;
+    if (!hist && !summ) return fail(ORT_EINVAL, "no output requested");
+    if (hist && out->ld < N) return fail(ORT_EINVAL, "ld %lld < rays %lld", (long long)out->ld, (long long)N);
+    if ((out->xs || out->ys)) for (int b = 0; b < nb; ++b) if (bundles[b].stop <= 0) return fail(ORT_EINVAL, "xs/ys requested but bundle %d has no stop", b);
+    const bool devp = flags & ORT_DEVICE_PTRS;
+
+    TraceParams<T> p;
+    memset(&p, 0, sizeof p);
+    p.recs = Sel<T>::rec(sys); p.coefs = Sel<T>::coef(sys); p.S = S; p.ncoef = sys->ncoef;
+    rc = upload_bundles<T>(ctx, sys, nb, bundles, ny, nx, axes_len, flags, &p.bundles); if (rc) return rc;
+    p.ny = ny; p.nx = nx; p.rpb = rpb; p.tiles_per_bundle = (int)((rpb + kTile - 1) / kTile);
+    p.raybasis = (flags & ORT_RAYBASIS) ? 1 : 0;
+    const int64_t blocks = (int64_t)nb * p.tiles_per_bundle;
+
+    if (devp) {
+        p.axes = axes;
+        p.xv = out->xv; p.yv = out->yv; p.ld = out->ld;
+        p.xf = out->xf; p.yf = out->yf; p.xs = out->xs; p.ys = out->ys; p.status = out->status;
+        return launch_trace_modes<T, true>(ctx, p, blocks, hist, summ, flags);
+    }
+    // host buffers: stage through context scratch
+    rc = to_device<T>(ctx, SL_AXES, axes, (size_t)axes_len, &p.axes); if (rc) return rc;
+    T *dxv = nullptr, *dyv = nullptr;
+    if (hist) {
+        rc = dev_out<T>(ctx, SL_OUT0, (size_t)S * N, &dxv); if (rc) return rc;
+        rc = dev_out<T>(ctx, SL_OUT1, (size_t)S * N, &dyv); if (rc) return rc;
+        p.xv = dxv; p.yv = dyv; p.ld = N;
+    }
+    T* dsum = nullptr; int32_t* dst = nullptr;
+    if (summ) {
+        rc = dev_out<T>(ctx, SL_OUT2, (size_t)4 * N, &dsum); if (rc) return rc;
+        rc = dev_out<int32_t>(ctx, SL_OUT3, (size_t)N, &dst); if (rc) return rc;
+        p.xf = dsum; p.yf = dsum + N;
+        bool have_stop = true;
+        for (int b = 0; b < nb; ++b) have_stop = have_stop && bundles[b].stop > 0;
+        if (have_stop) { p.xs = dsum + 2 * N; p.ys = dsum + 3 * N; }
+        p.status = dst;
+    }
+    rc = launch_trace_modes<T, true>(ctx, p, blocks, hist, summ, flags); if (rc) return rc;
+    if (hist) {
+        if (out->ld == N) {
+            rc = from_device<T>(ctx, out->xv, dxv, (size_t)S * N); if (rc) return rc;
+            rc = from_device<T>(ctx, out->yv, dyv, (size_t)S * N); if (rc) return rc;
+        } else {
+            HIP_TRY(hipMemcpy2DAsync(out->xv, out->ld * sizeof(T), dxv, N * sizeof(T), N * sizeof(T), S, hipMemcpyDeviceToHost, ctx->stream));
+            HIP_TRY(hipMemcpy2DAsync(out->yv, out->ld * sizeof(T), dyv, N * sizeof(T), N * sizeof(T), S, hipMemcpyDeviceToHost, ctx->stream));
+        }
+    }
+    if (summ) {
+        if (out->xf) { rc = from_device<T>(ctx, out->xf, p.xf, (size_t)N); if (rc) return rc; }
+        if (out->yf) { rc = from_device<T>(ctx, out->yf, p.yf, (size_t)N); if (rc) return rc; }
+        if (out->xs && p.xs) { rc = from_device<T>(ctx, out->xs, p.xs, (size_t)N); if (rc) return rc; }
+        if (out->ys && p.ys) { rc = from_device<T>(ctx, out->ys, p.ys, (size_t)N); if (rc) return rc; }
+        if (out->status) { rc = from_device<int32_t>(ctx, out->status, dst, (size_t)N); if (rc) return rc; }
+    }
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    return ORT_OK;
+}
+
+template <typename T>
+int trace_list_impl(ort_ctx* ctx, const ort_system* sys, int isys, int64_t nrays,
+                    const T* y, const T* x, const T* U, const T* V,
+                    T* xv, T* yv, int64_t ld, int32_t* status, unsigned flags)
+{
+    int rc = check_ctx(ctx); if (rc) return rc;
+    rc = check_sys(ctx, sys); if (rc) return rc;
+    if (isys < 0 || isys >= sys->nsys) return fail(ORT_EINVAL, "system index %d out of range", isys);
+    if (nrays < 0 || !y || !x || !U || !V) return fail(ORT_EINVAL, "bad ray list arguments");
+    if (nrays == 0) return ORT_OK;
+    const int S = sys->rows - 1;
+    const bool hist = xv && yv;
+    const bool summ = status != nullptr;
+    if (!hist && !summ) return fail(ORT_EINVAL, "no output requested");
+    if (hist && ld < nrays) return fail(ORT_EINVAL, "ld %lld < rays %lld", (long long)ld, (long long)nrays);
+    TraceParams<T> p;
+    memset(&p, 0, sizeof p);
+    p.recs = Sel<T>::rec(sys); p.coefs = Sel<T>::coef(sys); p.S = S; p.ncoef = sys->ncoef;
+    p.nrays = nrays; p.isys = isys; p.slopes_given = (flags & ORT_INPUT_SLOPES) ? 1 : 0;
+    const int64_t blocks = (nrays + kTile - 1) / kTile;
+    if (flags & ORT_DEVICE_PTRS) {
+        p.ly = y; p.lx = x; p.lU = U; p.lV = V;
+        p.xv = xv; p.yv = yv; p.ld = ld; p.status = status;
+        return launch_trace_modes<T, false>(ctx, p, blocks, hist, summ, flags);
+    }
+    rc = to_device<T>(ctx, SL_IN0, y, (size_t)nrays, &p.ly); if (rc) return rc;
+    rc = to_device<T>(ctx, SL_IN1, x, (size_t)nrays, &p.lx); if (rc) return rc;
+    rc = to_device<T>(ctx, SL_IN2, U, (size_t)nrays, &p.lU); if (rc) return rc;
+    rc = to_device<T>(ctx, SL_IN3, V, (size_t)nrays, &p.lV); if (rc) return rc;
+    T *dxv = nullptr, *dyv = nullptr; int32_t* dst = nullptr;
+    if (hist) {
+        rc = dev_out<T>(ctx, SL_OUT0, (size_t)S * nrays, &dxv); if (rc) return rc;
+        rc = dev_out<T>(ctx, SL_OUT1, (size_t)S * nrays, &dyv); if (rc) return rc;
+        p.xv = dxv; p.yv = dyv; p.ld = nrays;
+    }
+    if (summ) { rc = dev_out<int32_t>(ctx, SL_OUT3, (size_t)nrays, &dst); if (rc) return rc; p.status = dst; }
+    rc = launch_trace_modes<T, false>(ctx, p, blocks, hist, summ, flags); if (rc) return rc;
+    if (hist) {
+        HIP_TRY(hipMemcpy2DAsync(xv, ld * sizeof(T), dxv, nrays * sizeof(T), nrays * sizeof(T), S, hipMemcpyDeviceToHost, ctx->stream));
+        HIP_TRY(hipMemcpy2DAsync(yv, ld * sizeof(T), dyv, nrays * sizeof(T), nrays * sizeof(T), S, hipMemcpyDeviceToHost, ctx->stream));
+    }
+    if (summ) { rc = from_device<int32_t>(ctx, status, dst, (size_t)nrays); if (rc) return rc; }
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    return ORT_OK;
+}
+
+}  // namespace
+
+// ======================================================================================
+extern "C" {
+
+int ort_version(void) { return ORT_VERSION; }
+const char* ort_last_error(void) { return g_err.c_str(); }
+
+int ort_ctx_create(int device, void* stream, ort_ctx** out)
+{
+    if (!out) return fail(ORT_EINVAL, "null out");
+    *out = nullptr;
+    int count = 0;
+    hipError_t e = hipGetDeviceCount(&count);
+    if (e != hipSuccess || count <= 0)
+        return fail(ORT_EHIP, "no HIP device available (%s); this engine has no CPU fallback",
+                    e == hipSuccess ? "device count is 0" : hipGetErrorString(e));
+    if (device < 0 || device >= count) return fail(ORT_EINVAL, "device %d out of range (0..%d)", device, count - 1);
+    HIP_TRY(hipSetDevice(device));
+    hipDeviceProp_t prop;
+    HIP_TRY(hipGetDeviceProperties(&prop, device));
+    if (strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+        return fail(ORT_EHIP, "device %d is %s; this library carries gfx950 code only", device, prop.gcnArchName);
+    ort_ctx* c = new (std::nothrow) ort_ctx();
+    if (!c) return fail(ORT_ENOMEM, "out of host memory");
+    c->device = device;
+    if (stream) { c->stream = static_cast<hipStream_t>(stream); c->own_stream = false; }
+    else {
+        hipError_t es = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
+        if (es != hipSuccess) { delete c; return fail(ORT_EHIP, "hipStreamCreate failed: %s", hipGetErrorString(es)); }
+        c->own_stream = true;
+    }
+    hipError_t e0 = hipEventCreate(&c->ev0), e1 = hipEventCreate(&c->ev1);
+    if (e0 != hipSuccess || e1 != hipSuccess) { delete c; return fail(ORT_EHIP, "hipEventCreate failed"); }
+    *out = c;
+    return ORT_OK;
+}
+
+int ort_ctx_destroy(ort_ctx* ctx)
+{
+    if (!ctx) return ORT_OK;
+    hipError_t e = hipSetDevice(ctx->device); (void)e;
+    e = hipStreamSynchronize(ctx->stream); (void)e;
+    for (auto& s : ctx->slot) s.release();
+    if (ctx->ev0) { e = hipEventDestroy(ctx->ev0); (void)e; }
+    if (ctx->ev1) { e = hipEventDestroy(ctx->ev1); (void)e; }
+    if (ctx->own_stream && ctx->stream) { e = hipStreamDestroy(ctx->stream); (void)e; }
+    delete ctx;
+    return ORT_OK;
+}
+
+int ort_ctx_set_stream(ort_ctx* ctx, void* stream)
+{
+    int rc = check_ctx(ctx); if (rc) return rc;
+    if (!stream) return fail(ORT_EINVAL, "null stream");
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    if (ctx->own_stream) { HIP_TRY(hipStreamDestroy(ctx->stream)); ctx->own_stream = false; }
+    ctx->stream = static_cast<hipStream_t>(stream);
+    return ORT_OK;
+}
+
+int ort_ctx_synchronize(ort_ctx* ctx)
+{
+    int rc = check_ctx(ctx); if (rc) return rc;
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    return ORT_OK;
+}
+
+int ort_ctx_timer_start(ort_ctx* ctx)
+{
+    int rc = check_ctx(ctx); if (rc) return rc;
+    HIP_TRY(hipEventRecord(ctx->ev0, ctx->stream));
+    return ORT_OK;
+}
+
+int ort_ctx_timer_stop(ort_ctx* ctx, float* ms)
+{
+    int rc = check_ctx(ctx); if (rc) return rc;
+    if (!ms) return fail(ORT_EINVAL, "null ms");
+    HIP_TRY(hipEventRecord(ctx->ev1, ctx->stream));
+    HIP_TRY(hipEventSynchronize(ctx->ev1));
+    HIP_TRY(hipEventElapsedTime(ms, ctx->ev0, ctx->ev1));
+    return ORT_OK;
+}
+
+int ort_ctx_device_info(ort_ctx* ctx, char* name, int name_len, int* cus, int* clock_mhz, int64_t* mem_bytes)
+{
+    int rc = check_ctx(ctx); if (rc) return rc;
+    hipDeviceProp_t prop;
+    HIP_TRY(hipGetDeviceProperties(&prop, ctx->device));
+    if (name && name_len > 0) { snprintf(name, (size_t)name_len, "%s (%s)", prop.name, prop.gcnArchName); }
+    if (cus) *cus = prop.multiProcessorCount;
+    if (clock_mhz) *clock_mhz = prop.clockRate / 1000;
+    if (mem_bytes) *mem_bytes = (int64_t)prop.totalGlobalMem;
+    return ORT_OK;
+}
+
+// --------------------------------------------------------------------------------------
+int ort_system_create(ort_ctx* ctx, int nsys, int rows, const double* R, const double* t, const double* n,
+                      const double* K, const double* coef, int ncoef, ort_system** out)
+{
+    int rc = check_ctx(ctx); if (rc) return rc;
+    if (!out) return fail(ORT_EINVAL, "null out");
+    *out = nullptr;
+    if (nsys <= 0 || !R || !t || !n) return fail(ORT_EINVAL, "bad system arguments");
+    if (rows < 2 || rows > ORT_MAX_ROWS) return fail(ORT_EINVAL, "rows %d outside 2..%d", rows, ORT_MAX_ROWS);
+    if (ncoef < 0 || ncoef > ORT_MAX_NCOEF) return fail(ORT_EINVAL, "ncoef %d outside 0..%d", ncoef, ORT_MAX_NCOEF);
+    if (!coef) ncoef = 0;
+    if (ncoef == 0) coef = nullptr;
+    const int S = rows - 1;
+    std::vector<SurfRec<double>> r64; std::vector<double> c64;
+    std::vector<SurfRec<float>> r32; std::vector<float> c32;
+    build_records<double>(nsys, rows, ncoef, R, t, n, K, coef, r64, c64);
+    build_records<float>(nsys, rows, ncoef, R, t, n, K, coef, r32, c32);
+    std::vector<MerSurf> mer((size_t)nsys * S);
+    ort_system* sys = new (std::nothrow) ort_system();
+    if (!sys) return fail(ORT_ENOMEM, "out of host memory");
+    sys->t_last.resize((size_t)nsys);
+    for (int s = 0; s < nsys; ++s) {
+        for (int i = 0; i < S; ++i) {
+            const SurfRec<double>& r = r64[(size_t)s * S + i];
+            MerSurf m;
+            memset(&m, 0, sizeof m);
+            m.t = r.t; m.R = r.R; m.sgn = r.sgn; m.K = r.K;
+            m.n1 = n[(size_t)s * rows + i]; m.n2 = n[(size_t)s * rows + i + 1];
+            m.finite = r.finite; m.ncoef = r.ncoef;
+            mer[(size_t)s * S + i] = m;
+        }
+        sys->t_last[(size_t)s] = t[(size_t)s * rows + rows - 1];
+    }
+    sys->ctx = ctx; sys->nsys = nsys; sys->rows = rows; sys->ncoef = ncoef;
+    auto up = [&](void** dst, const void* src, size_t bytes) -> int {
+        HIP_TRY(hipMalloc(dst, bytes));
+        HIP_TRY(hipMemcpy(*dst, src, bytes, hipMemcpyHostToDevice));
+        return ORT_OK;
+    };
+    rc = up((void**)&sys->rec64, r64.data(), r64.size() * sizeof(SurfRec<double>));
+    if (!rc) rc = up((void**)&sys->rec32, r32.data(), r32.size() * sizeof(SurfRec<float>));
+    if (!rc) rc = up((void**)&sys->mer, mer.data(), mer.size() * sizeof(MerSurf));
+    if (!rc && ncoef > 0) rc = up((void**)&sys->coef64, c64.data(), c64.size() * sizeof(double));
+    if (!rc && ncoef > 0) rc = up((void**)&sys->coef32, c32.data(), c32.size() * sizeof(float));
+    if (rc) { ort_system_destroy(sys); return rc; }
+    *out = sys;
+    return ORT_OK;
+}
+
+int ort_system_destroy(ort_system* sys)
+{
+    if (!sys) return ORT_OK;
+    hipError_t e;
+    if (sys->ctx) { e = hipSetDevice(sys->ctx->device); (void)e; e = hipStreamSynchronize(sys->ctx->stream); (void)e; }
+    if (sys->rec64) { e = hipFree(sys->rec64); (void)e; }
+    if (sys->rec32) { e = hipFree(sys->rec32); (void)e; }
+    if (sys->mer) { e = hipFree(sys->mer); (void)e; }
+    if (sys->coef64) { e = hipFree(sys->coef64); (void)e; }
+    if (sys->coef32) { e = hipFree(sys->coef32); (void)e; }
+    delete sys;
+    return ORT_OK;
+}
+
+int ort_system_rows(const ort_system* sys) { return sys ? sys->rows : fail(ORT_EINVAL, "null system"); }
+int ort_system_count(const ort_system* sys) { return sys ? sys->nsys : fail(ORT_EINVAL, "null system"); }
+
+// --------------------------------------------------------------------------------------
+int ort_trace_skew_f64(ort_ctx* ctx, const ort_system* sys, int isys, int64_t nrays,
+                       const double* y, const double* x, const double* U, const double* V,
+                       double* xv, double* yv, int64_t ld, int32_t* status, unsigned flags)
+{
+    return trace_list_impl<double>(ctx, sys, isys, nrays, y, x, U, V, xv, yv, ld, status, flags);
+}
+
+int ort_trace_skew_f32(ort_ctx* ctx, const ort_system* sys, int isys, int64_t nrays,
+                       const float* y, const float* x, const float* U, const float* V,
+                       float* xv, float* yv, int64_t ld, int32_t* status, unsigned flags)
+{
+    return trace_list_impl<float>(ctx, sys, isys, nrays, y, x, U, V, xv, yv, ld, status, flags);
+}
+
+int ort_trace_grid_f64(ort_ctx* ctx, const ort_system* sys, int nb, const ort_bundle* bundles,
+                       const double* axes, int64_t axes_len, int ny, int nx,
+                       const ort_grid_out_f64* out, unsigned flags)
+{
+    return trace_grid_impl<double, ort_grid_out_f64>(ctx, sys, nb, bundles, axes, axes_len, ny, nx, out, flags);
+}
+
+int ort_trace_grid_f32(ort_ctx* ctx, const ort_system* sys, int nb, const ort_bundle* bundles,
+                       const float* axes, int64_t axes_len, int ny, int nx,
+                       const ort_grid_out_f32* out, unsigned flags)
+{
+    return trace_grid_impl<float, ort_grid_out_f32>(ctx, sys, nb, bundles, axes, axes_len, ny, nx, out, flags);
+}
+
+// --------------------------------------------------------------------------------------
+int ort_full_trace_f64(ort_ctx* ctx, const ort_system* sys, int nb, const ort_bundle* bundles,
+                       const double* axes, int64_t axes_len, int ny, int nx,
+                       double* ex, double* ey, double* rho, double* theta,
+                       int64_t* count, double* rms, unsigned flags)
+{
+    typedef double T;
+    int rc = check_ctx(ctx); if (rc) return rc;
+    rc = check_sys(ctx, sys); if (rc) return rc;
+    if (nb <= 0 || !bundles || !axes || ny <= 0 || nx <= 0 || !ex || !ey || !rho || !theta || !count || !rms)
+        return fail(ORT_EINVAL, "bad full_trace arguments");
+    const int S = sys->rows - 1;
+    for (int b = 0; b < nb; ++b)
+        if (bundles[b].stop <= 0 || bundles[b].stop > S) return fail(ORT_EINVAL, "bundle %d: full_trace needs a stop index in 1..%d", b, S);
+    const int64_t rpb = (int64_t)ny * nx;
+    const int64_t N = rpb * nb;
+    const bool devp = flags & ORT_DEVICE_PTRS;
+
+    TraceParams<T> p;
+    memset(&p, 0, sizeof p);
+    p.recs = sys->rec64; p.coefs = sys->coef64; p.S = S; p.ncoef = sys->ncoef;
+    rc = upload_bundles<T>(ctx, sys, nb, bundles, ny, nx, axes_len, flags, &p.bundles); if (rc) return rc;
+    p.ny = ny; p.nx = nx; p.rpb = rpb; p.tiles_per_bundle = (int)((rpb + kTile - 1) / kTile);
+    p.raybasis = (flags & ORT_RAYBASIS) ? 1 : 0;
+    const int64_t tiles = (int64_t)nb * p.tiles_per_bundle;
+    if (devp) p.axes = axes;
+    else { rc = to_device<T>(ctx, SL_AXES, axes, (size_t)axes_len, &p.axes); if (rc) return rc; }
+
+    rc = dev_out<T>(ctx, SL_WEX, (size_t)N, &p.w_ex); if (rc) return rc;
+    rc = dev_out<T>(ctx, SL_WEY, (size_t)N, &p.w_ey); if (rc) return rc;
+    rc = dev_out<T>(ctx, SL_WR, (size_t)N, &p.w_r); if (rc) return rc;
+    rc = dev_out<T>(ctx, SL_WTH, (size_t)N, &p.w_th); if (rc) return rc;
+    rc = dev_out<int32_t>(ctx, SL_TCNT, (size_t)tiles, &p.tile_cnt); if (rc) return rc;
+    rc = dev_out<double>(ctx, SL_TSX, (size_t)tiles, &p.tile_sx); if (rc) return rc;
+    rc = dev_out<double>(ctx, SL_TSY, (size_t)tiles, &p.tile_sy); if (rc) return rc;
+    rc = dev_out<double>(ctx, SL_TRM, (size_t)tiles, &p.tile_rmax); if (rc) return rc;
+    int64_t* tile_off; double* tile_sq; FtBundleAgg* agg;
+    rc = dev_out<int64_t>(ctx, SL_TOFF, (size_t)tiles, &tile_off); if (rc) return rc;
+    rc = dev_out<double>(ctx, SL_TSQ, (size_t)tiles, &tile_sq); if (rc) return rc;
+    rc = dev_out<FtBundleAgg>(ctx, SL_AGG, (size_t)nb, &agg); if (rc) return rc;
+
+    T *dex = ex, *dey = ey, *drho = rho, *dth = theta; int64_t* dcount = count; double* drms = rms;
+    if (!devp) {
+        rc = dev_out<T>(ctx, SL_OUT0, (size_t)2 * N, &dex); if (rc) return rc;
+        rc = dev_out<T>(ctx, SL_OUT1, (size_t)2 * N, &dey); if (rc) return rc;
+        rc = dev_out<T>(ctx, SL_OUT2, (size_t)2 * N, &drho); if (rc) return rc;
+        rc = dev_out<T>(ctx, SL_OUT4, (size_t)2 * N, &dth); if (rc) return rc;
+        rc = dev_out<int64_t>(ctx, SL_RES0, (size_t)nb, &dcount); if (rc) return rc;
+        rc = dev_out<double>(ctx, SL_RES1, (size_t)nb, &drms); if (rc) return rc;
+    }
+    rc = launch_trace<T, true, false, false, true>(ctx, p, tiles, flags); if (rc) return rc;
+    hipLaunchKernelGGL(k_ft_scan, dim3((unsigned)nb), dim3(kBlock), 0, ctx->stream,
+                       p.tile_cnt, p.tile_sx, p.tile_sy, p.tile_rmax, p.tiles_per_bundle, tile_off, agg);
+    HIP_TRY(hipGetLastError());
+    hipLaunchKernelGGL((k_ft_scatter<T>), dim3((unsigned)tiles), dim3(kBlock), 0, ctx->stream,
+                       p.w_ex, p.w_ey, p.w_r, p.w_th, rpb, p.tiles_per_bundle, tile_off, agg,
+                       dex, dey, drho, dth, tile_sq);
+    HIP_TRY(hipGetLastError());
+    hipLaunchKernelGGL(k_ft_finalize, dim3((unsigned)nb), dim3(kBlock), 0, ctx->stream,
+                       tile_sq, p.tiles_per_bundle, agg, dcount, drms);
+    HIP_TRY(hipGetLastError());
+    if (!devp) {
+        rc = from_device<int64_t>(ctx, count, dcount, (size_t)nb); if (rc) return rc;
+        rc = from_device<double>(ctx, rms, drms, (size_t)nb); if (rc) return rc;
+        HIP_TRY(hipStreamSynchronize(ctx->stream));
+        for (int b = 0; b < nb; ++b) {
+            const size_t off = (size_t)b * 2 * rpb, cnt = (size_t)count[b];
+            if (!cnt) continue;
+            rc = from_device<T>(ctx, ex + off, dex + off, cnt); if (rc) return rc;
+            rc = from_device<T>(ctx, ey + off, dey + off, cnt); if (rc) return rc;
+            rc = from_device<T>(ctx, rho + off, drho + off, cnt); if (rc) return rc;
+            rc = from_device<T>(ctx, theta + off, dth + off, cnt); if (rc) return rc;
+        }
+        HIP_TRY(hipStreamSynchronize(ctx->stream));
+    }
+    return ORT_OK;
+}
+
+// --------------------------------------------------------------------------------------
+int ort_trace_meridional_f64(ort_ctx* ctx, const ort_system* sys, int isys, int64_t nrays,
+                             const double* y, const double* U,
+                             double* y_out, double* U_out, double* ts_out, int64_t ld, unsigned flags)
+{
+    int rc = check_ctx(ctx); if (rc) return rc;
+    rc = check_sys(ctx, sys); if (rc) return rc;
+    if (isys < 0 || isys >= sys->nsys) return fail(ORT_EINVAL, "system index %d out of range", isys);
+    if (nrays < 0 || !y || !U || !y_out || !U_out) return fail(ORT_EINVAL, "bad meridional arguments");
+    if (nrays == 0) return ORT_OK;
+    if (ld < nrays) return fail(ORT_EINVAL, "ld %lld < rays %lld", (long long)ld, (long long)nrays);
+    const int rows = sys->rows, S = rows - 1;
+    const MerSurf* surf = sys->mer + (size_t)isys * S;
+    const double* coefs = sys->coef64 ? sys->coef64 + (size_t)isys * rows * sys->ncoef : nullptr;
+    const int layout = (flags & ORT_LAYOUT_INPUT) ? 1 : 0;
+    const int64_t blocks = (nrays + kBlock - 1) / kBlock;
+    const double t_last = sys->t_last[(size_t)isys];
+    if (flags & ORT_DEVICE_PTRS) {
+        hipLaunchKernelGGL(k_trace_meridional, dim3((unsigned)blocks), dim3(kBlock), 0, ctx->stream,
+                           surf, coefs, S, sys->ncoef, layout, t_last, nrays, y, U, y_out, U_out, ts_out, ld);
+        HIP_TRY(hipGetLastError());
+        return ORT_OK;
+    }
+    const double *dy, *dU; double *oy, *oU, *ots = nullptr;
+    rc = to_device<double>(ctx, SL_IN0, y, (size_t)nrays, &dy); if (rc) return rc;
+    rc = to_device<double>(ctx, SL_IN1, U, (size_t)nrays, &dU); if (rc) return rc;
+    rc = dev_out<double>(ctx, SL_OUT0, (size_t)rows * nrays, &oy); if (rc) return rc;
+    rc = dev_out<double>(ctx, SL_OUT1, (size_t)rows * nrays, &oU); if (rc) return rc;
+    if (ts_out) { rc = dev_out<double>(ctx, SL_OUT2, (size_t)rows * nrays, &ots); if (rc) return rc; }
+    hipLaunchKernelGGL(k_trace_meridional, dim3((unsigned)blocks), dim3(kBlock), 0, ctx->stream,
+                       surf, coefs, S, sys->ncoef, layout, t_last, nrays, dy, dU, oy, oU, ots, nrays);
+    HIP_TRY(hipGetLastError());
+    const size_t w = (size_t)nrays * sizeof(double);
+    HIP_TRY(hipMemcpy2DAsync(y_out, ld * sizeof(double), oy, w, w, rows, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(hipMemcpy2DAsync(U_out, ld * sizeof(double), oU, w, w, rows, hipMemcpyDeviceToHost, ctx->stream));
+    if (ts_out) HIP_TRY(hipMemcpy2DAsync(ts_out, ld * sizeof(double), ots, w, w, rows, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    return ORT_OK;
+}
+
+// --------------------------------------------------------------------------------------
+int ort_trace_paraxial_f64(ort_ctx* ctx, int nlens, int k, const double* tau, const double* phi, const double* a,
+                           int64_t rays_per_lens, const double* y, const double* w,
+                           double* rt_y, double* rt_w, int64_t ld, unsigned flags)
+{
+    int rc = check_ctx(ctx); if (rc) return rc;
+    if (nlens <= 0 || k <= 0 || k > ORT_MAX_ROWS || !tau || !phi || rays_per_lens < 0 || !y || !w || !rt_y || !rt_w)
+        return fail(ORT_EINVAL, "bad paraxial arguments");
+    const int64_t N = (int64_t)nlens * rays_per_lens;
+    if (N == 0) return ORT_OK;
+    if (ld < N) return fail(ORT_EINVAL, "ld %lld < rays %lld", (long long)ld, (long long)N);
+    const int clip = (flags & ORT_CLIP) ? 1 : 0;
+    const int bpl = (int)((rays_per_lens + kBlock - 1) / kBlock);
+    const int64_t blocks = (int64_t)nlens * bpl;
+    if (blocks > 0x7fffffffLL) return fail(ORT_EINVAL, "launch too large");
+    const bool devp = flags & ORT_DEVICE_PTRS;
+    // the lens table is always small host data unless ORT_DEVICE_PTRS says otherwise
+    const double *dtau = tau, *dphi = phi, *da = a, *dy = y, *dw = w;
+    double *oy = rt_y, *ow = rt_w; int64_t old = ld;
+    if (!devp) {
+        rc = to_device<double>(ctx, SL_TAB0, tau, (size_t)nlens * k, &dtau); if (rc) return rc;
+        rc = to_device<double>(ctx, SL_TAB1, phi, (size_t)nlens * k, &dphi); if (rc) return rc;
+        if (a) { rc = to_device<double>(ctx, SL_TAB2, a, (size_t)nlens * k, &da); if (rc) return rc; }
+        rc = to_device<double>(ctx, SL_IN0, y, (size_t)N, &dy); if (rc) return rc;
+        rc = to_device<double>(ctx, SL_IN1, w, (size_t)N, &dw); if (rc) return rc;
+        rc = dev_out<double>(ctx, SL_OUT0, (size_t)(k + 1) * N, &oy); if (rc) return rc;
+        rc = dev_out<double>(ctx, SL_OUT1, (size_t)(k + 1) * N, &ow); if (rc) return rc;
+        old = N;
+    }
+    hipLaunchKernelGGL(k_trace_paraxial, dim3((unsigned)blocks), dim3(kBlock), 0, ctx->stream,
+                       k, dtau, dphi, da, clip, rays_per_lens, bpl, dy, dw, oy, ow, old);
+    HIP_TRY(hipGetLastError());
+    if (!devp) {
+        const size_t wd = (size_t)N * sizeof(double);
+        HIP_TRY(hipMemcpy2DAsync(rt_y, ld * sizeof(double), oy, wd, wd, k + 1, hipMemcpyDeviceToHost, ctx->stream));
+        HIP_TRY(hipMemcpy2DAsync(rt_w, ld * sizeof(double), ow, wd, wd, k + 1, hipMemcpyDeviceToHost, ctx->stream));
+        HIP_TRY(hipStreamSynchronize(ctx->stream));
+    }
+    return ORT_OK;
+}
+
+// --------------------------------------------------------------------------------------
+int ort_abcd_f64(ort_ctx* ctx, int nlens, int k, const double* tau, const double* phi, double* M, unsigned flags)
+{
+    int rc = check_ctx(ctx); if (rc) return rc;
+    if (nlens <= 0 || k <= 0 || !tau || !phi || !M) return fail(ORT_EINVAL, "bad abcd arguments");
+    const bool devp = flags & ORT_DEVICE_PTRS;
+    const double *dtau = tau, *dphi = phi; double* dM = M;
+    if (!devp) {
+        rc = to_device<double>(ctx, SL_TAB0, tau, (size_t)nlens * k, &dtau); if (rc) return rc;
+        rc = to_device<double>(ctx, SL_TAB1, phi, (size_t)nlens * k, &dphi); if (rc) return rc;
+        rc = dev_out<double>(ctx, SL_OUT0, (size_t)nlens * 4, &dM); if (rc) return rc;
+    }
+    const int blocks = (nlens + kBlock - 1) / kBlock;
+    hipLaunchKernelGGL(k_abcd, dim3((unsigned)blocks), dim3(kBlock), 0, ctx->stream, nlens, k, dtau, dphi, dM);
+    HIP_TRY(hipGetLastError());
+    if (!devp) {
+        rc = from_device<double>(ctx, M, dM, (size_t)nlens * 4); if (rc) return rc;
+        HIP_TRY(hipStreamSynchronize(ctx->stream));
+    }
+    return ORT_OK;
+}
+
+static int abcd_apply(ort_ctx* ctx, const double* M, int64_t nv, const double* v, const double* tau,
+                      const double* tau_p, double* out, unsigned flags, int reverse)
+{
+    int rc = check_ctx(ctx); if (rc) return rc;
+    if (!M || nv < 0 || !v || !tau || !tau_p || !out) return fail(ORT_EINVAL, "bad abcd transfer arguments");
+    if (nv == 0) return ORT_OK;
+    const bool devp = flags & ORT_DEVICE_PTRS;
+    const double *dM = M, *dv = v, *dt = tau, *dtp = tau_p; double* dout = out;
+    if (!devp) {
+        rc = to_device<double>(ctx, SL_TAB0, M, 4, &dM); if (rc) return rc;
+        rc = to_device<double>(ctx, SL_IN0, v, (size_t)nv * 2, &dv); if (rc) return rc;
+        rc = to_device<double>(ctx, SL_IN1, tau, (size_t)nv, &dt); if (rc) return rc;
+        rc = to_device<double>(ctx, SL_IN2, tau_p, (size_t)nv, &dtp); if (rc) return rc;
+        rc = dev_out<double>(ctx, SL_OUT0, (size_t)nv * 2, &dout); if (rc) return rc;
+    }
+    const int64_t blocks = (nv + kBlock - 1) / kBlock;
+    hipLaunchKernelGGL(k_abcd_transfer, dim3((unsigned)blocks), dim3(kBlock), 0, ctx->stream, dM, nv, dv, dt, dtp, dout, reverse);
+    HIP_TRY(hipGetLastError());
+    if (!devp) {
+        rc = from_device<double>(ctx, out, dout, (size_t)nv * 2); if (rc) return rc;
+        HIP_TRY(hipStreamSynchronize(ctx->stream));
+    }
+    return ORT_OK;
+}
+
+int ort_abcd_transfer_f64(ort_ctx* ctx, const double* M, int64_t nv, const double* v, const double* tau,
+                          const double* tau_p, double* out, unsigned flags)
+{
+    return abcd_apply(ctx, M, nv, v, tau, tau_p, out, flags, 0);
+}
+
+int ort_abcd_reverse_transfer_f64(ort_ctx* ctx, const double* M, int64_t nv, const double* v, const double* tau_p,
+                                  const double* tau, double* out, unsigned flags)
+{
+    return abcd_apply(ctx, M, nv, v, tau, tau_p, out, flags, 1);
+}
+
+}  // extern "C"

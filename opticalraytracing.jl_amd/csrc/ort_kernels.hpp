@@ -1,0 +1,576 @@
+// ort_kernels.hpp — gfx950 kernels of the batched ray-trace engine.
+//
+// Layout in HBM
+//   surface table   SurfRec<T>[nsys][S]  (+ coef T[nsys][rows][ncoef]); a workgroup copies
+//                   the S records of ITS system into LDS once (<= 5 KiB) — or, with
+//                   USE_LDS = false, indexes global memory with a wave-uniform address so
+//                   the compiler issues scalar loads into SGPRs.
+//   rays            never stored: a bundle's rays are generated from two 1-D axes (L2
+//                   resident) — or read once, coalesced, from SoA lists.
+//   history         T[S][ld] surface-major: lane l of a wave writes 16 B (RPT = 2 adjacent
+//                   rays) at consecutive addresses -> 1 KiB per store instruction.
+//   summary         SoA T[N] x {xf, yf, xs, ys} + int32 status[N].
+// One thread owns RPT = 2 adjacent rays: 16-byte stores and two independent FP64 div/sqrt
+// dependency chains per lane.  Workgroup = 256 threads = 512 rays; a launch is
+// nb * ceil(ny*nx/512) workgroups (>> 256 CUs at every BASELINE config but #1).  Output is
+// streamed once and never re-read, so no XCD-aware remap is needed: the only shared data is
+// the <= 5 KiB table, resident in every XCD's L2.
+#pragma once
+
+#include "ort_device.hpp"
+
+namespace ort {
+
+constexpr int kBlock = 256;
+constexpr int kRPT = 2;
+constexpr int kTile = kBlock * kRPT;
+constexpr int kMaxRows = 64;
+constexpr int kMaxCoef = 12;
+
+template <typename T>
+struct DevBundle {
+    int32_t system;
+    int32_t stop;       // 0-based loop index captured as the stop hit, -1 = none
+    T u, v;             // slopes tan U, tan V (host libm)
+    T a_stop, hprime;
+    T ybar, z0;
+    int64_t yoff, xoff;
+};
+
+typedef double dvec2_t __attribute__((ext_vector_type(2)));
+typedef float fvec2_t __attribute__((ext_vector_type(2)));
+template <typename T> struct Vec2;
+template <> struct Vec2<double> { using type = dvec2_t; };
+template <> struct Vec2<float> { using type = fvec2_t; };
+
+template <typename T>
+struct TraceParams {
+    const SurfRec<T>* recs;     // [nsys][S]
+    const T* coefs;             // [nsys][rows][ncoef] or null
+    int S;                      // loop iterations = rows - 1
+    int ncoef;
+    // grid source
+    const DevBundle<T>* bundles;
+    const T* axes;
+    int ny, nx;
+    int64_t rpb;                // rays per bundle = ny*nx
+    int tiles_per_bundle;
+    // list source
+    const T* ly; const T* lx; const T* lU; const T* lV;
+    int64_t nrays; int isys; int slopes_given;
+    int raybasis;
+    // outputs
+    T* xv; T* yv; int64_t ld;
+    T* xf; T* yf; T* xs; T* ys;
+    int32_t* status;
+    // full_trace dense workspace + tile aggregates
+    T* w_ex; T* w_ey; T* w_r; T* w_th;
+    int32_t* tile_cnt; double* tile_sx; double* tile_sy; double* tile_rmax;
+};
+
+// Two adjacent rays of one lane: one 2*sizeof(T) streaming store when the address allows.
+template <typename T>
+__device__ __forceinline__ void store_pair(T* base, int64_t g, bool two, T a, T b)
+{
+    const bool aligned = (reinterpret_cast<uintptr_t>(base + g) & (2 * sizeof(T) - 1)) == 0;
+    if (two && aligned) {
+        typename Vec2<T>::type v2; v2.x = a; v2.y = b;
+        __builtin_nontemporal_store(v2, reinterpret_cast<typename Vec2<T>::type*>(base + g));
+    } else {
+        __builtin_nontemporal_store(a, base + g);
+        if (two) __builtin_nontemporal_store(b, base + g + 1);
+    }
+}
+
+__device__ __forceinline__ double dev_tan(double a) { return ::tan(a); }
+__device__ __forceinline__ float dev_tan(float a) { return ::tanf(a); }
+__device__ __forceinline__ double dev_hypot(double a, double b) { return ::hypot(a, b); }
+__device__ __forceinline__ float dev_hypot(float a, float b) { return ::hypotf(a, b); }
+__device__ __forceinline__ double dev_atan2(double a, double b) { return ::atan2(a, b); }
+__device__ __forceinline__ float dev_atan2(float a, float b) { return ::atan2f(a, b); }
+
+// ------------------------------------------------------------------------------------
+// The hot kernel.  GRID: rays generated from bundle axes; otherwise read from lists.
+// HIST: write per-surface history.  SUMM: write image/stop hits + status.
+// FT: full_trace epilogue (stop filter, dense workspace, tile aggregates).
+// ------------------------------------------------------------------------------------
+template <typename T, int MATH, bool USE_LDS, bool GRID, bool HIST, bool SUMM, bool FT>
+__global__ __launch_bounds__(kBlock) void k_trace(TraceParams<T> p)
+{
+    __shared__ SurfRec<T> s_rec[USE_LDS ? kMaxRows : 1];
+    __shared__ T s_coef[USE_LDS ? kMaxRows * kMaxCoef : 1];
+    __shared__ int s_wcnt[kBlock / 64];
+    __shared__ double s_wsx[kBlock / 64], s_wsy[kBlock / 64], s_wmax[kBlock / 64];
+
+    const int tid = threadIdx.x;
+    const int S = p.S;
+    int sysid, b = 0;
+    int64_t j0;          // first ray of this thread inside its bundle / list
+    int64_t gbase;       // global index of ray j0
+    int64_t limit;       // rays in this bundle / list
+    if (GRID) {
+        b = blockIdx.x / p.tiles_per_bundle;
+        const int tile = blockIdx.x - b * p.tiles_per_bundle;
+        sysid = p.bundles[b].system;
+        j0 = (int64_t)tile * kTile + (int64_t)tid * kRPT;
+        limit = p.rpb;
+        gbase = (int64_t)b * p.rpb + j0;
+    } else {
+        sysid = p.isys;
+        j0 = (int64_t)blockIdx.x * kTile + (int64_t)tid * kRPT;
+        limit = p.nrays;
+        gbase = j0;
+    }
+    const SurfRec<T>* __restrict__ grec = p.recs + (int64_t)sysid * S;
+    const T* __restrict__ gcoef = p.coefs ? p.coefs + (int64_t)sysid * (S + 1) * p.ncoef : nullptr;
+    const int ncoef = p.ncoef;
+
+    if (USE_LDS) {
+        // stage this system's table: S records of sizeof(SurfRec<T>) bytes, as 16-B words
+        constexpr int kW = sizeof(SurfRec<T>) / 16;
+        const uint4* src = reinterpret_cast<const uint4*>(grec);
+        uint4* dst = reinterpret_cast<uint4*>(s_rec);
+        for (int w = tid; w < S * kW; w += kBlock) dst[w] = src[w];
+        if (gcoef)
+            for (int w = tid; w < S * ncoef; w += kBlock) s_coef[w] = gcoef[ncoef + w];  // rows 1..S
+        __syncthreads();
+    }
+
+    Ray<T> ray[kRPT];
+    bool live[kRPT];
+    int32_t st[kRPT];
+    T xs_[kRPT], ys_[kRPT];
+    int stopi = -1;
+    T hprime = T(0), a_stop = T(0);
+#pragma unroll
+    for (int r = 0; r < kRPT; ++r) {
+        const int64_t j = j0 + r;
+        live[r] = j < limit;
+        const int64_t jj = live[r] ? j : (limit - 1);   // clamp: dead lanes retrace a valid ray
+        T y, x, u, v;
+        if (GRID) {
+            const DevBundle<T>& bd = p.bundles[b];
+            const int iy = (int)(jj / p.nx);
+            const int ix = (int)(jj - (int64_t)iy * p.nx);
+            y = p.axes[bd.yoff + iy];
+            x = p.axes[bd.xoff + ix];
+            if (p.raybasis) {                        // PupilSampling.jl:124-127 (Q8)
+                u = dev_tan((bd.ybar - y) / bd.z0);
+                v = dev_tan(-x / bd.z0);
+            } else {
+                u = bd.u; v = bd.v;
+            }
+            stopi = bd.stop; hprime = bd.hprime; a_stop = bd.a_stop;
+        } else {
+            y = p.ly[jj]; x = p.lx[jj];
+            u = p.lU[jj]; v = p.lV[jj];
+            if (!p.slopes_given) { u = dev_tan(u); v = dev_tan(v); }   // :38-39
+        }
+        ray_init<T, MATH>(ray[r], y, x, u, v);
+        st[r] = S + 1;
+        xs_[r] = T(0); ys_[r] = T(0);
+    }
+    const bool two = live[1];
+
+    for (int i = 0; i < S; ++i) {
+        const SurfRec<T>& rec = USE_LDS ? s_rec[i] : grec[i];
+        const T* cf = USE_LDS ? (s_coef + i * ncoef) : (gcoef ? gcoef + (int64_t)(i + 1) * ncoef : nullptr);
+#pragma unroll
+        for (int r = 0; r < kRPT; ++r) {
+            surface_step<T, MATH>(ray[r], rec, cf);
+            if (SUMM || FT) {
+                if (st[r] == S + 1 && (t_isnan(ray[r].x) || t_isnan(ray[r].y))) st[r] = i + 1;
+                if (i == stopi) { xs_[r] = ray[r].x; ys_[r] = ray[r].y; }
+            }
+        }
+        if (HIST) {
+            if (live[0]) {
+                store_pair<T>(p.xv + (int64_t)i * p.ld, gbase, two, ray[0].x, ray[1].x);
+                store_pair<T>(p.yv + (int64_t)i * p.ld, gbase, two, ray[0].y, ray[1].y);
+            }
+        }
+    }
+
+    if (SUMM) {
+        if (live[0]) {
+            if (p.xf) store_pair<T>(p.xf, gbase, two, ray[0].x, ray[1].x);
+            if (p.yf) store_pair<T>(p.yf, gbase, two, ray[0].y, ray[1].y);
+            if (p.xs) store_pair<T>(p.xs, gbase, two, xs_[0], xs_[1]);
+            if (p.ys) store_pair<T>(p.ys, gbase, two, ys_[0], ys_[1]);
+            if (p.status) {
+#pragma unroll
+                for (int r = 0; r < kRPT; ++r) {
+                    if (!live[r]) continue;
+                    int32_t s = st[r];
+                    if (stopi >= 0) {
+                        const T ri = dev_hypot(xs_[r], ys_[r]);
+                        if (ri > a_stop) s |= (1 << 16);
+                    }
+                    p.status[gbase + r] = s;
+                }
+            }
+        }
+    }
+
+    if (FT) {
+        // stop filter + dense staging (PupilSampling.jl:129-137); survivors are compacted,
+        // in ray order, by k_ft_scatter.
+        int cnt = 0; double sx = 0.0, sy = 0.0, rmax = -1.0;
+        T exv[kRPT], eyv[kRPT], rv[kRPT], thv[kRPT];
+#pragma unroll
+        for (int r = 0; r < kRPT; ++r) {
+            const T xf = ray[r].x, yf = ray[r].y;
+            const T ri = dev_hypot(xs_[r], ys_[r]);                  // :131
+            const bool drop = (ri > a_stop) || t_isnan(xf) || t_isnan(yf) || !live[r];  // :132
+            thv[r] = dev_atan2(ys_[r], xs_[r]);                      // :133
+            eyv[r] = yf - hprime;                                    // :134
+            exv[r] = xf;                                             // :135
+            rv[r] = drop ? T(-1) : ri;                               // :136, -1 marks a dropped ray
+            if (!drop) { ++cnt; sx += (double)exv[r]; sy += (double)eyv[r]; rmax = fmax(rmax, (double)ri); }
+        }
+        if (live[0]) {
+            store_pair<T>(p.w_ex, gbase, two, exv[0], exv[1]);
+            store_pair<T>(p.w_ey, gbase, two, eyv[0], eyv[1]);
+            store_pair<T>(p.w_r, gbase, two, rv[0], rv[1]);
+            store_pair<T>(p.w_th, gbase, two, thv[0], thv[1]);
+        }
+        // tile aggregates: fixed-shape tree -> bitwise reproducible
+        for (int off = 32; off > 0; off >>= 1) {
+            cnt += __shfl_down(cnt, off);
+            sx += __shfl_down(sx, off);
+            sy += __shfl_down(sy, off);
+            rmax = fmax(rmax, __shfl_down(rmax, off));
+        }
+        const int wave = tid >> 6;
+        if ((tid & 63) == 0) { s_wcnt[wave] = cnt; s_wsx[wave] = sx; s_wsy[wave] = sy; s_wmax[wave] = rmax; }
+        __syncthreads();
+        if (tid == 0) {
+            int c = 0; double ax = 0.0, ay = 0.0, mx = -1.0;
+            for (int w = 0; w < kBlock / 64; ++w) { c += s_wcnt[w]; ax += s_wsx[w]; ay += s_wsy[w]; mx = fmax(mx, s_wmax[w]); }
+            p.tile_cnt[blockIdx.x] = c; p.tile_sx[blockIdx.x] = ax; p.tile_sy[blockIdx.x] = ay;
+            p.tile_rmax[blockIdx.x] = mx;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------
+// full_trace, stage B: per bundle, exclusive scan of the tile survivor counts and the
+// bundle aggregates (count, centroid, max radius).  One workgroup per bundle.
+// ------------------------------------------------------------------------------------
+struct FtBundleAgg {
+    int64_t m;        // survivors (first half)
+    double mux, muy;  // centroid of the mirrored set  (PupilSampling.jl:171)
+    double rmax;      // maximum(r)                    (:142)
+    double sq;        // sum of squared deviations (filled by k_ft_finalize)
+};
+
+__global__ __launch_bounds__(kBlock) void k_ft_scan(const int32_t* __restrict__ tile_cnt,
+                                                    const double* __restrict__ tile_sx,
+                                                    const double* __restrict__ tile_sy,
+                                                    const double* __restrict__ tile_rmax,
+                                                    int tiles_per_bundle,
+                                                    int64_t* __restrict__ tile_off,
+                                                    FtBundleAgg* __restrict__ agg)
+{
+    __shared__ int64_t s_w[kBlock / 64];
+    __shared__ int64_t s_carry;
+    __shared__ double s_rx[kBlock], s_ry[kBlock], s_rm[kBlock];
+    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int64_t base = (int64_t)b * tiles_per_bundle;
+    if (tid == 0) s_carry = 0;
+    double ax = 0.0, ay = 0.0, mx = -1.0;
+    __syncthreads();
+    for (int t0 = 0; t0 < tiles_per_bundle; t0 += kBlock) {
+        const int t = t0 + tid;
+        const int64_t c = (t < tiles_per_bundle) ? tile_cnt[base + t] : 0;
+        if (t < tiles_per_bundle) { ax += tile_sx[base + t]; ay += tile_sy[base + t]; mx = fmax(mx, tile_rmax[base + t]); }
+        // inclusive wave scan
+        int64_t v = c;
+        for (int off = 1; off < 64; off <<= 1) {
+            const int64_t nb = __shfl_up(v, off);
+            if (lane >= off) v += nb;
+        }
+        if (lane == 63) s_w[wave] = v;
+        __syncthreads();
+        int64_t woff = 0;
+        for (int w = 0; w < wave; ++w) woff += s_w[w];
+        const int64_t carry = s_carry;
+        if (t < tiles_per_bundle) tile_off[base + t] = carry + woff + v - c;
+        __syncthreads();
+        if (tid == kBlock - 1) s_carry = carry + woff + v;
+        __syncthreads();
+    }
+    // deterministic tree over the 256 per-thread partials
+    s_rx[tid] = ax; s_ry[tid] = ay; s_rm[tid] = mx;
+    __syncthreads();
+    for (int off = kBlock / 2; off > 0; off >>= 1) {
+        if (tid < off) { s_rx[tid] += s_rx[tid + off]; s_ry[tid] += s_ry[tid + off]; s_rm[tid] = fmax(s_rm[tid], s_rm[tid + off]); }
+        __syncthreads();
+    }
+    if (tid == 0) {
+        const int64_t m = s_carry;
+        FtBundleAgg a;
+        a.m = m;
+        // mean of [ex; -ex] and of [ey; ey] over n = 2m entries
+        a.mux = m ? (s_rx[0] + (-s_rx[0])) / (double)(2 * m) : 0.0;
+        a.muy = m ? (s_ry[0] + s_ry[0]) / (double)(2 * m) : 0.0;
+        a.rmax = s_rm[0];
+        a.sq = 0.0;
+        agg[b] = a;
+    }
+}
+
+// ------------------------------------------------------------------------------------
+// full_trace, stage C: order-preserving compaction (wave ballot + popcount prefix, then
+// wave offsets through LDS), mirror, rho/theta, squared deviations per tile.
+// ------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(kBlock) void k_ft_scatter(const T* __restrict__ w_ex, const T* __restrict__ w_ey,
+                                                       const T* __restrict__ w_r, const T* __restrict__ w_th,
+                                                       int64_t rpb, int tiles_per_bundle,
+                                                       const int64_t* __restrict__ tile_off,
+                                                       const FtBundleAgg* __restrict__ agg,
+                                                       T* __restrict__ ex, T* __restrict__ ey,
+                                                       T* __restrict__ rho, T* __restrict__ theta,
+                                                       double* __restrict__ tile_sq)
+{
+    __shared__ int s_wcnt[kBlock / 64];
+    __shared__ double s_wsq[kBlock / 64];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int b = blockIdx.x / tiles_per_bundle;
+    const int tile = blockIdx.x - b * tiles_per_bundle;
+    const int64_t j0 = (int64_t)tile * kTile + (int64_t)tid * kRPT;
+    const int64_t g0 = (int64_t)b * rpb + j0;
+    const FtBundleAgg a = agg[b];
+    T e_x[kRPT], e_y[kRPT], rr[kRPT], th[kRPT];
+    bool keep[kRPT];
+#pragma unroll
+    for (int r = 0; r < kRPT; ++r) {
+        const bool in = (j0 + r) < rpb;
+        e_x[r] = in ? w_ex[g0 + r] : T(0);
+        e_y[r] = in ? w_ey[g0 + r] : T(0);
+        rr[r] = in ? w_r[g0 + r] : T(-1);
+        th[r] = in ? w_th[g0 + r] : T(0);
+        keep[r] = in && !(rr[r] < T(0));
+    }
+    const unsigned long long m0 = __ballot(keep[0]);
+    const unsigned long long m1 = __ballot(keep[1]);
+    const unsigned long long lt = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+    const int rank0 = __popcll(m0 & lt) + __popcll(m1 & lt);
+    const int wtot = __popcll(m0) + __popcll(m1);
+    if (lane == 0) s_wcnt[wave] = wtot;
+    __syncthreads();
+    int woff = 0;
+    for (int w = 0; w < wave; ++w) woff += s_wcnt[w];
+    const int64_t out0 = (int64_t)b * 2 * rpb;            // bundle region
+    const int64_t base = out0 + tile_off[blockIdx.x] + woff + rank0;
+    double sq = 0.0;
+    int k = 0;
+#pragma unroll
+    for (int r = 0; r < kRPT; ++r) {
+        if (keep[r]) {
+            const int64_t o = base + k;
+            const T rh = rr[r] / (T)a.rmax;                           // :142
+            ex[o] = e_x[r];  ey[o] = e_y[r];  rho[o] = rh;  theta[o] = th[r];
+            ex[o + a.m] = -e_x[r];                                    // :141
+            ey[o + a.m] = e_y[r];                                     // :140
+            rho[o + a.m] = rh;                                        // :143
+            theta[o + a.m] = (T)3.141592653589793 - th[r];            // :144
+            const double dx1 = (double)e_x[r] - a.mux, dx2 = -(double)e_x[r] - a.mux;
+            const double dy = (double)e_y[r] - a.muy;
+            sq += (dx1 * dx1 + dx2 * dx2) + (dy * dy + dy * dy);
+            ++k;
+        }
+    }
+    for (int off = 32; off > 0; off >>= 1) sq += __shfl_down(sq, off);
+    if (lane == 0) s_wsq[wave] = sq;
+    __syncthreads();
+    if (tid == 0) {
+        double t = 0.0;
+        for (int w = 0; w < kBlock / 64; ++w) t += s_wsq[w];
+        tile_sq[blockIdx.x] = t;
+    }
+}
+
+// full_trace, stage D: sigma per bundle (PupilSampling.jl:169-173).
+__global__ __launch_bounds__(kBlock) void k_ft_finalize(const double* __restrict__ tile_sq, int tiles_per_bundle,
+                                                        const FtBundleAgg* __restrict__ agg,
+                                                        int64_t* __restrict__ count, double* __restrict__ rms)
+{
+    __shared__ double s_r[kBlock];
+    const int b = blockIdx.x, tid = threadIdx.x;
+    double acc = 0.0;
+    for (int t = tid; t < tiles_per_bundle; t += kBlock) acc += tile_sq[(int64_t)b * tiles_per_bundle + t];
+    s_r[tid] = acc;
+    __syncthreads();
+    for (int off = kBlock / 2; off > 0; off >>= 1) {
+        if (tid < off) s_r[tid] += s_r[tid + off];
+        __syncthreads();
+    }
+    if (tid == 0) {
+        const int64_t m = agg[b].m;
+        count[b] = 2 * m;
+        rms[b] = m ? sqrt(s_r[0] / (double)(2 * m)) : __builtin_nan("");
+    }
+}
+
+// ------------------------------------------------------------------------------------
+// Meridional real-ray trace, src/RayTracing.jl:145-169 (sag :75-88, tilt :98).
+// One thread per ray; history [rows][ld].  Trig through ocml (tan/asin/atan/sin/cos).
+// ------------------------------------------------------------------------------------
+struct MerSurf {   // row i+1 of the prescription as seen by loop iteration i
+    double t, R, sgn, K, n1, n2;
+    int32_t finite, ncoef;
+};
+
+__global__ __launch_bounds__(kBlock) void k_trace_meridional(const MerSurf* __restrict__ surf, const double* __restrict__ coefs,
+                                                             int S, int ncoef, int layout_mode, double t_last,
+                                                             int64_t nrays, const double* __restrict__ y_in,
+                                                             const double* __restrict__ U_in,
+                                                             double* __restrict__ y_out, double* __restrict__ U_out,
+                                                             double* __restrict__ ts_out, int64_t ld)
+{
+    __shared__ MerSurf s_s[kMaxRows];
+    __shared__ double s_c[kMaxRows * kMaxCoef];
+    for (int w = threadIdx.x; w < S; w += kBlock) s_s[w] = surf[w];
+    if (coefs) for (int w = threadIdx.x; w < S * ncoef; w += kBlock) s_c[w] = coefs[ncoef + w];
+    __syncthreads();
+    const int64_t g = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (g >= nrays) return;
+    double y = y_in[g], U = U_in[g];
+    y_out[g] = y; U_out[g] = U;                                   // :150
+    double sprev = 0.0;
+    for (int i = 0; i < S; ++i) {
+        const MerSurf s = s_s[i];
+        const double* c = s_c + i * ncoef;
+        const double tcur = s.t - sprev;                          // ts[i] after :161
+        const double tU = ::tan(U);
+        y = y + tU * tcur;                                        // :152
+        double sg;
+        if (s.finite) {                                           // :76
+            const double beta = s.R - y * tU;                     // :77
+            const double y2 = y * y;                              // :78
+            const double sec = 1.0 / ::cos(U);
+            const double D = beta * beta - y2 * (sec * sec + s.K);    // :79
+            sg = y2 / (beta + s.sgn * __builtin_sqrt(D));         // :81
+            sg = sg + (s.ncoef > 0 ? poly_eval<double>(c, s.ncoef, y) : 0.0);
+            sg = (D >= 0.0) ? sg : __builtin_nan("");             // :80,83
+        } else sg = 0.0;                                          // :86
+        y = y + sg * tU;                                          // :158
+        if (ts_out) ts_out[(int64_t)i * ld + g] = tcur + sg;      // ts[i] += s (:160)
+        sprev = sg;
+        double theta;
+        if (s.K == 0.0 && !layout_mode && s.ncoef == 0) {
+            theta = ::asin(y / s.R);                              // :162, tilt(y, R) = y / R (:101)
+        } else {
+            double tl = s.sgn * y / __builtin_sqrt(s.R * s.R - y * y * (1.0 + s.K));   // :98
+            tl = tl + (s.ncoef > 0 ? poly_deriv<double>(c, s.ncoef, y) : 0.0);
+            theta = ::atan(tl);
+        }
+        const double sin_ip = s.n1 * ::sin(U + theta) / s.n2;     // :163
+        U = (fabs(sin_ip) <= 1.0) ? ::asin(sin_ip) - theta : __builtin_nan("");   // :164
+        y_out[(int64_t)(i + 1) * ld + g] = y;                     // :165
+        U_out[(int64_t)(i + 1) * ld + g] = U;                     // :166
+    }
+    if (ts_out) ts_out[(int64_t)S * ld + g] = t_last - sprev;     // ts[end] -= s (:161)
+}
+
+// ------------------------------------------------------------------------------------
+// Paraxial y-nu trace, src/RayTracing.jl:127-143 (+ :55-69).  One thread per ray; lens
+// table of the ray's lens staged in LDS.  grid.x = lens * blocks_per_lens + chunk.
+// ------------------------------------------------------------------------------------
+__global__ __launch_bounds__(kBlock) void k_trace_paraxial(int k, const double* __restrict__ tau, const double* __restrict__ phi,
+                                                           const double* __restrict__ a, int clip,
+                                                           int64_t rays_per_lens, int blocks_per_lens,
+                                                           const double* __restrict__ y_in, const double* __restrict__ w_in,
+                                                           double* __restrict__ rt_y, double* __restrict__ rt_w, int64_t ld)
+{
+    __shared__ double s_tau[kMaxRows], s_phi[kMaxRows], s_a[kMaxRows];
+    const int lens = blockIdx.x / blocks_per_lens;
+    const int chunk = blockIdx.x - lens * blocks_per_lens;
+    for (int i = threadIdx.x; i < k; i += kBlock) {
+        s_tau[i] = tau[(int64_t)lens * k + i];
+        s_phi[i] = phi[(int64_t)lens * k + i];
+        s_a[i] = a ? a[(int64_t)lens * k + i] : __builtin_inf();
+    }
+    __syncthreads();
+    const int64_t r = (int64_t)chunk * kBlock + threadIdx.x;
+    if (r >= rays_per_lens) return;
+    const int64_t g = (int64_t)lens * rays_per_lens + r;
+    double y = y_in[g], w = w_in[g];
+    rt_y[g] = y; rt_w[g] = w;                                     // :132
+    bool dead = false;
+    for (int i = 0; i < k; ++i) {
+        const double tq = s_tau[i];
+        const double yp = __builtin_isfinite(tq) ? y + w * tq : y;    // :61-64
+        const double wp = w - yp * s_phi[i];                          // :66-69
+        y = yp; w = wp;
+        if (clip && !dead && (fabs(y) - s_a[i] > 1e-13)) dead = true; // :135-137
+        rt_y[(int64_t)(i + 1) * ld + g] = dead ? __builtin_nan("") : y;
+        rt_w[(int64_t)(i + 1) * ld + g] = dead ? __builtin_nan("") : w;
+    }
+}
+
+// ------------------------------------------------------------------------------------
+// ABCD, src/TransferMatrix.jl:1-17.  One thread per lens / per vector.
+// ------------------------------------------------------------------------------------
+__device__ __forceinline__ void mm2(const double* A, const double* B, double* C)
+{
+    const double c0 = A[0] * B[0] + A[1] * B[2];
+    const double c1 = A[0] * B[1] + A[1] * B[3];
+    const double c2 = A[2] * B[0] + A[3] * B[2];
+    const double c3 = A[2] * B[1] + A[3] * B[3];
+    C[0] = c0; C[1] = c1; C[2] = c2; C[3] = c3;
+}
+
+__global__ __launch_bounds__(kBlock) void k_abcd(int nlens, int k, const double* __restrict__ tau,
+                                                 const double* __restrict__ phi, double* __restrict__ M)
+{
+    const int l = blockIdx.x * kBlock + threadIdx.x;
+    if (l >= nlens) return;
+    double acc[4] = {1.0, 0.0, 0.0, 1.0};
+    for (int i = k - 1; i >= 0; --i) {                            // reverse(axes(M, 1)) (:4)
+        const double tq = tau[(int64_t)l * k + i], ph = phi[(int64_t)l * k + i];
+        const double Mi[4] = {1.0, tq, -ph, 1.0 - tq * ph};
+        if (i == k - 1) { acc[0] = Mi[0]; acc[1] = Mi[1]; acc[2] = Mi[2]; acc[3] = Mi[3]; }
+        else { double tmp[4]; mm2(acc, Mi, tmp); acc[0] = tmp[0]; acc[1] = tmp[1]; acc[2] = tmp[2]; acc[3] = tmp[3]; }
+    }
+    M[(int64_t)l * 4 + 0] = acc[0]; M[(int64_t)l * 4 + 1] = acc[1];
+    M[(int64_t)l * 4 + 2] = acc[2]; M[(int64_t)l * 4 + 3] = acc[3];
+}
+
+__device__ __forceinline__ void extend2(const double* M, double tau, double tau_p, double* E)
+{
+    const double L[4] = {1.0, tau_p, 0.0, 1.0};
+    const double Rm[4] = {1.0, tau, 0.0, 1.0};
+    double tmp[4];
+    mm2(L, M, tmp);                                                // :8, left to right
+    mm2(tmp, Rm, E);
+}
+
+__global__ __launch_bounds__(kBlock) void k_abcd_transfer(const double* __restrict__ M, int64_t nv, const double* __restrict__ v,
+                                                          const double* __restrict__ tau, const double* __restrict__ tau_p,
+                                                          double* __restrict__ out, int reverse)
+{
+    const int64_t g = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (g >= nv) return;
+    const double Mm[4] = {M[0], M[1], M[2], M[3]};
+    double E[4];
+    extend2(Mm, tau[g], tau_p[g], E);
+    const double v0 = v[2 * g], v1 = v[2 * g + 1];
+    if (!reverse) {                                                // :10
+        out[2 * g] = E[0] * v0 + E[1] * v1;
+        out[2 * g + 1] = E[2] * v0 + E[3] * v1;
+    } else {                                                       // :13, LU with partial pivoting
+        double a = E[0], b = E[1], c = E[2], d = E[3], r0 = v0, r1 = v1;
+        if (fabs(c) > fabs(a)) { double t; t = a; a = c; c = t; t = b; b = d; d = t; t = r0; r0 = r1; r1 = t; }
+        const double l = c / a;
+        const double d2 = d - l * b;
+        const double y1 = r1 - l * r0;
+        const double x1 = y1 / d2;
+        const double x0 = (r0 - b * x1) / a;
+        out[2 * g] = x0; out[2 * g + 1] = x1;
+    }
+}
+
+}  // namespace ort

@@ -1,0 +1,219 @@
+"""HipEngine — numpy-facing wrapper of the C ABI (include/ort.h).
+
+The host layer (api.py) talks to an *engine*: an object with the methods below.  The only
+engine the package ships is this one, and it runs every trace on the GPU through
+libort_hip.so; it raises when the library or the device is missing.  (Tests build a second
+engine around the CPU oracle to check host logic without a GPU; that class lives under
+tests/, not here.)
+
+Array conventions: per-surface histories are [rows_or_S, nrays] C-contiguous (surface-major,
+the `ld` layout of the ABI); per-ray inputs are 1-D.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from dataclasses import dataclass
+from typing import List, Optional, Sequence
+
+import numpy as np
+
+from . import _capi
+from ._capi import Context, DeviceSystem, check, f64, ptr
+
+
+@dataclass
+class Prescription:
+    """Columns of the reference `surfaces` matrix for nsys systems (+ K, polynomial coefs)."""
+    R: np.ndarray            # [nsys, rows]
+    t: np.ndarray
+    n: np.ndarray
+    K: Optional[np.ndarray] = None      # [nsys, rows]
+    coef: Optional[np.ndarray] = None   # [nsys, rows, ncoef]
+
+    def __post_init__(self):
+        self.R = np.atleast_2d(f64(self.R))
+        self.t = np.atleast_2d(f64(self.t))
+        self.n = np.atleast_2d(f64(self.n))
+        if self.K is not None:
+            self.K = np.atleast_2d(f64(self.K))
+        if self.coef is not None:
+            c = f64(self.coef)
+            self.coef = c[None] if c.ndim == 2 else c
+
+    @property
+    def rows(self) -> int:
+        return self.R.shape[1]
+
+    @property
+    def nsys(self) -> int:
+        return self.R.shape[0]
+
+    def key(self) -> bytes:
+        parts = [self.R.tobytes(), self.t.tobytes(), self.n.tobytes(),
+                 b"" if self.K is None else self.K.tobytes(),
+                 b"" if self.coef is None else self.coef.tobytes(),
+                 str(self.R.shape).encode()]
+        return b"|".join(parts)
+
+    @classmethod
+    def from_matrix(cls, surfaces, K=None, coef=None) -> "Prescription":
+        M = np.asarray(surfaces, dtype=np.float64)
+        return cls(M[:, 0].copy(), M[:, 1].copy(), M[:, 2].copy(), K, coef)
+
+
+class HipEngine:
+    name = "hip"
+
+    def __init__(self, device: int = 0, stream: Optional[int] = None, fast_math: bool = False,
+                 use_lds: bool = True):
+        self.ctx = Context(device, stream)
+        self.base_flags = (_capi.ORT_FAST_MATH if fast_math else 0) | (0 if use_lds else _capi.ORT_NO_LDS)
+        self._systems = {}
+
+    # ---- systems ---------------------------------------------------------------------
+    def system(self, pres: Prescription) -> DeviceSystem:
+        k = pres.key()
+        s = self._systems.get(k)
+        if s is None:
+            if len(self._systems) > 32:
+                self._systems.pop(next(iter(self._systems))).close()
+            s = DeviceSystem(self.ctx, pres.R, pres.t, pres.n, pres.K, pres.coef)
+            self._systems[k] = s
+        return s
+
+    # ---- skew: raytrace(surfaces, y, x, U, V, Vector{RealRay})  PupilSampling.jl:34-65 --
+    def skew(self, pres: Prescription, y, x, U, V, isys: int = 0, slopes: bool = False,
+             want_status: bool = False):
+        y, x, U, V = (np.atleast_1d(f64(a)) for a in (y, x, U, V))
+        y, x, U, V = np.broadcast_arrays(y, x, U, V)
+        y, x, U, V = (np.ascontiguousarray(a) for a in (y, x, U, V))
+        N = y.size
+        S = pres.rows - 1
+        xv = np.empty((S, N)); yv = np.empty((S, N))
+        st = np.empty(N, dtype=np.int32) if want_status else None
+        flags = self.base_flags | (_capi.ORT_INPUT_SLOPES if slopes else 0)
+        sysd = self.system(pres)
+        check(self.ctx.lib.ort_trace_skew_f64(self.ctx.h, sysd.h, isys, N, ptr(y), ptr(x), ptr(U), ptr(V),
+                                              ptr(xv), ptr(yv), N, ptr(st), flags))
+        return (xv, yv, st) if want_status else (xv, yv)
+
+    # ---- grid bundles: PupilSampling.jl:121-138 -----------------------------------------
+    def grid(self, pres: Prescription, bundles: Sequence[dict], axes, ny: int, nx: int,
+             history: bool = True, summary: bool = True, raybasis: bool = False):
+        axes = f64(axes).ravel()
+        nb = len(bundles)
+        N = nb * ny * nx
+        S = pres.rows - 1
+        out = _capi.ort_grid_out_f64()
+        res = {}
+        if history:
+            res["xv"] = np.empty((S, N)); res["yv"] = np.empty((S, N))
+            out.xv, out.yv, out.ld = ptr(res["xv"]), ptr(res["yv"]), N
+        if summary:
+            have_stop = all(int(b.get("stop", 0)) > 0 for b in bundles)
+            res["xf"] = np.empty(N); res["yf"] = np.empty(N)
+            res["status"] = np.empty(N, dtype=np.int32)
+            out.xf, out.yf, out.status = ptr(res["xf"]), ptr(res["yf"]), ptr(res["status"])
+            if have_stop:
+                res["xs"] = np.empty(N); res["ys"] = np.empty(N)
+                out.xs, out.ys = ptr(res["xs"]), ptr(res["ys"])
+        barr = _capi.make_bundles(bundles)
+        flags = self.base_flags | (_capi.ORT_RAYBASIS if raybasis else 0)
+        sysd = self.system(pres)
+        check(self.ctx.lib.ort_trace_grid_f64(self.ctx.h, sysd.h, nb, barr, ptr(axes), axes.size, ny, nx,
+                                              C.byref(out), flags))
+        return res
+
+    # ---- full_trace grid stage: PupilSampling.jl:121-146,169-173 -------------------------
+    def full_trace_grid(self, pres: Prescription, bundles: Sequence[dict], axes, ny: int, nx: int,
+                        raybasis: bool = False) -> List[dict]:
+        axes = f64(axes).ravel()
+        nb = len(bundles)
+        cap = 2 * ny * nx
+        ex = np.empty((nb, cap)); ey = np.empty((nb, cap)); rho = np.empty((nb, cap)); th = np.empty((nb, cap))
+        count = np.zeros(nb, dtype=np.int64); rms = np.zeros(nb)
+        barr = _capi.make_bundles(bundles)
+        flags = self.base_flags | (_capi.ORT_RAYBASIS if raybasis else 0)
+        sysd = self.system(pres)
+        check(self.ctx.lib.ort_full_trace_f64(self.ctx.h, sysd.h, nb, barr, ptr(axes), axes.size, ny, nx,
+                                              ptr(ex), ptr(ey), ptr(rho), ptr(th), ptr(count), ptr(rms), flags))
+        out = []
+        for b in range(nb):
+            c = int(count[b])
+            out.append({"ex": ex[b, :c].copy(), "ey": ey[b, :c].copy(), "rho": rho[b, :c].copy(),
+                        "theta": th[b, :c].copy(), "rms": float(rms[b]), "count": c})
+        return out
+
+    # ---- meridional: raytrace(surfaces, y, U, RealRay)  RayTracing.jl:145-169 -----------
+    def meridional(self, pres: Prescription, y, U, layout_mode: bool = False, isys: int = 0):
+        y, U = (np.atleast_1d(f64(a)) for a in (y, U))
+        y, U = np.broadcast_arrays(y, U)
+        y, U = np.ascontiguousarray(y), np.ascontiguousarray(U)
+        N = y.size
+        rows = pres.rows
+        yo = np.empty((rows, N)); Uo = np.empty((rows, N)); ts = np.empty((rows, N))
+        flags = self.base_flags | (_capi.ORT_LAYOUT_INPUT if layout_mode else 0)
+        sysd = self.system(pres)
+        check(self.ctx.lib.ort_trace_meridional_f64(self.ctx.h, sysd.h, isys, N, ptr(y), ptr(U),
+                                                    ptr(yo), ptr(Uo), ptr(ts), N, flags))
+        return yo, Uo, ts
+
+    # ---- paraxial: raytrace(lens, y, ω, a; clip)  RayTracing.jl:127-143 ------------------
+    def paraxial(self, tau, phi, y, w, a=None, clip: bool = False):
+        tau = np.atleast_2d(f64(tau)); phi = np.atleast_2d(f64(phi))
+        nlens, k = tau.shape
+        y, w = (np.atleast_1d(f64(v)) for v in (y, w))
+        y, w = np.broadcast_arrays(y, w)
+        y, w = np.ascontiguousarray(y), np.ascontiguousarray(w)
+        N = y.size
+        if N % nlens:
+            raise ValueError("ray count must be a multiple of the lens count")
+        ap = None
+        if a is not None:
+            ap = np.atleast_2d(f64(a))
+            if ap.shape != tau.shape:
+                raise ValueError("aperture vector must have one entry per lens row")
+        rt_y = np.empty((k + 1, N)); rt_w = np.empty((k + 1, N))
+        flags = self.base_flags | (_capi.ORT_CLIP if clip else 0)
+        check(self.ctx.lib.ort_trace_paraxial_f64(self.ctx.h, nlens, k, ptr(tau), ptr(phi), ptr(ap),
+                                                  N // nlens, ptr(y), ptr(w), ptr(rt_y), ptr(rt_w), N, flags))
+        return rt_y, rt_w
+
+    # ---- ABCD: TransferMatrix.jl:1-17 -----------------------------------------------------
+    def abcd(self, tau, phi) -> np.ndarray:
+        tau = np.atleast_2d(f64(tau)); phi = np.atleast_2d(f64(phi))
+        nlens, k = tau.shape
+        M = np.empty((nlens, 2, 2))
+        check(self.ctx.lib.ort_abcd_f64(self.ctx.h, nlens, k, ptr(tau), ptr(phi), ptr(M), self.base_flags))
+        return M
+
+    def abcd_transfer(self, M, v, tau, tau_p, reverse: bool = False) -> np.ndarray:
+        M = f64(M, (2, 2))
+        v = np.atleast_2d(f64(v))
+        nv = v.shape[0]
+        tau = np.ascontiguousarray(np.broadcast_to(f64(tau), (nv,)))
+        tau_p = np.ascontiguousarray(np.broadcast_to(f64(tau_p), (nv,)))
+        out = np.empty((nv, 2))
+        if reverse:
+            check(self.ctx.lib.ort_abcd_reverse_transfer_f64(self.ctx.h, ptr(M), nv, ptr(v), ptr(tau_p), ptr(tau),
+                                                             ptr(out), self.base_flags))
+        else:
+            check(self.ctx.lib.ort_abcd_transfer_f64(self.ctx.h, ptr(M), nv, ptr(v), ptr(tau), ptr(tau_p),
+                                                     ptr(out), self.base_flags))
+        return out
+
+
+_default: Optional[HipEngine] = None
+
+
+def default_engine() -> HipEngine:
+    """The process-wide GPU engine (device 0).  Raises when no gfx950 device is usable."""
+    global _default
+    if _default is None:
+        _default = HipEngine(0)
+    return _default
+
+
+def set_default_engine(engine) -> None:
+    global _default
+    _default = engine
