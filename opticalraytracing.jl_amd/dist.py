@@ -1,0 +1,83 @@
+"""Multi-GPU plumbing: one process per GPU, torch.distributed ("nccl" = RCCL over xGMI on
+ROCm; "gloo" on CPU for tests).
+
+The path shards over independent units — (system, field, index column, pupil row): no ray
+reads another ray's state (src/PupilSampling.jl:34-65 is a pure function).  Units are split
+into contiguous, equal slabs in rank order, so concatenating rank outputs in rank order
+reproduces the reference's append order (PupilSampling.jl:134-137).  There is no data-path
+collective; the only exchange is the reassembly of image-plane hit points (one all-gather of
+equal-size dense slabs) or, when only spot statistics are wanted, of per-bundle moments.
+"""
+from __future__ import annotations
+
+import os
+from typing import List, Sequence, Tuple
+
+
+def env_rank_world() -> Tuple[int, int, int]:
+    return (int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1")),
+            int(os.environ.get("LOCAL_RANK", "0")))
+
+
+def shard_bounds(n_units: int, world: int) -> List[Tuple[int, int]]:
+    """Contiguous slabs [lo, hi) in rank order; the first n_units % world ranks get one extra."""
+    base, extra = divmod(n_units, world)
+    out, lo = [], 0
+    for r in range(world):
+        hi = lo + base + (1 if r < extra else 0)
+        out.append((lo, hi))
+        lo = hi
+    return out
+
+
+def shard(seq: Sequence, rank: int, world: int) -> Sequence:
+    lo, hi = shard_bounds(len(seq), world)[rank]
+    return seq[lo:hi]
+
+
+def init_process_group(backend: str = "nccl"):
+    import torch.distributed as dist
+    if not dist.is_initialized():
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29511")
+        dist.init_process_group(backend=backend)
+    return dist
+
+
+def allgather_hits(xf, yf, group=None):
+    """All-gather equal-size per-rank hit slabs (image-plane x, y) into rank-ordered tensors of
+    world*len entries: ONE collective over a packed [2, n] buffer."""
+    import torch
+    import torch.distributed as dist
+    world = dist.get_world_size(group)
+    n = xf.numel()
+    packed = torch.stack([xf.reshape(-1), yf.reshape(-1)])            # [2, n]
+    out = torch.empty((world, 2, n), dtype=packed.dtype, device=packed.device)
+    dist.all_gather_into_tensor(out, packed, group=group)
+    return out[:, 0, :].reshape(-1), out[:, 1, :].reshape(-1)
+
+
+def allgather_ragged(values, group=None):
+    """All-gather 1-D tensors of different lengths (compacted survivors): counts first, then
+    padded slabs; returns the rank-ordered concatenation."""
+    import torch
+    import torch.distributed as dist
+    world = dist.get_world_size(group)
+    n = torch.tensor([values.numel()], dtype=torch.int64, device=values.device)
+    counts = torch.empty(world, dtype=torch.int64, device=values.device)
+    dist.all_gather_into_tensor(counts, n, group=group)
+    m = int(counts.max().item())
+    pad = torch.zeros(m, dtype=values.dtype, device=values.device)
+    pad[:values.numel()] = values.reshape(-1)
+    out = torch.empty((world, m), dtype=values.dtype, device=values.device)
+    dist.all_gather_into_tensor(out, pad, group=group)
+    return torch.cat([out[r, :int(counts[r].item())] for r in range(world)])
+
+
+def allreduce_moments(count, sx, sy, sxx, syy, group=None):
+    """Spot statistics without moving hits: all-reduce (n, Σx, Σy, Σx², Σy²) per bundle."""
+    import torch
+    import torch.distributed as dist
+    buf = torch.stack([count.double(), sx.double(), sy.double(), sxx.double(), syy.double()])
+    dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=group)
+    return buf[0], buf[1], buf[2], buf[3], buf[4]

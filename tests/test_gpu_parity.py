@@ -1,0 +1,343 @@
+"""GPU parity: the HIP path (through the C ABI) against the CPU oracle on identical inputs.
+
+Bars (BASELINE.json north_star): Float64 coordinates within 1e-10 relative
+(denominator max(|ref|, 1 mm) — coordinates legitimately cross 0), status / surface-hit index
+bit-exact.  The default arithmetic policy performs the reference's operation sequence with
+IEEE / and sqrt, so wherever no libm call is involved we assert BITWISE equality.
+"""
+import math
+
+import numpy as np
+import pytest
+
+import opticalraytracing_jl_amd as ort
+from opticalraytracing_jl_amd import Prescription
+from tests import common as cm
+
+pytestmark = pytest.mark.gpu
+
+TOL = 1e-10
+
+
+def _random_rays(n, a1, seed=1):
+    rng = np.random.default_rng(seed)                       # SURVEY §8d random-ray parity set
+    y = rng.uniform(-0.9 * a1, 0.9 * a1, n)
+    x = rng.uniform(-0.9 * a1, 0.9 * a1, n)
+    U = rng.uniform(-0.2, 0.2, n)
+    V = rng.uniform(-0.2, 0.2, n)
+    return y, x, U, V
+
+
+def _ext(surfaces, focus):
+    e = np.vstack([surfaces, [math.inf, 0.0, 1.0]])
+    e[-2, 1] = focus
+    return e
+
+
+@pytest.mark.parametrize("name", ["cooke", "tessar", "catadioptric", "double_gauss"])
+def test_skew_list_bitexact_with_slopes(hip_engine, oracle_engine, name):
+    M = {"cooke": _ext(cm.cooke(), 77.40534796682427), "tessar": _ext(cm.tessar(), 40.0),
+         "catadioptric": cm.catadioptric(), "double_gauss": _ext(cm.double_gauss(), 57.8)}[name]
+    pres = Prescription.from_matrix(M)
+    a1 = {"cooke": 14.7, "tessar": 9.5, "catadioptric": 15.0, "double_gauss": 29.0}[name]
+    y, x, U, V = _random_rays(20001, a1)                    # odd count: exercises the tail lane
+    u, v = np.tan(U), np.tan(V)
+    gx, gy, gs = hip_engine.skew(pres, y, x, u, v, slopes=True, want_status=True)
+    ox, oy, os_ = oracle_engine.skew(pres, y, x, u, v, slopes=True, want_status=True)
+    assert np.array_equal(gs, os_)
+    assert np.array_equal(gx, ox, equal_nan=True)
+    assert np.array_equal(gy, oy, equal_nan=True)
+
+
+def test_skew_list_angles(hip_engine, oracle_engine):
+    """tan() runs on the device here (ocml vs glibc: last-ulp differences)."""
+    pres = Prescription.from_matrix(_ext(cm.cooke(), 77.40534796682427))
+    y, x, U, V = _random_rays(4096, 14.7, seed=2)
+    gx, gy, gs = hip_engine.skew(pres, y, x, U, V, want_status=True)
+    ox, oy, os_ = oracle_engine.skew(pres, y, x, U, V, want_status=True)
+    assert np.array_equal(gs, os_)
+    assert cm.rel_err(gx, ox, 1.0).max() <= TOL
+    assert cm.rel_err(gy, oy, 1.0).max() <= TOL
+
+
+def test_miss_and_tir_status(hip_engine, oracle_engine):
+    """Edge cases of the reference: surface miss -> NaN from that surface on
+    (PupilSampling.jl:9); TIR leaves the ray undeviated (Q1)."""
+    pres = Prescription.from_matrix(_ext(cm.cooke(), 77.4))
+    y = np.array([0.0, 36.0, 38.0, 60.0, -45.0, 10.0, 5.0, 14.0])
+    x = np.array([0.0, 10.0, 0.0, 0.0, 30.0, 10.0, 40.0, 0.0])
+    U = np.array([0.0, 0.0, 0.0, 0.3, -0.2, 0.9, 0.0, -1.2])
+    V = np.array([0.0, 0.0, 0.0, 0.0, 0.1, 0.9, 0.0, 0.0])
+    u, v = np.tan(U), np.tan(V)
+    gx, gy, gs = hip_engine.skew(pres, y, x, u, v, slopes=True, want_status=True)
+    ox, oy, os_ = oracle_engine.skew(pres, y, x, u, v, slopes=True, want_status=True)
+    assert (os_ < pres.rows).any() and (os_ == pres.rows).any()      # both kinds present
+    assert np.array_equal(gs, os_)
+    assert np.array_equal(np.isnan(gx), np.isnan(ox))
+    assert np.array_equal(gx, ox, equal_nan=True) and np.array_equal(gy, oy, equal_nan=True)
+    # a dense singlet of high index: steep rays meet the glass->air TIR branch
+    tir = Prescription.from_matrix(np.array([[math.inf, 0.0, 1.0], [30.0, 25.0, 1.9], [-30.0, 10.0, 1.0],
+                                             [math.inf, 0.0, 1.0]]))
+    yy = np.linspace(-26.0, 26.0, 257)
+    g = hip_engine.skew(tir, yy, 0.3 * yy, 0.0 * yy, 0.0 * yy, slopes=True, want_status=True)
+    o = oracle_engine.skew(tir, yy, 0.3 * yy, 0.0 * yy, 0.0 * yy, slopes=True, want_status=True)
+    assert np.array_equal(g[2], o[2])
+    assert np.array_equal(g[0], o[0], equal_nan=True) and np.array_equal(g[1], o[1], equal_nan=True)
+
+
+def _dg_bundles(engine, k, fields=(0.0, 0.7, 1.0), lines=(0, 1, 2)):
+    """3 fields x 3 index columns of the Double-Gauss, square pupil k x k (BASELINE config 2)."""
+    from opticalraytracing_jl_amd import api, workloads
+    systems = [ort.solve(cm.double_gauss(line), cm.DG_A, cm.DG_H, engine=engine) for line in lines]
+    return workloads.square_pupil_bundles(api, systems, k, fields=fields)
+
+
+def test_grid_cooke_config1_bitexact(hip_engine, oracle_engine):
+    """BASELINE config 1: Cooke triplet, 1 field, 64 x 32 half pupil (reference mode)."""
+    system = ort.solve(cm.cooke(), cm.COOKE_A, cm.COOKE_H, engine=oracle_engine)
+    aim = ort.full_trace_aim(system.layout, system, 1.0, engine=oracle_engine)
+    pres = ort.extended_prescription(system.layout, aim.focus)
+    axes = np.concatenate([ort.linrange(aim.y1, aim.y2, 64), ort.linrange(0.0, aim.y_EP, 32)])
+    b = dict(system=0, stop=aim.stop, U=aim.U, V=0.0, a_stop=aim.a_stop, hprime=aim.hprime, yaxis_off=0, xaxis_off=64)
+    g = hip_engine.grid(pres, [b], axes, 64, 32)
+    o = oracle_engine.grid(pres, [b], axes, 64, 32)
+    for key in ("xv", "yv", "xf", "yf", "xs", "ys"):
+        assert np.array_equal(g[key], o[key], equal_nan=True), key
+    assert np.array_equal(g["status"], o["status"])
+
+
+def test_grid_double_gauss_config2_small(hip_engine, oracle_engine):
+    """Config 2 shape at 96 x 96 per bundle (oracle-sized): 9 bundles, 3 systems, bit-exact."""
+    pres, bundles, axes = _dg_bundles(oracle_engine, 96)
+    g = hip_engine.grid(pres, bundles, axes, 96, 96)
+    o = oracle_engine.grid(pres, bundles, axes, 96, 96)
+    for key in ("xv", "yv", "xf", "yf", "xs", "ys"):
+        assert np.array_equal(g[key], o[key], equal_nan=True), key
+    assert np.array_equal(g["status"], o["status"])
+    assert ((o["status"] >> 16) & 1).any()                   # some rays fail the stop filter
+
+
+def test_grid_odd_sizes_and_no_lds(oracle_engine):
+    """Ragged tiles (rays per bundle not a multiple of the 512-ray tile, odd nx) and the
+    scalar-load variant of the surface table."""
+    eng = ort.HipEngine(0, use_lds=False)
+    pres, bundles, axes = _dg_bundles(oracle_engine, 37, fields=(0.0, 1.0), lines=(0, 2))
+    g = eng.grid(pres, bundles, axes, 37, 37)
+    o = oracle_engine.grid(pres, bundles, axes, 37, 37)
+    for key in ("xv", "yv", "xf", "yf"):
+        assert np.array_equal(g[key], o[key], equal_nan=True), key
+    assert np.array_equal(g["status"], o["status"])
+
+
+def test_fast_math_within_tolerance(oracle_engine):
+    eng = ort.HipEngine(0, fast_math=True)
+    pres, bundles, axes = _dg_bundles(oracle_engine, 64)
+    g = eng.grid(pres, bundles, axes, 64, 64)
+    o = oracle_engine.grid(pres, bundles, axes, 64, 64)
+    assert np.array_equal(g["status"] & 0xffff, o["status"] & 0xffff)
+    worst = max(cm.rel_err(g[k], o[k], 1.0).max() for k in ("xv", "yv"))
+    assert worst <= 1e-12, worst                             # far inside the 1e-10 bar
+    flips = int(np.count_nonzero(g["status"] != o["status"]))
+    assert flips == 0, f"{flips} stop-filter flips"
+
+
+def test_aspheric_config3_small(hip_engine, oracle_engine):
+    """Config 3 shape: conic + polynomial terms on 4 surfaces.  The device uses the analytic
+    p'; the reference a complex step (RayTracing.jl:103) — equal to O(eps^2)."""
+    M4, coef = cm.double_gauss_aspheric()
+    ext = np.vstack([M4, [math.inf, 0.0, 1.0, 0.0]])
+    ext[-2, 1] = 57.8
+    cext = np.vstack([coef, np.zeros((1, coef.shape[1]))])
+    pres = Prescription(ext[:, 0], ext[:, 1], ext[:, 2], ext[:, 3], cext[None])
+    y, x, U, V = _random_rays(30000, 16.0, seed=3)
+    U *= 0.5; V *= 0.5
+    u, v = np.tan(U), np.tan(V)
+    gx, gy, gs = hip_engine.skew(pres, y, x, u, v, slopes=True, want_status=True)
+    ox, oy, os_ = oracle_engine.skew(pres, y, x, u, v, slopes=True, want_status=True)
+    assert np.array_equal(gs, os_)
+    assert max(cm.rel_err(gx, ox, 1.0).max(), cm.rel_err(gy, oy, 1.0).max()) <= 1e-12
+
+
+@pytest.mark.parametrize("H", [0.0, 0.7, 1.0])
+def test_full_trace_singlet(hip_engine, oracle_engine, H):
+    """The reference's own full_trace case (test/runtests.jl:364-372), grid stage on the GPU."""
+    system = ort.solve(cm.singlet(), [20.0, 20.0], 17.787, engine=oracle_engine)
+    aim = ort.full_trace_aim(system.layout, system, H, engine=oracle_engine)
+    g = ort.full_trace_grid(system.layout, aim, 64, engine=hip_engine)
+    o = ort.full_trace_grid(system.layout, aim, 64, engine=oracle_engine)
+    assert len(g.x) == len(o.x)                              # same survivors, same order
+    assert np.array_equal(g.x, o.x) and np.array_equal(g.y, o.y)
+    assert cm.rel_err(g.r, o.r, 1e-3).max() <= TOL           # hypot: ocml vs glibc
+    assert cm.rel_err(g.t, o.t, 1e-3).max() <= TOL           # atan2
+    assert abs(g.RMS - o.RMS) <= TOL * o.RMS
+    assert abs(g.RMS - {0.0: 0.739649, 0.7: 1.1, 1.0: 1.4}[H]) < 0.07
+
+
+def test_full_trace_end_to_end_on_gpu(hip_engine, oracle_engine):
+    """solve + aiming + grid all through the GPU engine == all through the oracle."""
+    sg = ort.solve(cm.cooke(), cm.COOKE_A, cm.COOKE_H, engine=hip_engine)
+    so = ort.solve(cm.cooke(), cm.COOKE_A, cm.COOKE_H, engine=oracle_engine)
+    assert sg.f == so.f and sg.EBFD == so.EBFD and sg.stop == so.stop
+    assert np.array_equal(sg.M.M, so.M.M)
+    eg = ort.full_trace(sg, 0.7, engine=hip_engine)
+    eo = ort.full_trace(so, 0.7, engine=oracle_engine)
+    assert len(eg.x) == len(eo.x)
+    assert cm.rel_err(eg.x, eo.x, 1.0).max() <= 1e-9        # aiming iterates through device trig
+    assert abs(eg.RMS - eo.RMS) <= 1e-9 * eo.RMS
+
+
+def test_full_trace_multi_bundle_and_raybasis(hip_engine, oracle_engine):
+    pres, bundles, axes = _dg_bundles(oracle_engine, 50)
+    g = hip_engine.full_trace_grid(pres, bundles, axes, 50, 50)
+    o = oracle_engine.full_trace_grid(pres, bundles, axes, 50, 50)
+    for gb, ob in zip(g, o):
+        assert gb["count"] == ob["count"] and gb["count"] > 0
+        assert np.array_equal(gb["ex"], ob["ex"]) and np.array_equal(gb["ey"], ob["ey"])
+        assert cm.rel_err(gb["rho"], ob["rho"], 1e-3).max() <= TOL
+        assert abs(gb["rms"] - ob["rms"]) <= TOL * ob["rms"]
+    # finite-conjugate (RayBasis) rule, PupilSampling.jl:124-127: angles per ray, tan on device
+    for b in bundles:
+        b["ybar"], b["z0"] = -40.0, -900.0
+    g = hip_engine.full_trace_grid(pres, bundles[:2], axes, 50, 50, raybasis=True)
+    o = oracle_engine.full_trace_grid(pres, bundles[:2], axes, 50, 50, raybasis=True)
+    for gb, ob in zip(g, o):
+        assert gb["count"] == ob["count"]
+        assert cm.rel_err(gb["ex"], ob["ex"], 1.0).max() <= TOL
+        assert abs(gb["rms"] - ob["rms"]) <= TOL * max(ob["rms"], 1e-3)
+
+
+def test_meridional(hip_engine, oracle_engine):
+    for M, layout_mode in ((cm.cooke(), False), (cm.catadioptric(), False), (cm.tessar(), True)):
+        pres = Prescription.from_matrix(M)
+        rng = np.random.default_rng(5)
+        y = rng.uniform(-8, 8, 999); U = rng.uniform(-0.2, 0.2, 999)
+        g = hip_engine.meridional(pres, y, U, layout_mode)
+        o = oracle_engine.meridional(pres, y, U, layout_mode)
+        for a, b in zip(g, o):
+            assert cm.rel_err(a, b, 1.0).max() <= TOL
+    # conic, reflecting: the parabola of test/runtests.jl:335-338
+    P = cm.parabola_M()
+    pres = Prescription(P[:, 0], P[:, 1], P[:, 2], P[:, 3])
+    y = np.linspace(1.0, 30.0, 64)
+    g = hip_engine.meridional(pres, y, 0.0 * y, True)
+    o = oracle_engine.meridional(pres, y, 0.0 * y, True)
+    for a, b in zip(g, o):
+        assert cm.rel_err(a, b, 1.0).max() <= TOL
+
+
+def test_paraxial_and_abcd_bitexact(hip_engine, oracle_engine):
+    rng = np.random.default_rng(11)
+    nl, k = 7, 9
+    tau = rng.uniform(0.0, 12.0, (nl, k)); phi = rng.uniform(-0.02, 0.02, (nl, k))
+    tau[2, 0] = math.inf                                     # transfer skips non-finite τ (Q18)
+    a = rng.uniform(3.0, 12.0, (nl, k))
+    y = rng.uniform(-6, 6, nl * 300); w = rng.uniform(-0.2, 0.2, nl * 300)
+    for clip in (False, True):
+        g = hip_engine.paraxial(tau, phi, y, w, a, clip)
+        o = oracle_engine.paraxial(tau, phi, y, w, a, clip)
+        assert np.array_equal(g[0], o[0], equal_nan=True) and np.array_equal(g[1], o[1], equal_nan=True)
+        if clip:
+            assert np.isnan(o[0]).any() and not np.isnan(o[0]).all()
+    tau[2, 0] = 1.0
+    Mg, Mo = hip_engine.abcd(tau, phi), oracle_engine.abcd(tau, phi)
+    assert np.array_equal(Mg, Mo)
+    v = rng.uniform(-1, 1, (500, 2)); t1 = rng.uniform(-50, 50, 500); t2 = rng.uniform(-50, 50, 500)
+    for rev in (False, True):
+        assert np.array_equal(hip_engine.abcd_transfer(Mg[0], v, t1, t2, rev),
+                              oracle_engine.abcd_transfer(Mo[0], v, t1, t2, rev))
+
+
+def test_f32_build_extension(oracle_engine):
+    """Float32 instantiation (BASELINE config 5; the reference itself is Float64-only, Q21):
+    compared with the same loop in float on the CPU, 1e-4 relative, status exact away from
+    the Δ≥0 boundaries."""
+    import ctypes as C
+    from opticalraytracing_jl_amd import _capi
+    from oracle import cpu as oc
+    eng = ort.default_engine()
+    M = _ext(cm.double_gauss(), 57.8)
+    pres = Prescription.from_matrix(M)
+    sysd = eng.system(pres)
+    k = 128
+    yax = np.linspace(-14, 14, k).astype(np.float32); xax = np.linspace(-14, 14, k).astype(np.float32)
+    axes = np.concatenate([yax, xax])
+    N, S = k * k, pres.rows - 1
+    xv = np.empty((S, N), dtype=np.float32); yv = np.empty((S, N), dtype=np.float32)
+    st = np.empty(N, dtype=np.int32)
+    out = _capi.ort_grid_out_f32()
+    out.xv, out.yv, out.ld, out.status = xv.ctypes.data, yv.ctypes.data, N, st.ctypes.data
+    b = _capi.make_bundles([dict(system=0, stop=0, U=0.1, V=0.0, yaxis_off=0, xaxis_off=k)])
+    _capi.check(eng.ctx.lib.ort_trace_grid_f32(eng.ctx.h, sysd.h, 1, b, axes.ctypes.data, axes.size, k, k,
+                                               C.byref(out), 0))
+    L = oc.lib()
+    f = lambda a: np.ascontiguousarray(a, dtype=np.float32)
+    R, t, n = f(M[:, 0]), f(M[:, 1]), f(M[:, 2])
+    oxv = np.empty((S, N), dtype=np.float32); oyv = np.empty((S, N), dtype=np.float32)
+    ost = np.empty(N, dtype=np.int32)
+    fp = lambda a: a.ctypes.data_as(C.POINTER(C.c_float))
+    L.orc_trace_skew_grid_f32(pres.rows, fp(R), fp(t), fp(n), None, None, 0, k, fp(yax), k, fp(xax),
+                              np.float32(math.tan(0.1)), np.float32(0.0), fp(oxv), fp(oyv), N,
+                              ost.ctypes.data_as(C.POINTER(C.c_int32)), 1)
+    assert np.count_nonzero(st != ost) <= 2
+    ok = st == ost
+    assert cm.rel_err(xv[:, ok], oxv[:, ok], 1.0).max() <= 1e-4
+    assert cm.rel_err(yv[:, ok], oyv[:, ok], 1.0).max() <= 1e-4
+
+
+def test_device_pointer_path_full_size_properties(oracle_engine):
+    """BASELINE config 2 at FULL size (3 fields x 3 index columns x 1024 x 1024, S = 12)
+    through the device-pointer ABI (torch tensors).  Too large for the oracle, so check
+    size-independent properties: (1) x -> -x mirror symmetry, exact; (2) a strided sample of
+    rays re-traced by the oracle from explicit lists, bit-exact; (3) status histogram sanity."""
+    import ctypes as C
+    import torch
+    from opticalraytracing_jl_amd import _capi
+    eng = ort.default_engine()
+    k = 1024
+    pres, bundles, axes = _dg_bundles(oracle_engine, k)
+    nb, rpb = len(bundles), k * k
+    N, S = nb * rpb, pres.rows - 1
+    dev = torch.device("cuda:0")
+    d_axes = torch.from_numpy(axes).to(dev)
+    xv = torch.empty((S, N), dtype=torch.float64, device=dev)
+    yv = torch.empty((S, N), dtype=torch.float64, device=dev)
+    st = torch.empty(N, dtype=torch.int32, device=dev)
+    xf = torch.empty(N, dtype=torch.float64, device=dev); yf = torch.empty_like(xf)
+    xs = torch.empty_like(xf); ys = torch.empty_like(xf)
+    out = _capi.ort_grid_out_f64()
+    out.xv, out.yv, out.ld = xv.data_ptr(), yv.data_ptr(), N
+    out.xf, out.yf, out.xs, out.ys, out.status = xf.data_ptr(), yf.data_ptr(), xs.data_ptr(), ys.data_ptr(), st.data_ptr()
+    sysd = eng.system(pres)
+    barr = _capi.make_bundles(bundles)
+    torch.cuda.synchronize()
+    _capi.check(eng.ctx.lib.ort_trace_grid_f64(eng.ctx.h, sysd.h, nb, barr, d_axes.data_ptr(), axes.size, k, k,
+                                               C.byref(out), _capi.ORT_DEVICE_PTRS))
+    eng.ctx.synchronize()
+    # (0) summary == last / stop rows of the history
+    assert torch.equal(xf, xv[-1]) or torch.equal(torch.nan_to_num(xf), torch.nan_to_num(xv[-1]))
+    stop = bundles[0]["stop"]
+    assert torch.equal(torch.nan_to_num(ys), torch.nan_to_num(yv[stop - 1]))
+    # (1) mirror symmetry in x (V = 0): x(iy, ix) == -x(iy, k-1-ix), y equal — exact
+    X = xv.view(S, nb, k, k); Y = yv.view(S, nb, k, k)
+    assert torch.equal(torch.nan_to_num(X), torch.nan_to_num(-X.flip(-1)))
+    assert torch.equal(torch.nan_to_num(Y), torch.nan_to_num(Y.flip(-1)))
+    # (2) strided sample against the oracle
+    idx = np.arange(0, N, 40009)
+    sxv = xv[:, torch.from_numpy(idx).to(dev)].cpu().numpy(); syv = yv[:, torch.from_numpy(idx).to(dev)].cpu().numpy()
+    sst = st[torch.from_numpy(idx).to(dev)].cpu().numpy()
+    for b in range(nb):
+        sel = (idx // rpb) == b
+        j = idx[sel] % rpb
+        bd = bundles[b]
+        yy = axes[bd["yaxis_off"] + j // k]; xx = axes[bd["xaxis_off"] + j % k]
+        sub = Prescription(pres.R[bd["system"]], pres.t[bd["system"]], pres.n[bd["system"]])
+        u = np.full(j.size, math.tan(bd["U"])); v = np.zeros(j.size)
+        ox, oy, os_ = oracle_engine.skew(sub, yy, xx, u, v, slopes=True, want_status=True)
+        assert np.array_equal(sxv[:, sel], ox, equal_nan=True) and np.array_equal(syv[:, sel], oy, equal_nan=True)
+        assert np.array_equal(sst[sel] & 0xffff, os_)
+    # (3) every ray of this well-corrected system reaches the image; the square pupil's corners
+    # fail the stop filter: the kept fraction is close to pi/4
+    s = st.cpu().numpy()
+    assert np.all((s & 0xffff) == S + 1)
+    kept = 1.0 - np.count_nonzero(s >> 16) / N
+    assert abs(kept - math.pi / 4) < 0.05
