@@ -15,7 +15,7 @@ CSRC = os.path.join(HERE, "csrc")
 OUT = os.path.join(CSRC, "libort_hip.so")
 SOURCES = ["ort_hip.hip"]
 DEPS = ["ort_hip.hip", "ort_kernels.hpp", "ort_device.hpp", os.path.join("..", "..", "include", "ort.h")]
-FLAGS = ["--offload-arch=gfx950", "-O3", "-ffp-contract=off", "-fPIC", "-shared", "-std=c++17",
+FLAGS = ["--offload-arch=gfx950", "-O3", "-ffp-contract=off", "-fPIC", "-shared", "-std=c++17", "-fno-slp-vectorize",
          "-Wall"]
 
 

@@ -12,9 +12,15 @@
 //   MATH_IEEE  the exact operation sequence of the reference loop, one IEEE operation per
 //              reference operation, no contraction (this file is compiled with
 //              -ffp-contract=off), correctly rounded / and sqrt.
-//   MATH_FAST  algebraically merged: reciprocal square roots shared between tilt and
-//              normalisation, one reciprocal for both slopes, explicit FMAs.  Differs from
-//              MATH_IEEE by a few ulp per surface (tested to <= 1e-12 relative).
+//   MATH_FAST  the same geometry in direction-cosine form (no slopes): for a conic row the
+//              path length is d = F / (G + sqrt(G^2 - a F)), the discriminant's root IS the
+//              cosine of incidence on a sphere, and the sphere's normal needs no square root:
+//              2 rsq + 1 rcp seeds per ray-surface instead of 4 IEEE sqrt + 6 IEEE divisions.
+//              Seeds (v_rsq_f64 / v_rcp_f64, 2^-24 accurate, measured: tools/ubench.hip) are
+//              refined by ONE cubically convergent step to <= 1 ulp.  Rows carrying a
+//              polynomial term keep the reference's slope form (its additive p(y) is a quirk,
+//              not a geometric intersection, Q2).  Differs from MATH_IEEE by rounding only
+//              (tested <= 1e-12 relative, bar 1e-10).
 #pragma once
 
 #include <hip/hip_runtime.h>
@@ -37,12 +43,15 @@ struct alignas(16) SurfRec {
     T eta;     // n[i] / n[i+1]               :22
     T eta2;    // eta^2                       :24
     T K;       // K[i+1]
-    T invR;    // 1 / R (0 for a flat row)    MATH_FAST only
+    T invR;    // c = 1 / R (0 for a flat row)   MATH_FAST only
     T pad_;
     int32_t finite;   // isfinite(R)          :2
     int32_t ncoef;    // coefficients in use for this row (0 -> p = zero)
-    int32_t pad2_[2];
+    int32_t kind;     // MATH_FAST row class: KIND_SPHERE / KIND_FLAT / KIND_CONIC / KIND_POLY
+    int32_t cls;      // packed wave-uniform class bits (CLS_*), read once per surface
 };
+
+enum { KIND_SPHERE = 0, KIND_FLAT = 1, KIND_CONIC = 2, KIND_POLY = 3 };
 
 template <typename T>
 struct Ray {
@@ -66,58 +75,43 @@ template <> __device__ __forceinline__ float t_nan<float>() { return __builtin_n
 
 template <typename T> __device__ __forceinline__ bool t_isnan(T a) { return a != a; }
 
-// fast reciprocal / reciprocal square root: hardware seed + Newton steps (MATH_FAST).
+// Fast reciprocal / reciprocal square root (MATH_FAST): hardware seed (relative error
+// 2^-24.4 / 2^-24.2 on gfx950, tools/ubench.hip) + ONE cubically convergent step:
+//   1/a      = r0 (1 + e + e^2 + ...),        e = 1 - a r0        -> error e^3  ~ 2^-73
+//   1/sqrt a = r0 (1 + e/2 + 3e^2/8 + ...),   e = 1 - a r0^2      -> error 5e^3/16 ~ 2^-71
 __device__ __forceinline__ double fast_rcp(double a)
 {
-    double r = __builtin_amdgcn_rcp(a);
-    double e = __builtin_fma(-a, r, 1.0);
-    r = __builtin_fma(r, e, r);
-    e = __builtin_fma(-a, r, 1.0);
-    r = __builtin_fma(r, e, r);
-    return r;
+    const double r0 = __builtin_amdgcn_rcp(a);
+    const double e = __builtin_fma(-a, r0, 1.0);
+    const double p = __builtin_fma(e, e, e);
+    return __builtin_fma(r0, p, r0);
 }
 __device__ __forceinline__ float fast_rcp(float a)
 {
-    float r = __builtin_amdgcn_rcpf(a);
-    float e = __builtin_fmaf(-a, r, 1.0f);
-    return __builtin_fmaf(r, e, r);
+    const float r0 = __builtin_amdgcn_rcpf(a);
+    const float e = __builtin_fmaf(-a, r0, 1.0f);
+    return __builtin_fmaf(r0, e, r0);
 }
 __device__ __forceinline__ double fast_rsqrt(double a)
 {
-    double r = __builtin_amdgcn_rsq(a);
-    // two Newton steps: r <- r + r*(0.5 - 0.5*a*r*r) ... written with the half-residual
-    double h = 0.5 * r;
-    double g = a * r;
-    double e = __builtin_fma(-h, g, 0.5);
-    r = __builtin_fma(r, e, r);
-    h = 0.5 * r;
-    g = a * r;
-    e = __builtin_fma(-h, g, 0.5);
-    r = __builtin_fma(r, e, r);
-    return r;
+    const double r0 = __builtin_amdgcn_rsq(a);
+    const double t = a * r0;
+    const double e = __builtin_fma(-t, r0, 1.0);
+    const double p = __builtin_fma(0.375, e, 0.5);
+    return __builtin_fma(r0, e * p, r0);
 }
 __device__ __forceinline__ float fast_rsqrt(float a)
 {
-    float r = __builtin_amdgcn_rsqf(a);
-    float e = __builtin_fmaf(-0.5f * a * r, r, 0.5f);
-    return __builtin_fmaf(r, e, r);
+    const float r0 = __builtin_amdgcn_rsqf(a);
+    const float e = __builtin_fmaf(-a * r0, r0, 1.0f);
+    return __builtin_fmaf(r0, 0.5f * e, r0);
 }
-// sqrt(a) = a * rsqrt(a), with one correction step; a = 0 handled.
-__device__ __forceinline__ double fast_sqrt(double a)
+// sqrt(a) = a * rsqrt(a); a == 0 -> 0 (the seed is +inf there); a < 0 -> NaN.
+template <typename T>
+__device__ __forceinline__ T fast_sqrt(T a)
 {
-    double r = fast_rsqrt(a);
-    double g = a * r;
-    double d = __builtin_fma(-g, g, a);
-    g = __builtin_fma(0.5 * r, d, g);
-    return a == 0.0 ? 0.0 : g;
-}
-__device__ __forceinline__ float fast_sqrt(float a)
-{
-    float r = fast_rsqrt(a);
-    float g = a * r;
-    float d = __builtin_fmaf(-g, g, a);
-    g = __builtin_fmaf(0.5f * r, d, g);
-    return a == 0.0f ? 0.0f : g;
+    const T g = a * fast_rsqrt(a);
+    return a == T(0) ? T(0) : g;
 }
 
 // p(y), Horner (Types.jl:21-27 restricted to a power series).
@@ -155,7 +149,10 @@ __device__ __forceinline__ void ray_init(Ray<T>& r, T y, T x, T u, T v)
 }
 
 // One loop iteration of src/PupilSampling.jl:45-63 in the reference's operation order.
-template <typename T>
+// FINITE = isfinite(R) (:2), HASP = the row carries polynomial coefficients: both are
+// wave-uniform, so the kernel branches on them ONCE per surface and runs this straight-line
+// body for all of a lane's rays (the scheduler interleaves their div/sqrt chains).
+template <typename T, bool FINITE, bool HASP>
 __device__ __forceinline__ void surface_step_ieee(Ray<T>& r, const SurfRec<T>& s,
                                                   const T* __restrict__ coef)
 {
@@ -163,13 +160,13 @@ __device__ __forceinline__ void surface_step_ieee(Ray<T>& r, const SurfRec<T>& s
     r.y = r.y + r.u * tcur;                          // :46
     r.x = r.x + r.v * tcur;                          // :47
     T sg;
-    if (s.finite) {                                  // wave-uniform (:2)
+    if (FINITE) {                                    // :2
         const T beta = (s.R - r.y * r.u) - r.x * r.v;            // :3
         const T r2 = r.x * r.x + r.y * r.y;                      // :4
         const T D = beta * beta - r2 * ((s.opk + r.u * r.u) + r.v * r.v);   // :5
         sg = r2 / (beta + s.sgn * t_sqrt<T>(D));                 // :7
-        if (s.ncoef > 0) sg = sg + poly_eval<T>(coef, s.ncoef, r.y);
-        else             sg = sg + T(0);
+        if (HASP) sg = sg + poly_eval<T>(coef, s.ncoef, r.y);
+        else      sg = sg + T(0);
         sg = (D >= T(0)) ? sg : t_nan<T>();                      // :6,9
     } else {
         sg = T(0);                                               // :12
@@ -182,7 +179,7 @@ __device__ __forceinline__ void surface_step_ieee(Ray<T>& r, const SurfRec<T>& s
     const T sq = t_sqrt<T>(Dt);
     T tx = s.sgn * r.x / sq;
     T ty = s.sgn * r.y / sq;
-    if (s.ncoef > 0) {
+    if (HASP) {
         tx = tx + poly_deriv<T>(coef, s.ncoef, r.x);             // Q2: p'(x) on the x slope
         ty = ty + poly_deriv<T>(coef, s.ncoef, r.y);
     } else {
@@ -207,70 +204,135 @@ __device__ __forceinline__ void surface_step_ieee(Ray<T>& r, const SurfRec<T>& s
     r.v = r.k0 / r.k2;                               // :60
 }
 
-// The same iteration, algebraically merged (MATH_FAST):
-//   normal: with Dt = R^2 - r^2(1+K), |(tx,ty,-1)|^2 = (R^2 - K r^2)/Dt, hence
-//           m = (sgn x, sgn y, -sqrt(Dt)) / sqrt(R^2 - K r^2)      (no polynomial)
-//   slopes: one reciprocal of k2;  sag: one reciprocal;  FMAs throughout.
+// MATH_FAST, row with a polynomial term: the reference's slope form (sag :1-14, tilt :16-19)
+// with fused arithmetic.  r.sprev is the z offset of the ray point from the current vertex.
 template <typename T>
-__device__ __forceinline__ void surface_step_fast(Ray<T>& r, const SurfRec<T>& s,
-                                                  const T* __restrict__ coef)
+__device__ __forceinline__ void surface_step_fast_poly(Ray<T>& r, const SurfRec<T>& s,
+                                                       const T* __restrict__ coef)
 {
+    const T ik = fast_rcp(r.k2);
+    const T u = r.k1 * ik, v = r.k0 * ik;                        // :59-60
     const T tcur = s.t - r.sprev;
-    r.y = t_fma<T>(r.u, tcur, r.y);
-    r.x = t_fma<T>(r.v, tcur, r.x);
-    T m0, m1, m2;
-    if (s.finite) {
-        const T beta = t_fma<T>(-r.x, r.v, t_fma<T>(-r.y, r.u, s.R));
-        const T r2 = t_fma<T>(r.x, r.x, r.y * r.y);
-        const T A = t_fma<T>(r.v, r.v, t_fma<T>(r.u, r.u, s.opk));
-        const T D = t_fma<T>(beta, beta, -(r2 * A));
-        T sg = r2 * fast_rcp(beta + s.sgn * fast_sqrt(D));
-        if (s.ncoef > 0) sg = sg + poly_eval<T>(coef, s.ncoef, r.y);
-        sg = (D >= T(0)) ? sg : t_nan<T>();
-        r.y = t_fma<T>(sg, r.u, r.y);
-        r.x = t_fma<T>(sg, r.v, r.x);
-        r.sprev = sg;
-        const T rr = t_fma<T>(r.x, r.x, r.y * r.y);
-        const T Dt = t_fma<T>(-rr, s.opk, s.R2);
-        if (s.ncoef > 0) {
-            const T is = s.sgn * fast_rsqrt(Dt);
-            const T tx = t_fma<T>(r.x, is, poly_deriv<T>(coef, s.ncoef, r.x));
-            const T ty = t_fma<T>(r.y, is, poly_deriv<T>(coef, s.ncoef, r.y));
-            const T inv = fast_rsqrt(t_fma<T>(tx, tx, t_fma<T>(ty, ty, T(1))));
-            m0 = tx * inv; m1 = ty * inv; m2 = -inv;
-        } else {
-            const T q = t_fma<T>(-s.K, rr, s.R2);        // R^2 - K r^2
-            const T inv = fast_rsqrt(q);
-            const T si = s.sgn * inv;
-            m0 = r.x * si; m1 = r.y * si; m2 = -(fast_sqrt(Dt) * inv);
-            // Dt < 0 (beyond the conic's rim): reference normal is NaN -> ray undeviated
-            m2 = (Dt >= T(0)) ? m2 : t_nan<T>();
-        }
-    } else {
-        r.sprev = T(0);
-        m0 = T(0); m1 = T(0); m2 = T(-1);
-    }
+    r.y = t_fma<T>(u, tcur, r.y);
+    r.x = t_fma<T>(v, tcur, r.x);
+    const T beta = t_fma<T>(-r.x, v, t_fma<T>(-r.y, u, s.R));
+    const T r2 = t_fma<T>(r.x, r.x, r.y * r.y);
+    const T A = t_fma<T>(v, v, t_fma<T>(u, u, s.opk));
+    const T D = t_fma<T>(beta, beta, -(r2 * A));
+    T sg = r2 * fast_rcp(beta + s.sgn * fast_sqrt<T>(D)) + poly_eval<T>(coef, s.ncoef, r.y);
+    sg = (D >= T(0)) ? sg : t_nan<T>();
+    r.y = t_fma<T>(sg, u, r.y);
+    r.x = t_fma<T>(sg, v, r.x);
+    r.sprev = sg;
+    const T rr = t_fma<T>(r.x, r.x, r.y * r.y);
+    const T is = s.sgn * fast_rsqrt(t_fma<T>(-rr, s.opk, s.R2));
+    const T tx = t_fma<T>(r.x, is, poly_deriv<T>(coef, s.ncoef, r.x));   // Q2
+    const T ty = t_fma<T>(r.y, is, poly_deriv<T>(coef, s.ncoef, r.y));
+    const T inv = fast_rsqrt(t_fma<T>(tx, tx, t_fma<T>(ty, ty, T(1))));
+    const T m0 = tx * inv, m1 = ty * inv, m2 = -inv;
     const T g = -t_fma<T>(r.k2, m2, t_fma<T>(r.k1, m1, r.k0 * m0));
     const T D2 = t_fma<T>(-s.eta2, t_fma<T>(-g, g, T(1)), T(1));
-    const T cf = t_fma<T>(s.eta, g, -fast_sqrt(D2));
     const bool ok = D2 >= T(0);
-    const T n0 = t_fma<T>(s.eta, r.k0, cf * m0);
-    const T n1 = t_fma<T>(s.eta, r.k1, cf * m1);
-    const T n2 = t_fma<T>(s.eta, r.k2, cf * m2);
-    r.k0 = ok ? n0 : r.k0;
-    r.k1 = ok ? n1 : r.k1;
-    r.k2 = ok ? n2 : r.k2;
-    const T ik = fast_rcp(r.k2);
-    r.u = r.k1 * ik;
-    r.v = r.k0 * ik;
+    const T cf = ok ? t_fma<T>(s.eta, g, -fast_sqrt<T>(D2)) : T(0);
+    const T ee = ok ? s.eta : T(1);
+    r.k0 = t_fma<T>(ee, r.k0, cf * m0);
+    r.k1 = t_fma<T>(ee, r.k1, cf * m1);
+    r.k2 = t_fma<T>(ee, r.k2, cf * m2);
 }
 
-template <typename T, int MATH>
-__device__ __forceinline__ void surface_step(Ray<T>& r, const SurfRec<T>& s,
-                                             const T* __restrict__ coef)
+// MATH_FAST, conic row (sphere, flat, conic) in direction-cosine form.  With the ray point
+// P0 = (x, y, z0) relative to the row's vertex and unit direction k (k0 <-> x, k1 <-> y,
+// k2 <-> z), the conic  c (x^2 + y^2 + (1+K) z^2) - 2 z = 0  is met at path length
+//     d = F / (G + sqrt(G^2 - a F)),   F = c (x^2 + y^2 + (1+K) z0^2) - 2 z0,
+//     G = k2 - c (x k0 + y k1 + (1+K) z0 k2),   a = c (1 + K k2^2)
+// (the root that tends to -z0/k2 as c -> 0: the vertex-side sheet the reference picks with
+// sign(R), PupilSampling.jl:7).  The unnormalised normal is (-c x, -c y, 1 - c (1+K) z); on
+// a sphere it is already unit and k.n equals the square root above.
+template <typename T, int KIND, bool REFR>
+__device__ __forceinline__ void surface_step_fast_conic(Ray<T>& r, const SurfRec<T>& s)
 {
-    if (MATH == MATH_IEEE) surface_step_ieee<T>(r, s, coef);
-    else                   surface_step_fast<T>(r, s, coef);
+    const T z0 = r.sprev - s.t;
+    T n0, n1, n2, cosi;
+    if (KIND == KIND_FLAT) {
+        const T d = -z0 * fast_rcp(r.k2);
+        r.x = t_fma<T>(d, r.k0, r.x);
+        r.y = t_fma<T>(d, r.k1, r.y);
+        r.sprev = T(0);
+        if (!REFR) return;
+        n0 = T(0); n1 = T(0); n2 = T(1); cosi = r.k2;
+    } else if (KIND == KIND_SPHERE) {
+        const T c = s.invR;
+        const T Pk = t_fma<T>(z0, r.k2, t_fma<T>(r.y, r.k1, r.x * r.k0));
+        const T P2 = t_fma<T>(z0, z0, t_fma<T>(r.y, r.y, r.x * r.x));
+        const T F = t_fma<T>(c, P2, T(-2) * z0);
+        const T G = t_fma<T>(-c, Pk, r.k2);
+        const T E2 = t_fma<T>(G, G, -(c * F));
+        const T E = fast_sqrt<T>(E2);                            // NaN when the ray misses (:9)
+        const T d = F * fast_rcp(G + E);
+        r.x = t_fma<T>(d, r.k0, r.x);
+        r.y = t_fma<T>(d, r.k1, r.y);
+        const T z = t_fma<T>(d, r.k2, z0);
+        r.sprev = z;
+        n0 = -(c * r.x); n1 = -(c * r.y); n2 = t_fma<T>(-c, z, T(1));
+        cosi = E;
+    } else {
+        const T c = s.invR;
+        const T zk = s.opk * z0;
+        const T Pk = t_fma<T>(zk, r.k2, t_fma<T>(r.y, r.k1, r.x * r.k0));
+        const T P2 = t_fma<T>(zk, z0, t_fma<T>(r.y, r.y, r.x * r.x));
+        const T F = t_fma<T>(c, P2, T(-2) * z0);
+        const T G = t_fma<T>(-c, Pk, r.k2);
+        const T a = c * t_fma<T>(s.K * r.k2, r.k2, T(1));
+        const T E2 = t_fma<T>(G, G, -(a * F));
+        const T E = fast_sqrt<T>(E2);
+        const T d = F * fast_rcp(G + E);
+        r.x = t_fma<T>(d, r.k0, r.x);
+        r.y = t_fma<T>(d, r.k1, r.y);
+        const T z = t_fma<T>(d, r.k2, z0);
+        r.sprev = z;
+        const T N0 = -(c * r.x), N1 = -(c * r.y), N2 = t_fma<T>(-c * s.opk, z, T(1));
+        const T inv = fast_rsqrt(t_fma<T>(N2, N2, t_fma<T>(N1, N1, N0 * N0)));
+        n0 = N0 * inv; n1 = N1 * inv; n2 = N2 * inv;
+        cosi = t_fma<T>(r.k2, n2, t_fma<T>(r.k1, n1, r.k0 * n0));
+    }
+    // vector Snell (:21-32) with n = -m:  k' = eta k + (cos I' - eta cos I) n;  TIR: k stays (Q1)
+    const T D2 = t_fma<T>(-s.eta2, t_fma<T>(-cosi, cosi, T(1)), T(1));
+    const bool ok = D2 >= T(0);
+    const T gam = ok ? t_fma<T>(-s.eta, cosi, fast_sqrt<T>(D2)) : T(0);
+    const T ee = ok ? s.eta : T(1);
+    r.k0 = t_fma<T>(ee, r.k0, gam * n0);
+    r.k1 = t_fma<T>(ee, r.k1, gam * n1);
+    r.k2 = t_fma<T>(ee, r.k2, gam * n2);
+}
+
+// All N rays of a lane through one surface.  `cls` packs the row's wave-uniform class bits
+// (scalar register): the branch is taken once per surface, the bodies are straight-line.
+enum { CLS_FINITE = 1, CLS_HASP = 2, CLS_REFR = 4, CLS_KIND_SHIFT = 4 };
+
+template <typename T, int MATH, int N>
+__device__ __forceinline__ void surface_step_n(Ray<T> (&r)[N], const SurfRec<T>& s,
+                                               const T* __restrict__ coef, int cls)
+{
+#define ORT_ALL_RAYS(call) _Pragma("unroll") for (int q = 0; q < N; ++q) { call; }
+    if (MATH == MATH_IEEE) {
+        if (cls & CLS_FINITE) {
+            if (cls & CLS_HASP) { ORT_ALL_RAYS((surface_step_ieee<T, true, true>(r[q], s, coef))) }
+            else                { ORT_ALL_RAYS((surface_step_ieee<T, true, false>(r[q], s, coef))) }
+        } else {
+            if (cls & CLS_HASP) { ORT_ALL_RAYS((surface_step_ieee<T, false, true>(r[q], s, coef))) }
+            else                { ORT_ALL_RAYS((surface_step_ieee<T, false, false>(r[q], s, coef))) }
+        }
+    } else {
+        const int kind = cls >> CLS_KIND_SHIFT;
+        if (kind == KIND_SPHERE)     { ORT_ALL_RAYS((surface_step_fast_conic<T, KIND_SPHERE, true>(r[q], s))) }
+        else if (kind == KIND_FLAT) {
+            if (cls & CLS_REFR)      { ORT_ALL_RAYS((surface_step_fast_conic<T, KIND_FLAT, true>(r[q], s))) }
+            else                     { ORT_ALL_RAYS((surface_step_fast_conic<T, KIND_FLAT, false>(r[q], s))) }
+        }
+        else if (kind == KIND_CONIC) { ORT_ALL_RAYS((surface_step_fast_conic<T, KIND_CONIC, true>(r[q], s))) }
+        else                         { ORT_ALL_RAYS((surface_step_fast_poly<T>(r[q], s, coef))) }
+    }
+#undef ORT_ALL_RAYS
 }
 
 }  // namespace ort

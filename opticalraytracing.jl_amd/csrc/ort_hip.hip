@@ -128,6 +128,9 @@ void build_records(int nsys, int rows, int ncoef, const double* R, const double*
                 for (int j = 0; j < ncoef; ++j) if ((T)c[j] != T(0)) nc = ncoef;   // all-zero row == `zero`
             }
             r.ncoef = nc;
+            r.kind = nc > 0 ? KIND_POLY : (!r.finite ? KIND_FLAT : (Kv != T(0) ? KIND_CONIC : KIND_SPHERE));
+            r.cls = (r.finite ? CLS_FINITE : 0) | (nc > 0 ? CLS_HASP : 0) | ((r.eta != T(1)) ? CLS_REFR : 0) |
+                    (r.kind << CLS_KIND_SHIFT);
             out[(size_t)s * S + i] = r;
         }
     }

@@ -175,10 +175,11 @@ __global__ __launch_bounds__(kBlock) void k_trace(TraceParams<T> p)
     for (int i = 0; i < S; ++i) {
         const SurfRec<T>& rec = USE_LDS ? s_rec[i] : grec[i];
         const T* cf = USE_LDS ? (s_coef + i * ncoef) : (gcoef ? gcoef + (int64_t)(i + 1) * ncoef : nullptr);
+        const int cls = __builtin_amdgcn_readfirstlane(rec.cls);     // wave-uniform -> scalar branch
+        surface_step_n<T, MATH, kRPT>(ray, rec, cf, cls);
+        if (SUMM || FT) {
 #pragma unroll
-        for (int r = 0; r < kRPT; ++r) {
-            surface_step<T, MATH>(ray[r], rec, cf);
-            if (SUMM || FT) {
+            for (int r = 0; r < kRPT; ++r) {
                 if (st[r] == S + 1 && (t_isnan(ray[r].x) || t_isnan(ray[r].y))) st[r] = i + 1;
                 if (i == stopi) { xs_[r] = ray[r].x; ys_[r] = ray[r].y; }
             }
