@@ -44,7 +44,7 @@ struct alignas(16) SurfRec {
     T eta2;    // eta^2                       :24
     T K;       // K[i+1]
     T invR;    // c = 1 / R (0 for a flat row)   MATH_FAST only
-    T pad_;
+    T ome2;    // 1 - eta^2                   MATH_FAST only
     int32_t finite;   // isfinite(R)          :2
     int32_t ncoef;    // coefficients in use for this row (0 -> p = zero)
     int32_t kind;     // MATH_FAST row class: KIND_SPHERE / KIND_FLAT / KIND_CONIC / KIND_POLY
@@ -74,6 +74,18 @@ template <> __device__ __forceinline__ double t_nan<double>() { return __builtin
 template <> __device__ __forceinline__ float t_nan<float>() { return __builtin_nanf(""); }
 
 template <typename T> __device__ __forceinline__ bool t_isnan(T a) { return a != a; }
+
+template <typename T> __device__ __forceinline__ T t_max(T a, T b);
+template <> __device__ __forceinline__ double t_max<double>(double a, double b) { return __builtin_fmax(a, b); }
+template <> __device__ __forceinline__ float t_max<float>(float a, float b) { return __builtin_fmaxf(a, b); }
+template <typename T> __device__ __forceinline__ T t_tiny();
+template <> __device__ __forceinline__ double t_tiny<double>() { return 1e-300; }
+template <> __device__ __forceinline__ float t_tiny<float>() { return 1e-36f; }
+
+// Keep a value in a VGPR at this point: stops the compiler from sinking the expensive
+// expression that produced it under a lane mask (a branchy select would split the block and
+// serialise the two rays of a lane).
+template <typename T> __device__ __forceinline__ void pin(T& v) { asm volatile("" : "+v"(v)); }
 
 // Fast reciprocal / reciprocal square root (MATH_FAST): hardware seed (relative error
 // 2^-24.4 / 2^-24.2 on gfx950, tools/ubench.hip) + ONE cubically convergent step:
@@ -113,6 +125,10 @@ __device__ __forceinline__ T fast_sqrt(T a)
     const T g = a * fast_rsqrt(a);
     return a == T(0) ? T(0) : g;
 }
+
+// sqrt of a strictly positive argument (caller clamps): no guard.
+template <typename T>
+__device__ __forceinline__ T fast_sqrt_pos(T a) { return a * fast_rsqrt(a); }
 
 // p(y), Horner (Types.jl:21-27 restricted to a power series).
 template <typename T>
@@ -233,7 +249,9 @@ __device__ __forceinline__ void surface_step_fast_poly(Ray<T>& r, const SurfRec<
     const T g = -t_fma<T>(r.k2, m2, t_fma<T>(r.k1, m1, r.k0 * m0));
     const T D2 = t_fma<T>(-s.eta2, t_fma<T>(-g, g, T(1)), T(1));
     const bool ok = D2 >= T(0);
-    const T cf = ok ? t_fma<T>(s.eta, g, -fast_sqrt<T>(D2)) : T(0);
+    T cf = t_fma<T>(s.eta, g, -fast_sqrt_pos<T>(t_max<T>(D2, t_tiny<T>())));
+    pin(cf);
+    cf = ok ? cf : T(0);
     const T ee = ok ? s.eta : T(1);
     r.k0 = t_fma<T>(ee, r.k0, cf * m0);
     r.k1 = t_fma<T>(ee, r.k1, cf * m1);
@@ -248,20 +266,24 @@ __device__ __forceinline__ void surface_step_fast_poly(Ray<T>& r, const SurfRec<
 // (the root that tends to -z0/k2 as c -> 0: the vertex-side sheet the reference picks with
 // sign(R), PupilSampling.jl:7).  The unnormalised normal is (-c x, -c y, 1 - c (1+K) z); on
 // a sphere it is already unit and k.n equals the square root above.
-template <typename T, int KIND, bool REFR>
+// REFR: the row refracts (eta != 1).  TIR: |eta| > 1, total internal reflection is possible
+// and the reference's "k untouched" rule (Q1) needs a select; for |eta| <= 1 the radicand
+// 1 - eta^2 (1 - cos^2 I) >= 1 - eta^2 >= 0 and no select is emitted.
+template <typename T, int KIND, bool REFR, bool TIR>
 __device__ __forceinline__ void surface_step_fast_conic(Ray<T>& r, const SurfRec<T>& s)
 {
     const T z0 = r.sprev - s.t;
-    T n0, n1, n2, cosi;
+    const T c = s.invR;
+    T cos2, cosi, n2;          // n = (-c' x, -c' y, n2) with c' = cn below
+    T cn;
     if (KIND == KIND_FLAT) {
         const T d = -z0 * fast_rcp(r.k2);
         r.x = t_fma<T>(d, r.k0, r.x);
         r.y = t_fma<T>(d, r.k1, r.y);
         r.sprev = T(0);
         if (!REFR) return;
-        n0 = T(0); n1 = T(0); n2 = T(1); cosi = r.k2;
+        cn = T(0); n2 = T(1); cosi = r.k2; cos2 = r.k2 * r.k2;
     } else if (KIND == KIND_SPHERE) {
-        const T c = s.invR;
         const T Pk = t_fma<T>(z0, r.k2, t_fma<T>(r.y, r.k1, r.x * r.k0));
         const T P2 = t_fma<T>(z0, z0, t_fma<T>(r.y, r.y, r.x * r.x));
         const T F = t_fma<T>(c, P2, T(-2) * z0);
@@ -273,10 +295,9 @@ __device__ __forceinline__ void surface_step_fast_conic(Ray<T>& r, const SurfRec
         r.y = t_fma<T>(d, r.k1, r.y);
         const T z = t_fma<T>(d, r.k2, z0);
         r.sprev = z;
-        n0 = -(c * r.x); n1 = -(c * r.y); n2 = t_fma<T>(-c, z, T(1));
-        cosi = E;
+        cn = c; n2 = t_fma<T>(-c, z, T(1));                      // unit normal (-c x, -c y, 1 - c z)
+        cosi = E; cos2 = E2;                                     // k.n = sqrt(G^2 - c F)
     } else {
-        const T c = s.invR;
         const T zk = s.opk * z0;
         const T Pk = t_fma<T>(zk, r.k2, t_fma<T>(r.y, r.k1, r.x * r.k0));
         const T P2 = t_fma<T>(zk, z0, t_fma<T>(r.y, r.y, r.x * r.x));
@@ -290,24 +311,33 @@ __device__ __forceinline__ void surface_step_fast_conic(Ray<T>& r, const SurfRec
         r.y = t_fma<T>(d, r.k1, r.y);
         const T z = t_fma<T>(d, r.k2, z0);
         r.sprev = z;
-        const T N0 = -(c * r.x), N1 = -(c * r.y), N2 = t_fma<T>(-c * s.opk, z, T(1));
+        const T N0 = c * r.x, N1 = c * r.y, N2 = t_fma<T>(-c * s.opk, z, T(1));
         const T inv = fast_rsqrt(t_fma<T>(N2, N2, t_fma<T>(N1, N1, N0 * N0)));
-        n0 = N0 * inv; n1 = N1 * inv; n2 = N2 * inv;
-        cosi = t_fma<T>(r.k2, n2, t_fma<T>(r.k1, n1, r.k0 * n0));
+        cn = c * inv; n2 = N2 * inv;
+        cosi = t_fma<T>(r.k2, n2, -cn * t_fma<T>(r.k1, r.y, r.k0 * r.x));
+        cos2 = cosi * cosi;
     }
-    // vector Snell (:21-32) with n = -m:  k' = eta k + (cos I' - eta cos I) n;  TIR: k stays (Q1)
-    const T D2 = t_fma<T>(-s.eta2, t_fma<T>(-cosi, cosi, T(1)), T(1));
-    const bool ok = D2 >= T(0);
-    const T gam = ok ? t_fma<T>(-s.eta, cosi, fast_sqrt<T>(D2)) : T(0);
-    const T ee = ok ? s.eta : T(1);
-    r.k0 = t_fma<T>(ee, r.k0, gam * n0);
-    r.k1 = t_fma<T>(ee, r.k1, gam * n1);
+    // vector Snell (:21-32) with n = -m:  k' = eta k + (cos I' - eta cos I) n
+    //   1 - eta^2 (1 - cos^2 I) = (1 - eta^2) + eta^2 cos^2 I
+    const T D2 = t_fma<T>(s.eta2, cos2, s.ome2);
+    T cp = fast_sqrt_pos<T>(t_max<T>(D2, t_tiny<T>()));          // radicand clamped: no NaN, sqrt(0) ~ 0
+    T gam = t_fma<T>(-s.eta, cosi, cp);
+    T ee = s.eta;
+    if (TIR) {                                                   // TIR / NaN: k stays (Q1)
+        pin(gam);
+        const bool ok = D2 >= T(0);
+        gam = ok ? gam : T(0);
+        ee = ok ? ee : T(1);
+    }
+    const T gc = gam * cn;
+    r.k0 = t_fma<T>(ee, r.k0, -(gc * r.x));
+    r.k1 = t_fma<T>(ee, r.k1, -(gc * r.y));
     r.k2 = t_fma<T>(ee, r.k2, gam * n2);
 }
 
 // All N rays of a lane through one surface.  `cls` packs the row's wave-uniform class bits
 // (scalar register): the branch is taken once per surface, the bodies are straight-line.
-enum { CLS_FINITE = 1, CLS_HASP = 2, CLS_REFR = 4, CLS_KIND_SHIFT = 4 };
+enum { CLS_FINITE = 1, CLS_HASP = 2, CLS_REFR = 4, CLS_TIR = 8, CLS_KIND_SHIFT = 4 };
 
 template <typename T, int MATH, int N>
 __device__ __forceinline__ void surface_step_n(Ray<T> (&r)[N], const SurfRec<T>& s,
@@ -324,13 +354,18 @@ __device__ __forceinline__ void surface_step_n(Ray<T> (&r)[N], const SurfRec<T>&
         }
     } else {
         const int kind = cls >> CLS_KIND_SHIFT;
-        if (kind == KIND_SPHERE)     { ORT_ALL_RAYS((surface_step_fast_conic<T, KIND_SPHERE, true>(r[q], s))) }
-        else if (kind == KIND_FLAT) {
-            if (cls & CLS_REFR)      { ORT_ALL_RAYS((surface_step_fast_conic<T, KIND_FLAT, true>(r[q], s))) }
-            else                     { ORT_ALL_RAYS((surface_step_fast_conic<T, KIND_FLAT, false>(r[q], s))) }
+        const bool tir = cls & CLS_TIR;
+        if (kind == KIND_SPHERE) {
+            if (tir) { ORT_ALL_RAYS((surface_step_fast_conic<T, KIND_SPHERE, true, true>(r[q], s))) }
+            else     { ORT_ALL_RAYS((surface_step_fast_conic<T, KIND_SPHERE, true, false>(r[q], s))) }
+        } else if (kind == KIND_FLAT) {
+            if (!(cls & CLS_REFR)) { ORT_ALL_RAYS((surface_step_fast_conic<T, KIND_FLAT, false, false>(r[q], s))) }
+            else                   { ORT_ALL_RAYS((surface_step_fast_conic<T, KIND_FLAT, true, true>(r[q], s))) }
+        } else if (kind == KIND_CONIC) {
+            ORT_ALL_RAYS((surface_step_fast_conic<T, KIND_CONIC, true, true>(r[q], s)))
+        } else {
+            ORT_ALL_RAYS((surface_step_fast_poly<T>(r[q], s, coef)))
         }
-        else if (kind == KIND_CONIC) { ORT_ALL_RAYS((surface_step_fast_conic<T, KIND_CONIC, true>(r[q], s))) }
-        else                         { ORT_ALL_RAYS((surface_step_fast_poly<T>(r[q], s, coef))) }
     }
 #undef ORT_ALL_RAYS
 }

@@ -129,7 +129,9 @@ void build_records(int nsys, int rows, int ncoef, const double* R, const double*
             }
             r.ncoef = nc;
             r.kind = nc > 0 ? KIND_POLY : (!r.finite ? KIND_FLAT : (Kv != T(0) ? KIND_CONIC : KIND_SPHERE));
+            r.ome2 = T(1) - r.eta2;
             r.cls = (r.finite ? CLS_FINITE : 0) | (nc > 0 ? CLS_HASP : 0) | ((r.eta != T(1)) ? CLS_REFR : 0) |
+                    (!(std::fabs(r.eta) <= T(1)) ? CLS_TIR : 0) |
                     (r.kind << CLS_KIND_SHIFT);
             out[(size_t)s * S + i] = r;
         }
