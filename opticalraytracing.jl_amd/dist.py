@@ -52,8 +52,9 @@ def allgather_hits(xf, yf, group=None):
     world = dist.get_world_size(group)
     n = xf.numel()
     packed = torch.stack([xf.reshape(-1), yf.reshape(-1)])            # [2, n]
-    out = torch.empty((world, 2, n), dtype=packed.dtype, device=packed.device)
-    dist.all_gather_into_tensor(out, packed, group=group)
+    out = torch.empty((world * 2, n), dtype=packed.dtype, device=packed.device)   # concat along dim 0
+    dist.all_gather_into_tensor(out, packed.contiguous(), group=group)
+    out = out.view(world, 2, n)
     return out[:, 0, :].reshape(-1), out[:, 1, :].reshape(-1)
 
 
@@ -69,8 +70,9 @@ def allgather_ragged(values, group=None):
     m = int(counts.max().item())
     pad = torch.zeros(m, dtype=values.dtype, device=values.device)
     pad[:values.numel()] = values.reshape(-1)
-    out = torch.empty((world, m), dtype=values.dtype, device=values.device)
+    out = torch.empty((world * m,), dtype=values.dtype, device=values.device)
     dist.all_gather_into_tensor(out, pad, group=group)
+    out = out.view(world, m)
     return torch.cat([out[r, :int(counts[r].item())] for r in range(world)])
 
 
