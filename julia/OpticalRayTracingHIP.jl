@@ -1,0 +1,132 @@
+# OpticalRayTracingHIP.jl — `ccall` shim over libort_hip.so (include/ort.h).
+#
+# Adds BATCH methods with the reference's names and argument order to OpticalRayTracing.jl,
+# and a `full_trace` that replaces only the grid stage (src/PupilSampling.jl:115-146), taking
+# the aiming scalars from the unmodified reference code.  Not exercised in the build container
+# (no Julia runtime there); the same C ABI is exercised through ctypes by the Python mirror.
+#
+#   ENV["ORT_HIP_LIB"] = "/path/to/libort_hip.so";  include("OpticalRayTracingHIP.jl")
+module OpticalRayTracingHIP
+
+using OpticalRayTracing
+import OpticalRayTracing: raytrace, full_trace, Layout, System, RealRay, RealRayError, TransferMatrix, Lens
+
+const LIB = get(ENV, "ORT_HIP_LIB", joinpath(@__DIR__, "..", "opticalraytracing.jl_amd", "csrc", "libort_hip.so"))
+
+const ORT_FAST_MATH = UInt32(1) << 5
+const ORT_CLIP = UInt32(1) << 4
+const ORT_LAYOUT_INPUT = UInt32(1) << 3
+
+struct OrtBundle            # == ort_bundle (include/ort.h)
+    system::Int32; stop::Int32
+    U::Float64; V::Float64; a_stop::Float64; hprime::Float64; ybar::Float64; z0::Float64
+    yaxis_off::Int64; xaxis_off::Int64
+end
+
+lasterr() = unsafe_string(ccall((:ort_last_error, LIB), Cstring, ()))
+check(rc) = rc == 0 ? nothing : rc == -2 ? throw(DomainError(rc, lasterr())) : error("ort: " * lasterr())
+
+mutable struct Context
+    h::Ptr{Cvoid}
+    function Context(device::Integer = 0)
+        r = Ref{Ptr{Cvoid}}(C_NULL)
+        check(ccall((:ort_ctx_create, LIB), Cint, (Cint, Ptr{Cvoid}, Ref{Ptr{Cvoid}}), device, C_NULL, r))
+        finalizer(c -> ccall((:ort_ctx_destroy, LIB), Cint, (Ptr{Cvoid},), c.h), new(r[]))
+    end
+end
+const CTX = Ref{Context}()
+ctx() = (isassigned(CTX) || (CTX[] = Context()); CTX[])
+
+"Power-series coefficients of a row's polynomial; the closure handed to the CPU path is built from the same vector."
+poly(c::Vector{Float64}) = OpticalRayTracing.Polynomial(y -> evalpoly(y, c))
+
+function upload(R, t, n, K = nothing, coef = nothing)
+    rows = length(R)
+    ncoef = coef === nothing ? 0 : size(coef, 2)
+    cT = coef === nothing ? C_NULL : pointer(permutedims(coef))     # [rows][ncoef] row-major
+    r = Ref{Ptr{Cvoid}}(C_NULL)
+    GC.@preserve R t n K coef check(ccall((:ort_system_create, LIB), Cint,
+        (Ptr{Cvoid}, Cint, Cint, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Cint, Ref{Ptr{Cvoid}}),
+        ctx().h, 1, rows, R, t, n, K === nothing ? C_NULL : pointer(K), cT, ncoef, r))
+    return r[]
+end
+release(sys) = ccall((:ort_system_destroy, LIB), Cint, (Ptr{Cvoid},), sys)
+
+# raytrace(surfaces, y, x, U, V, Vector{RealRay}) over ray VECTORS -> (xv, yv), each N x (rows-1)
+# (column j = surface j: the surface-major layout of the ABI is a Julia N x S matrix)
+function raytrace(surfaces::AbstractMatrix, y::Vector{Float64}, x::Vector{Float64},
+                  U::Vector{Float64}, V::Vector{Float64}, ::Type{Vector{RealRay}};
+                  K = nothing, coef = nothing, flags::UInt32 = UInt32(0))
+    M = Matrix{Float64}(surfaces[:, 1:3]); rows = size(M, 1); N = length(y)
+    sys = upload(M[:, 1], M[:, 2], M[:, 3], K, coef)
+    xv = Matrix{Float64}(undef, N, rows - 1); yv = similar(xv)
+    GC.@preserve y x U V xv yv check(ccall((:ort_trace_skew_f64, LIB), Cint,
+        (Ptr{Cvoid}, Ptr{Cvoid}, Cint, Int64, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64},
+         Ptr{Float64}, Ptr{Float64}, Int64, Ptr{Int32}, UInt32),
+        ctx().h, sys, 0, N, y, x, U, V, xv, yv, N, C_NULL, flags))
+    release(sys)
+    return xv, yv
+end
+
+# raytrace(surfaces, y, U, RealRay) over ray vectors -> (y, U, ts) N x rows; z = cumsum(ts, dims = 2)
+function raytrace(surfaces::AbstractMatrix, y::Vector{Float64}, U::Vector{Float64}, ::Type{RealRay};
+                  K = nothing, coef = nothing)
+    M = Matrix{Float64}(surfaces[:, 1:3]); rows = size(M, 1); N = length(y)
+    sys = upload(M[:, 1], M[:, 2], M[:, 3], K, coef)
+    yo = Matrix{Float64}(undef, N, rows); Uo = similar(yo); ts = similar(yo)
+    flags = surfaces isa Layout{OpticalRayTracing.Aspheric} ? ORT_LAYOUT_INPUT : UInt32(0)
+    GC.@preserve y U yo Uo ts check(ccall((:ort_trace_meridional_f64, LIB), Cint,
+        (Ptr{Cvoid}, Ptr{Cvoid}, Cint, Int64, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Int64, UInt32),
+        ctx().h, sys, 0, N, y, U, yo, Uo, ts, N, flags))
+    release(sys)
+    return yo, Uo, ts
+end
+
+# raytrace(lens, y, ω, a; clip) over ray vectors -> (rt_y, rt_ω) N x (k+1)
+function raytrace(lens::Lens, y::Vector{Float64}, ω::Vector{Float64},
+                  a::AbstractVector = fill(Inf, size(lens, 1)); clip = false)
+    τ = lens.M[:, 1]; ϕ = lens.M[:, 2]; k = length(τ); N = length(y); av = Vector{Float64}(a)
+    rt_y = Matrix{Float64}(undef, N, k + 1); rt_w = similar(rt_y)
+    GC.@preserve τ ϕ av y ω rt_y rt_w check(ccall((:ort_trace_paraxial_f64, LIB), Cint,
+        (Ptr{Cvoid}, Cint, Cint, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Int64, Ptr{Float64}, Ptr{Float64},
+         Ptr{Float64}, Ptr{Float64}, Int64, UInt32),
+        ctx().h, 1, k, τ, ϕ, av, N, y, ω, rt_y, rt_w, N, clip ? ORT_CLIP : UInt32(0)))
+    return rt_y, rt_w
+end
+
+# TransferMatrix(lens) on the device
+function transfer_matrix(lens::Lens)
+    τ = lens.M[:, 1]; ϕ = lens.M[:, 2]; M = Vector{Float64}(undef, 4)
+    GC.@preserve τ ϕ M check(ccall((:ort_abcd_f64, LIB), Cint,
+        (Ptr{Cvoid}, Cint, Cint, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, UInt32), ctx().h, 1, length(τ), τ, ϕ, M, 0))
+    return TransferMatrix(permutedims(reshape(M, 2, 2)))
+end
+
+# full_trace: aiming by the UNMODIFIED reference (src/PupilSampling.jl:88-114), grid stage on the GPU
+function full_trace(surfaces::Layout, system::System, H::Float64, k_rays::Int, focus, ::Val{:hip};
+                    coef = nothing, flags::UInt32 = UInt32(0))
+    H = abs(H); H ≤ 1.0 || throw(DomainError(H, "Domain: |H| ≤ 1.0"))
+    stop = system.stop; a_stop = abs(system.a[stop])
+    real_chief = trace_chief_ray(surfaces, system); real_marginal = trace_marginal_ray(surfaces, system)
+    EP_t = real_chief.z[1]; U = H * real_chief.u[1]; u = tan(U); y_EP = abs(real_marginal.y[1])
+    y1, y2 = OpticalRayTracing.trace_edge_rays(surfaces, y_EP - u * EP_t, -y_EP - u * EP_t, U, stop, a_stop)
+    h′ = u * system.f
+    R = [surfaces[:, 1]; Inf]; t = [surfaces[:, 2]; 0.0]; n = [surfaces[:, 3]; 1.0]; t[end-1] = focus
+    K = [surfaces.K; 0.0]
+    sys = upload(R, t, n, K, coef === nothing ? nothing : [coef; zeros(1, size(coef, 2))])
+    k2 = div(k_rays, 2)
+    axes = [collect(range(y1, y2, k_rays)); collect(range(0.0, y_EP, k2))]     # exact Julia grid
+    b = [OrtBundle(0, stop, U, 0.0, a_stop, h′, 0.0, 1.0, 0, k_rays)]
+    cap = 2 * k_rays * k2
+    εx = Vector{Float64}(undef, cap); εy = similar(εx); ρ = similar(εx); θ = similar(εx)
+    cnt = Ref{Int64}(0); rms = Ref{Float64}(0.0)
+    GC.@preserve axes b εx εy ρ θ check(ccall((:ort_full_trace_f64, LIB), Cint,
+        (Ptr{Cvoid}, Ptr{Cvoid}, Cint, Ptr{OrtBundle}, Ptr{Float64}, Int64, Cint, Cint,
+         Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ref{Int64}, Ref{Float64}, UInt32),
+        ctx().h, sys, 1, b, axes, length(axes), k_rays, k2, εx, εy, ρ, θ, cnt, rms, flags))
+    release(sys)
+    m = cnt[]
+    return RealRayError(εx[1:m], εy[1:m], system.marginal.nu[end], ρ[1:m], θ[1:m], H, rms[])
+end
+
+end # module
