@@ -84,7 +84,11 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--pupil", type=int, default=1024, help="pupil grid edge per bundle (config 2: 1024)")
-    ap.add_argument("--fast-math", action="store_true", help="merged-arithmetic policy (|rel err| <= 1e-12)")
+    ap.add_argument("--policy", default="fast", choices=["fast", "ieee"],
+                    help="arithmetic policy of the timed kernel: fast = direction-cosine form (<= 1e-12 relative vs "
+                         "the reference sequence, bar 1e-10); ieee = the reference's IEEE operation sequence "
+                         "(bit-identical to the CPU oracle).  The other policy is timed too and reported beside it.")
+    ap.add_argument("--fast-math", action="store_true", help="alias of --policy fast")
     ap.add_argument("--no-lds", action="store_true", help="surface table through scalar loads instead of LDS")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--mode", default="history", choices=["history", "summary", "full_trace"])
@@ -96,20 +100,29 @@ def main():
     import opticalraytracing_jl_amd as ort
     from opticalraytracing_jl_amd import _capi, api, dist as odist, workloads
 
+    if args.fast_math:
+        args.policy = "fast"
+    args.fast_math = args.policy == "fast"
     rank, world, local_rank = odist.env_rank_world()
     if args.gpus > 1 and world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} needs torchrun with {args.gpus} ranks (WORLD_SIZE={world})")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the engine has no CPU fallback")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    ndev = torch.cuda.device_count()
+    backend = os.environ.get("ORT_BENCH_BACKEND", "nccl")     # "gloo": rehearsal of N > 1 on a 1-GPU box
+    if backend == "nccl" and world > ndev:
+        raise SystemExit(f"{world} ranks but {ndev} GPUs: one process per GPU")
+    local_dev = local_rank % ndev
+    torch.cuda.set_device(local_dev)
+    dev = torch.device("cuda", local_dev)
+    cdev = dev if backend == "nccl" else torch.device("cpu")   # where collective buffers live
     dist = None
     if world > 1:
-        dist = odist.init_process_group("nccl")
+        dist = odist.init_process_group(backend)
 
     stream = torch.cuda.current_stream(dev)
     flags0 = (_capi.ORT_FAST_MATH if args.fast_math else 0) | (_capi.ORT_NO_LDS if args.no_lds else 0)
-    eng = ort.HipEngine(local_rank, stream=stream.cuda_stream, fast_math=args.fast_math, use_lds=not args.no_lds)
+    eng = ort.HipEngine(local_dev, stream=stream.cuda_stream, fast_math=args.fast_math, use_lds=not args.no_lds)
     ort.set_default_engine(eng)
     info = eng.ctx.device_info()
 
@@ -179,16 +192,34 @@ def main():
     torch.cuda.synchronize(dev)
     wall = time.perf_counter() - t0
     if dist is not None:
-        tw = torch.tensor([wall, ev_ms], dtype=torch.float64, device=dev)
+        tw = torch.tensor([wall, ev_ms], dtype=torch.float64, device=cdev)
         dist.all_reduce(tw, op=dist.ReduceOp.MAX)
         wall, ev_ms = float(tw[0]), float(tw[1])
+
+    # ---- the other arithmetic policy, same launch, reported beside the headline (rank 0, N = 1) ----
+    other = None
+    if world == 1 and args.mode != "full_trace":
+        ofl = (fl & ~_capi.ORT_FAST_MATH) if args.fast_math else (fl | _capi.ORT_FAST_MATH)
+        def ostep():
+            _capi.check(lib.ort_trace_grid_f64(h, sysd.h, nb, barr, d_axes.data_ptr(), axes.size, k, k, C.byref(out), ofl))
+        for _ in range(2):
+            ostep()
+        torch.cuda.synchronize(dev)
+        eng.ctx.timer_start()
+        osteps = max(3, args.steps // 2)
+        for _ in range(osteps):
+            ostep()
+        oms = eng.ctx.timer_stop() / osteps
+        other = {"policy": "ieee" if args.fast_math else "fast", "kernel_ms": oms,
+                 "value": inter / (oms * 1e-3), "achieved_GBps": algo_bytes / (oms * 1e-3) / 1e9,
+                 "frac": algo_bytes / (oms * 1e-3) / 1e9 / HBM_PEAK_GBS}
 
     # ---- the single reassembly all-gather of image-plane hits (untimed region, timed alone) ----
     gather = None
     if dist is not None and hits is not None:
         torch.cuda.synchronize(dev); dist.barrier()
         g0 = time.perf_counter()
-        gx, gy = odist.allgather_hits(hits[0], hits[1])
+        gx, gy = odist.allgather_hits(hits[0].to(cdev), hits[1].to(cdev))
         torch.cuda.synchronize(dev); dist.barrier()
         gdt = time.perf_counter() - g0
         gbytes = 16.0 * N * world
@@ -230,6 +261,8 @@ def main():
                      "algorithmic_bytes_per_launch": algo_bytes,
                      "frac_of_measured_copy_rate": achieved / HBM_MEASURED_COPY_GBS},
     }
+    if other is not None:
+        res["other_policy"] = other
     if gather is not None:
         res["allgather"] = gather
     if not args.no_cpu_baseline and world == 1:

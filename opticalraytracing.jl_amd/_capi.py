@@ -14,7 +14,7 @@ from typing import Optional
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "csrc", "libort_hip.so")
+LIB_PATH = os.environ.get("ORT_HIP_LIB") or os.path.join(_HERE, "csrc", "libort_hip.so")
 
 # flags / codes (include/ort.h)
 ORT_DEVICE_PTRS = 1 << 0

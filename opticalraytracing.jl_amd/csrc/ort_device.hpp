@@ -42,16 +42,18 @@ struct alignas(16) SurfRec {
     T opk;     // 1 + K[i+1]                  :5,17
     T eta;     // n[i] / n[i+1]               :22
     T eta2;    // eta^2                       :24
-    T K;       // K[i+1]
+    T K;       // K[i+1]; for KIND_SPHERE_C rows: t + R (centre form)
     T invR;    // c = 1 / R (0 for a flat row)   MATH_FAST only
     T ome2;    // 1 - eta^2                   MATH_FAST only
+    T e2c2;    // eta^2 c^2                   MATH_FAST centre form
+    T ec;      // eta |c|                     MATH_FAST centre form
     int32_t finite;   // isfinite(R)          :2
     int32_t ncoef;    // coefficients in use for this row (0 -> p = zero)
     int32_t kind;     // MATH_FAST row class: KIND_SPHERE / KIND_FLAT / KIND_CONIC / KIND_POLY
     int32_t cls;      // packed wave-uniform class bits (CLS_*), read once per surface
 };
 
-enum { KIND_SPHERE = 0, KIND_FLAT = 1, KIND_CONIC = 2, KIND_POLY = 3 };
+enum { KIND_SPHERE = 0, KIND_FLAT = 1, KIND_CONIC = 2, KIND_POLY = 3, KIND_SPHERE_C = 4 };
 
 template <typename T>
 struct Ray {
@@ -335,6 +337,45 @@ __device__ __forceinline__ void surface_step_fast_conic(Ray<T>& r, const SurfRec
     r.k2 = t_fma<T>(ee, r.k2, gam * n2);
 }
 
+// MATH_FAST, strongly curved sphere (|R| <= kCentreFormMaxR) in CENTRE form: with Q = P - C
+// (C = centre of curvature) the sphere is |Q|^2 = R^2, the vertex-side root of the quadratic is
+//     d = -b - sign(R) sqrt(b^2 - |Q0|^2 + R^2),   b = Q0 . k,
+// no reciprocal at all; the unit normal is -Q/R and cos I = |c| sqrt(...).  d is a difference of
+// two numbers of size |R|, so its absolute error is ~eps |R|: kept to rows where that is
+// << 1e-10 x 1 mm (measured <= 2e-13 relative on the Tessar's R = -275.7 row).
+// s.K holds t + R for these rows.
+constexpr double kCentreFormMaxR = 1.0e3;
+
+template <typename T, bool TIR>
+__device__ __forceinline__ void surface_step_fast_sphere_c(Ray<T>& r, const SurfRec<T>& s)
+{
+    const T Qz0 = r.sprev - s.K;
+    const T b = t_fma<T>(Qz0, r.k2, t_fma<T>(r.y, r.k1, r.x * r.k0));
+    const T q = t_fma<T>(Qz0, Qz0, t_fma<T>(r.y, r.y, r.x * r.x));
+    const T disc = t_fma<T>(b, b, s.R2 - q);
+    const T sq = fast_sqrt<T>(disc);                             // NaN when the ray misses (:9)
+    const T d = -t_fma<T>(s.sgn, sq, b);
+    r.x = t_fma<T>(d, r.k0, r.x);
+    r.y = t_fma<T>(d, r.k1, r.y);
+    const T Qz = t_fma<T>(d, r.k2, Qz0);
+    r.sprev = Qz + s.R;
+    const T c = s.invR;
+    const T D2 = t_fma<T>(s.e2c2, disc, s.ome2);                 // (1 - eta^2) + eta^2 cos^2 I
+    const T cp = fast_sqrt_pos<T>(t_max<T>(D2, t_tiny<T>()));
+    T gam = t_fma<T>(-s.ec, sq, cp);                             // cos I' - eta cos I, cos I = |c| sq
+    T ee = s.eta;
+    if (TIR) {
+        pin(gam);
+        const bool ok = D2 >= T(0);
+        gam = ok ? gam : T(0);
+        ee = ok ? ee : T(1);
+    }
+    const T gc = gam * c;
+    r.k0 = t_fma<T>(ee, r.k0, -(gc * r.x));
+    r.k1 = t_fma<T>(ee, r.k1, -(gc * r.y));
+    r.k2 = t_fma<T>(ee, r.k2, -(gc * Qz));
+}
+
 // All N rays of a lane through one surface.  `cls` packs the row's wave-uniform class bits
 // (scalar register): the branch is taken once per surface, the bodies are straight-line.
 enum { CLS_FINITE = 1, CLS_HASP = 2, CLS_REFR = 4, CLS_TIR = 8, CLS_KIND_SHIFT = 4 };
@@ -361,6 +402,9 @@ __device__ __forceinline__ void surface_step_n(Ray<T> (&r)[N], const SurfRec<T>&
         } else if (kind == KIND_FLAT) {
             if (!(cls & CLS_REFR)) { ORT_ALL_RAYS((surface_step_fast_conic<T, KIND_FLAT, false, false>(r[q], s))) }
             else                   { ORT_ALL_RAYS((surface_step_fast_conic<T, KIND_FLAT, true, true>(r[q], s))) }
+        } else if (kind == KIND_SPHERE_C) {
+            if (tir) { ORT_ALL_RAYS((surface_step_fast_sphere_c<T, true>(r[q], s))) }
+            else     { ORT_ALL_RAYS((surface_step_fast_sphere_c<T, false>(r[q], s))) }
         } else if (kind == KIND_CONIC) {
             ORT_ALL_RAYS((surface_step_fast_conic<T, KIND_CONIC, true, true>(r[q], s)))
         } else {

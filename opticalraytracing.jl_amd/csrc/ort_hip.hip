@@ -129,7 +129,13 @@ void build_records(int nsys, int rows, int ncoef, const double* R, const double*
             }
             r.ncoef = nc;
             r.kind = nc > 0 ? KIND_POLY : (!r.finite ? KIND_FLAT : (Kv != T(0) ? KIND_CONIC : KIND_SPHERE));
+            if (r.kind == KIND_SPHERE && std::fabs((double)Rv) <= kCentreFormMaxR && sizeof(T) == 8) {
+                r.kind = KIND_SPHERE_C;            // MATH_FAST centre form; K (== 0 here) carries t + R
+                r.K = r.t + Rv;
+            }
             r.ome2 = T(1) - r.eta2;
+            r.e2c2 = r.eta2 * (r.invR * r.invR);
+            r.ec = r.eta * std::fabs(r.invR);
             r.cls = (r.finite ? CLS_FINITE : 0) | (nc > 0 ? CLS_HASP : 0) | ((r.eta != T(1)) ? CLS_REFR : 0) |
                     (!(std::fabs(r.eta) <= T(1)) ? CLS_TIR : 0) |
                     (r.kind << CLS_KIND_SHIFT);
@@ -497,7 +503,7 @@ int ort_system_create(ort_ctx* ctx, int nsys, int rows, const double* R, const d
             const SurfRec<double>& r = r64[(size_t)s * S + i];
             MerSurf m;
             memset(&m, 0, sizeof m);
-            m.t = r.t; m.R = r.R; m.sgn = r.sgn; m.K = r.K;
+            m.t = r.t; m.R = r.R; m.sgn = r.sgn; m.K = K ? K[(size_t)s * rows + i + 1] : 0.0;
             m.n1 = n[(size_t)s * rows + i]; m.n2 = n[(size_t)s * rows + i + 1];
             m.finite = r.finite; m.ncoef = r.ncoef;
             mer[(size_t)s * S + i] = m;

@@ -21,8 +21,18 @@
 
 namespace ort {
 
+// Tunables (compile-time; the defaults are the measured best).
+#ifndef ORT_RPT
+#define ORT_RPT 2            // rays per lane
+#endif
+#ifndef ORT_NT_STORES
+#define ORT_NT_STORES 1      // non-temporal history stores
+#endif
+#ifndef ORT_MIN_WAVES
+#define ORT_MIN_WAVES 5      // __launch_bounds__ 2nd argument (waves per SIMD): 96 VGPRs, no spill in the fast history kernel
+#endif
 constexpr int kBlock = 256;
-constexpr int kRPT = 2;
+constexpr int kRPT = ORT_RPT;
 constexpr int kTile = kBlock * kRPT;
 constexpr int kMaxRows = 64;
 constexpr int kMaxCoef = 12;
@@ -75,11 +85,32 @@ __device__ __forceinline__ void store_pair(T* base, int64_t g, bool two, T a, T 
     const bool aligned = (reinterpret_cast<uintptr_t>(base + g) & (2 * sizeof(T) - 1)) == 0;
     if (two && aligned) {
         typename Vec2<T>::type v2; v2.x = a; v2.y = b;
+#if ORT_NT_STORES
         __builtin_nontemporal_store(v2, reinterpret_cast<typename Vec2<T>::type*>(base + g));
+#else
+        *reinterpret_cast<typename Vec2<T>::type*>(base + g) = v2;
+#endif
     } else {
+#if ORT_NT_STORES
         __builtin_nontemporal_store(a, base + g);
         if (two) __builtin_nontemporal_store(b, base + g + 1);
+#else
+        base[g] = a;
+        if (two) base[g + 1] = b;
+#endif
     }
+}
+
+// Unconditional 2-ray vector store (the caller has established alignment and liveness).
+template <typename T>
+__device__ __forceinline__ void store_vec2(T* p, T a, T b)
+{
+    typename Vec2<T>::type v2; v2.x = a; v2.y = b;
+#if ORT_NT_STORES
+    __builtin_nontemporal_store(v2, reinterpret_cast<typename Vec2<T>::type*>(p));
+#else
+    *reinterpret_cast<typename Vec2<T>::type*>(p) = v2;
+#endif
 }
 
 __device__ __forceinline__ double dev_tan(double a) { return ::tan(a); }
@@ -95,7 +126,7 @@ __device__ __forceinline__ float dev_atan2(float a, float b) { return ::atan2f(a
 // FT: full_trace epilogue (stop filter, dense workspace, tile aggregates).
 // ------------------------------------------------------------------------------------
 template <typename T, int MATH, bool USE_LDS, bool GRID, bool HIST, bool SUMM, bool FT>
-__global__ __launch_bounds__(kBlock) void k_trace(TraceParams<T> p)
+__global__ __launch_bounds__(kBlock, ORT_MIN_WAVES) void k_trace(TraceParams<T> p)
 {
     __shared__ SurfRec<T> s_rec[USE_LDS ? kMaxRows : 1];
     __shared__ T s_coef[USE_LDS ? kMaxRows * kMaxCoef : 1];
@@ -170,7 +201,18 @@ __global__ __launch_bounds__(kBlock) void k_trace(TraceParams<T> p)
         st[r] = S + 1;
         xs_[r] = T(0); ys_[r] = T(0);
     }
-    const bool two = live[1];
+    const bool two = (kRPT > 1) && live[kRPT - 1];
+    // History stores: one wave-uniform decision, taken once — every lane of the wave owns two live
+    // rays and both row bases keep 16-byte alignment on every surface (ld even) -> plain
+    // 16-byte stores off a scalar row base; otherwise the guarded per-lane path.
+    const int lane_off = tid * kRPT;
+    const int64_t blockbase = gbase - lane_off;                  // wave-uniform
+    bool vec_all = false;
+    if (HIST && kRPT == 2) {
+        const bool al = ((reinterpret_cast<uintptr_t>(p.xv + gbase) | reinterpret_cast<uintptr_t>(p.yv + gbase)) &
+                         (2 * sizeof(T) - 1)) == 0 && (p.ld & 1) == 0;
+        vec_all = __all(two && al);
+    }
 
     for (int i = 0; i < S; ++i) {
         const SurfRec<T>& rec = USE_LDS ? s_rec[i] : grec[i];
@@ -185,19 +227,24 @@ __global__ __launch_bounds__(kBlock) void k_trace(TraceParams<T> p)
             }
         }
         if (HIST) {
-            if (live[0]) {
-                store_pair<T>(p.xv + (int64_t)i * p.ld, gbase, two, ray[0].x, ray[1].x);
-                store_pair<T>(p.yv + (int64_t)i * p.ld, gbase, two, ray[0].y, ray[1].y);
+            if (vec_all) {
+                T* rx = p.xv + ((int64_t)i * p.ld + blockbase);  // scalar row base
+                T* ry = p.yv + ((int64_t)i * p.ld + blockbase);
+                store_vec2<T>(rx + lane_off, ray[0].x, ray[kRPT - 1].x);
+                store_vec2<T>(ry + lane_off, ray[0].y, ray[kRPT - 1].y);
+            } else if (live[0]) {
+                store_pair<T>(p.xv + (int64_t)i * p.ld, gbase, two, ray[0].x, ray[kRPT - 1].x);
+                store_pair<T>(p.yv + (int64_t)i * p.ld, gbase, two, ray[0].y, ray[kRPT - 1].y);
             }
         }
     }
 
     if (SUMM) {
         if (live[0]) {
-            if (p.xf) store_pair<T>(p.xf, gbase, two, ray[0].x, ray[1].x);
-            if (p.yf) store_pair<T>(p.yf, gbase, two, ray[0].y, ray[1].y);
-            if (p.xs) store_pair<T>(p.xs, gbase, two, xs_[0], xs_[1]);
-            if (p.ys) store_pair<T>(p.ys, gbase, two, ys_[0], ys_[1]);
+            if (p.xf) store_pair<T>(p.xf, gbase, two, ray[0].x, ray[kRPT - 1].x);
+            if (p.yf) store_pair<T>(p.yf, gbase, two, ray[0].y, ray[kRPT - 1].y);
+            if (p.xs) store_pair<T>(p.xs, gbase, two, xs_[0], xs_[kRPT - 1]);
+            if (p.ys) store_pair<T>(p.ys, gbase, two, ys_[0], ys_[kRPT - 1]);
             if (p.status) {
 #pragma unroll
                 for (int r = 0; r < kRPT; ++r) {
@@ -230,10 +277,10 @@ __global__ __launch_bounds__(kBlock) void k_trace(TraceParams<T> p)
             if (!drop) { ++cnt; sx += (double)exv[r]; sy += (double)eyv[r]; rmax = fmax(rmax, (double)ri); }
         }
         if (live[0]) {
-            store_pair<T>(p.w_ex, gbase, two, exv[0], exv[1]);
-            store_pair<T>(p.w_ey, gbase, two, eyv[0], eyv[1]);
-            store_pair<T>(p.w_r, gbase, two, rv[0], rv[1]);
-            store_pair<T>(p.w_th, gbase, two, thv[0], thv[1]);
+            store_pair<T>(p.w_ex, gbase, two, exv[0], exv[kRPT - 1]);
+            store_pair<T>(p.w_ey, gbase, two, eyv[0], eyv[kRPT - 1]);
+            store_pair<T>(p.w_r, gbase, two, rv[0], rv[kRPT - 1]);
+            store_pair<T>(p.w_th, gbase, two, thv[0], thv[kRPT - 1]);
         }
         // tile aggregates: fixed-shape tree -> bitwise reproducible
         for (int off = 32; off > 0; off >>= 1) {
@@ -355,7 +402,7 @@ __global__ __launch_bounds__(kBlock) void k_ft_scatter(const T* __restrict__ w_e
         keep[r] = in && !(rr[r] < T(0));
     }
     const unsigned long long m0 = __ballot(keep[0]);
-    const unsigned long long m1 = __ballot(keep[1]);
+    const unsigned long long m1 = (kRPT > 1) ? __ballot(keep[kRPT - 1]) : 0ull;
     const unsigned long long lt = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
     const int rank0 = __popcll(m0 & lt) + __popcll(m1 & lt);
     const int wtot = __popcll(m0) + __popcll(m1);

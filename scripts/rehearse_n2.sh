@@ -1,0 +1,7 @@
+#!/bin/bash
+# GPU box (1 GPU): rehearsal of the N = 2 launch path with the gloo backend (both ranks on cuda:0).
+cd /root/repo
+export ORT_BENCH_BACKEND=gloo
+timeout -k 10 300 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29533 bench.py --gpus 2 --steps 5 --warmup 2 --pupil 512 > gpurun_out/rehearse_n2.log 2>&1
+echo "rc=$?" >> gpurun_out/rehearse_n2.log
+tail -5 gpurun_out/rehearse_n2.log
