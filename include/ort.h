@@ -164,6 +164,34 @@ int ort_trace_meridional_f64(ort_ctx *ctx, const ort_system *sys, int isys, int6
                              double *y_out, double *U_out, double *ts_out, int64_t ld,
                              unsigned flags);
 
+/* ---- batched real-ray aiming: trace_chief_ray / trace_marginal_ray / trace_edge_rays -----
+ * One (system, field) pair per entry: the FD-Newton drivers of src/RayTracing.jl:223-240 (real
+ * marginal) and :265-296 (real chief, traced through the REVERSED prescription, which the
+ * caller uploads as `rev`, built as :267-277 incl. quirk Q17) and the edge-ray search of
+ * src/PupilSampling.jl:67-83 (Optim.BFGS in the reference; restated as the same FD-Newton),
+ * giving the aiming scalars of src/PupilSampling.jl:94-103 that ort_full_trace_f64 consumes.
+ * `in`, `out`: host arrays [n] (device arrays with ORT_DEVICE_PTRS).                        */
+typedef struct ort_aim_in {
+    int32_t system;        /* index into fwd and rev */
+    int32_t stop;          /* system.stop */
+    int32_t layout_fwd;    /* 1 = the prescription is a Layout{Aspheric} (Q16) */
+    int32_t layout_rev;    /* 1 = the reversed prescription was built from a Layout (:272-274) */
+    double H;              /* normalised field, |H| <= 1 (checked: ORT_EDOMAIN) */
+    double y_marg;         /* system.marginal.y[1] */
+    double a_stop;         /* system.a[stop] */
+    double chief_y_end;    /* system.chief.y[end] */
+    double chief_u_end;    /* system.chief.u[end] */
+    double f;              /* system.f */
+    double atol;           /* sqrt(eps()) by default in the reference */
+} ort_aim_in;
+typedef struct ort_aim_out {
+    double U, y1, y2, y_EP, hprime, EP_t, Ubar;
+    int32_t iters;
+    int32_t ok;            /* 0 = a Newton loop hit its iteration cap */
+} ort_aim_out;
+int ort_aim_f64(ort_ctx *ctx, const ort_system *fwd, const ort_system *rev, int n,
+                const ort_aim_in *in, ort_aim_out *out, unsigned flags);
+
 /* ---- paraxial y-nu trace: raytrace(lens, y, ω, a; clip) --------------------------------
  * src/RayTracing.jl:127-143 (+ transfer/refract :55-69).  nlens lenses of k rows each
  * (Lens.M columns τ, ϕ: [nlens][k]); a: [nlens][k] or NULL (fill(Inf)); rays_per_lens rays

@@ -48,6 +48,22 @@ class ort_bundle(C.Structure):
     ]
 
 
+class ort_aim_in(C.Structure):
+    _fields_ = [
+        ("system", C.c_int32), ("stop", C.c_int32), ("layout_fwd", C.c_int32), ("layout_rev", C.c_int32),
+        ("H", C.c_double), ("y_marg", C.c_double), ("a_stop", C.c_double),
+        ("chief_y_end", C.c_double), ("chief_u_end", C.c_double), ("f", C.c_double), ("atol", C.c_double),
+    ]
+
+
+class ort_aim_out(C.Structure):
+    _fields_ = [
+        ("U", C.c_double), ("y1", C.c_double), ("y2", C.c_double), ("y_EP", C.c_double),
+        ("hprime", C.c_double), ("EP_t", C.c_double), ("Ubar", C.c_double),
+        ("iters", C.c_int32), ("ok", C.c_int32),
+    ]
+
+
 class ort_grid_out_f64(C.Structure):
     _fields_ = [
         ("xv", C.c_void_p), ("yv", C.c_void_p), ("ld", C.c_int64),
@@ -85,6 +101,7 @@ SIGNATURES = {
     "ort_trace_grid_f64": (_i, [_p, _p, _i, C.POINTER(ort_bundle), _p, _l, _i, _i, C.POINTER(ort_grid_out_f64), _u]),
     "ort_trace_grid_f32": (_i, [_p, _p, _i, C.POINTER(ort_bundle), _p, _l, _i, _i, C.POINTER(ort_grid_out_f32), _u]),
     "ort_full_trace_f64": (_i, [_p, _p, _i, C.POINTER(ort_bundle), _p, _l, _i, _i, _p, _p, _p, _p, _p, _p, _u]),
+    "ort_aim_f64": (_i, [_p, _p, _p, _i, C.POINTER(ort_aim_in), C.POINTER(ort_aim_out), _u]),
     "ort_trace_meridional_f64": (_i, [_p, _p, _i, _l, _p, _p, _p, _p, _p, _l, _u]),
     "ort_trace_paraxial_f64": (_i, [_p, _i, _i, _p, _p, _p, _l, _p, _p, _p, _p, _l, _u]),
     "ort_abcd_f64": (_i, [_p, _i, _i, _p, _p, _p, _u]),

@@ -525,6 +525,20 @@ def trace_marginal_ray(*args, atol: float = EPS, engine=None):
     return RealRayT(Marginal, yv, uv, yu, ray.n, z)
 
 
+def reversed_layout(surfaces, system) -> "Layout":
+    """The reversed prescription the real chief ray is aimed through (RayTracing.jl:267-277)."""
+    marginal = system.marginal
+    M = np.asarray(surfaces.M if isinstance(surfaces, Layout) else surfaces, dtype=np.float64)
+    rev_R = -np.concatenate([[math.inf], M[:0:-1, 0]])                 # :267
+    rev_t = M[::-1, 1].copy()                                          # :268
+    rev_n = M[::-1, 2].copy()                                          # :269
+    BFD = marginal.z[-1] - marginal.z[-2]                              # :270
+    rev_t[0] = BFD                                                     # :271
+    if isinstance(surfaces, Layout):                                   # :272-274 (Q17: plain reverse of K, p)
+        return Layout(rev_R, rev_t, rev_n, surfaces.K[::-1].copy(), list(surfaces.p[::-1]))
+    return Layout(np.column_stack([rev_R, rev_t, rev_n]))              # :276
+
+
 def trace_chief_ray(*args, atol: float = EPS, engine=None):
     if isinstance(args[0], Lens):                                      # paraxial method :246
         return _trace_chief_paraxial(*args, engine=engine)
@@ -533,15 +547,8 @@ def trace_chief_ray(*args, atol: float = EPS, engine=None):
     surfaces, system = args[0], args[1]                                # :265-296
     chief, marginal = system.chief, system.marginal
     M = np.asarray(surfaces.M if isinstance(surfaces, Layout) else surfaces, dtype=np.float64)
-    rev_R = -np.concatenate([[math.inf], M[:0:-1, 0]])                 # :267
-    rev_t = M[::-1, 1].copy()                                          # :268
-    rev_n = M[::-1, 2].copy()                                          # :269
-    BFD = marginal.z[-1] - marginal.z[-2]                              # :270
-    rev_t[0] = BFD                                                     # :271
-    if isinstance(surfaces, Layout):                                   # :272-274 (Q17: plain reverse of K, p)
-        rev = Layout(rev_R, rev_t, rev_n, surfaces.K[::-1].copy(), list(surfaces.p[::-1]))
-    else:                                                              # :276
-        rev = Layout(np.column_stack([rev_R, rev_t, rev_n]))
+    rev = reversed_layout(surfaces, system)
+    rev_R = rev.R
     pres, layout_mode, ncol = _as_layout(rev)
     stop = len(rev_R) - system.stop                                    # :278
     ybp = chief.y[-1]                                                  # :279
@@ -697,6 +704,82 @@ def full_trace(*args, engine=None) -> RealRayError:
         focus = rest[1] if len(rest) > 1 else None
     aim = full_trace_aim(surfaces, system, H, focus, engine=engine)
     return full_trace_grid(surfaces, aim, int(k_rays), engine=engine)
+
+
+def _stack_prescriptions(press: Sequence[Prescription]) -> Prescription:
+    nc = max((p.coef.shape[2] for p in press if p.coef is not None), default=0)
+    coef = None
+    if nc:
+        coef = np.zeros((len(press), press[0].rows, nc))
+        for i, p in enumerate(press):
+            if p.coef is not None:
+                coef[i, :, :p.coef.shape[2]] = p.coef[0]
+    K = np.array([p.K[0] if p.K is not None else np.zeros(p.rows) for p in press])
+    return Prescription(np.array([p.R[0] for p in press]), np.array([p.t[0] for p in press]),
+                        np.array([p.n[0] for p in press]), K, coef)
+
+
+def full_trace_aim_batch(systems: Sequence[System], fields: Sequence[float], focus=None, engine=None) -> List[List[Aiming]]:
+    """Aiming for every (system, field) pair in ONE device launch (ort_aim_f64): the Newton loops of
+    RayTracing.jl:223-296 and the edge-ray search run one thread per pair.  Returns
+    aims[system][field].  All systems must have the same number of rows."""
+    eng = _eng(engine)
+    fields = [abs(float(H)) for H in fields]
+    for H in fields:
+        if not H <= 1.0:
+            raise DomainError(f"DomainError with {H}: Domain: |H| ≤ 1.0")
+    if not hasattr(eng, "aim"):        # an engine without the batched kernel: drive the loops from the host
+        return [[full_trace_aim(s.layout, s, H, focus, engine=eng) for H in fields] for s in systems]
+    fwd, rev, specs = [], [], []
+    for si, s in enumerate(systems):
+        pf, lf, _ = _as_layout(s.layout)
+        pr, lr, _ = _as_layout(reversed_layout(s.layout, s))
+        fwd.append(pf); rev.append(pr)
+        for H in fields:
+            specs.append(dict(system=si, stop=s.stop, layout_fwd=lf, layout_rev=lr, H=H, y_marg=s.marginal.y[0],
+                              a_stop=s.a[s.stop - 1], chief_y_end=s.chief.y[-1], chief_u_end=s.chief.u[-1],
+                              f=s.f, atol=EPS))
+    outs = eng.aim(_stack_prescriptions(fwd), _stack_prescriptions(rev), specs)
+    aims, i = [], 0
+    for s in systems:
+        row = []
+        foc = (s.marginal.z[-1] - s.marginal.z[-2]) if focus is None else focus
+        for H in fields:
+            o = outs[i]; i += 1
+            if not o["ok"]:
+                raise RuntimeError("ray aiming did not converge")
+            row.append(Aiming(H=H, U=o["U"], V=0.0, y1=o["y1"], y2=o["y2"], y_EP=o["y_EP"], hprime=o["hprime"],
+                              stop=s.stop, a_stop=abs(s.a[s.stop - 1]), focus=float(foc), nu=float(s.marginal.nu[-1])))
+        aims.append(row)
+    return aims
+
+
+def full_trace_batch(systems: Sequence[System], fields: Sequence[float], k_rays: int = SPOT_RAYS, focus=None,
+                     engine=None) -> List[List[RealRayError]]:
+    """`full_trace(system, H, k_rays)` for every (system, field) pair: one aiming launch, one
+    full_trace launch sequence (BASELINE configs 4-5).  Returns errs[system][field]."""
+    eng = _eng(engine)
+    aims = full_trace_aim_batch(systems, fields, focus, engine=eng)
+    k2 = k_rays // 2
+    press, bundles, axes, off = [], [], [], 0
+    for si, s in enumerate(systems):
+        press.append(extended_prescription(s.layout, aims[si][0].focus))
+        for a in aims[si]:
+            axes += [linrange(a.y1, a.y2, k_rays), linrange(0.0, a.y_EP, k2)]
+            bundles.append(dict(system=si, stop=a.stop, U=a.U, V=0.0, a_stop=a.a_stop, hprime=a.hprime,
+                                yaxis_off=off, xaxis_off=off + k_rays))
+            off += k_rays + k2
+    res = eng.full_trace_grid(_stack_prescriptions(press), bundles, np.concatenate(axes), k_rays, k2)
+    out, i = [], 0
+    for si, s in enumerate(systems):
+        row = []
+        for a in aims[si]:
+            r = res[i]; i += 1
+            if r["count"] == 0:
+                raise ValueError("reducing over an empty collection is not allowed")
+            row.append(RealRayError(r["ex"], r["ey"], a.nu, r["rho"], r["theta"], a.H, r["rms"]))
+        out.append(row)
+    return out
 
 
 def wavegrad(err: RealRayError, lam: float = LAMBDA):                 # PupilSampling.jl:165-167

@@ -86,6 +86,7 @@ struct ort_system {
     float* coef32 = nullptr;
     MerSurf* mer = nullptr;        // [nsys][S]
     std::vector<double> t_last;    // t[rows-1] per system (meridional ts tail)
+    double* d_tlast = nullptr;     // the same on the device (aiming kernel)
 };
 
 namespace {
@@ -519,6 +520,7 @@ int ort_system_create(ort_ctx* ctx, int nsys, int rows, const double* R, const d
     rc = up((void**)&sys->rec64, r64.data(), r64.size() * sizeof(SurfRec<double>));
     if (!rc) rc = up((void**)&sys->rec32, r32.data(), r32.size() * sizeof(SurfRec<float>));
     if (!rc) rc = up((void**)&sys->mer, mer.data(), mer.size() * sizeof(MerSurf));
+    if (!rc) rc = up((void**)&sys->d_tlast, sys->t_last.data(), sys->t_last.size() * sizeof(double));
     if (!rc && ncoef > 0) rc = up((void**)&sys->coef64, c64.data(), c64.size() * sizeof(double));
     if (!rc && ncoef > 0) rc = up((void**)&sys->coef32, c32.data(), c32.size() * sizeof(float));
     if (rc) { ort_system_destroy(sys); return rc; }
@@ -534,6 +536,7 @@ int ort_system_destroy(ort_system* sys)
     if (sys->rec64) { e = hipFree(sys->rec64); (void)e; }
     if (sys->rec32) { e = hipFree(sys->rec32); (void)e; }
     if (sys->mer) { e = hipFree(sys->mer); (void)e; }
+    if (sys->d_tlast) { e = hipFree(sys->d_tlast); (void)e; }
     if (sys->coef64) { e = hipFree(sys->coef64); (void)e; }
     if (sys->coef32) { e = hipFree(sys->coef32); (void)e; }
     delete sys;
@@ -687,6 +690,43 @@ int ort_trace_meridional_f64(ort_ctx* ctx, const ort_system* sys, int isys, int6
     HIP_TRY(hipMemcpy2DAsync(U_out, ld * sizeof(double), oU, w, w, rows, hipMemcpyDeviceToHost, ctx->stream));
     if (ts_out) HIP_TRY(hipMemcpy2DAsync(ts_out, ld * sizeof(double), ots, w, w, rows, hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(hipStreamSynchronize(ctx->stream));
+    return ORT_OK;
+}
+
+// --------------------------------------------------------------------------------------
+int ort_aim_f64(ort_ctx* ctx, const ort_system* fwd, const ort_system* rev, int n,
+                const ort_aim_in* in, ort_aim_out* out, unsigned flags)
+{
+    static_assert(sizeof(ort_aim_in) == sizeof(AimIn) && sizeof(ort_aim_out) == sizeof(AimOut), "ABI struct mismatch");
+    int rc = check_ctx(ctx); if (rc) return rc;
+    rc = check_sys(ctx, fwd); if (rc) return rc;
+    rc = check_sys(ctx, rev); if (rc) return rc;
+    if (n < 0 || !in || !out) return fail(ORT_EINVAL, "bad aim arguments");
+    if (n == 0) return ORT_OK;
+    if (fwd->rows != rev->rows || fwd->nsys != rev->nsys || fwd->ncoef != rev->ncoef)
+        return fail(ORT_EINVAL, "forward and reversed system batches differ in shape");
+    const bool devp = flags & ORT_DEVICE_PTRS;
+    const int S = fwd->rows - 1;
+    if (!devp) {
+        for (int i = 0; i < n; ++i) {
+            if (in[i].system < 0 || in[i].system >= fwd->nsys) return fail(ORT_EINVAL, "aim %d: system %d out of range", i, in[i].system);
+            if (in[i].stop < 1 || in[i].stop > S) return fail(ORT_EINVAL, "aim %d: stop %d out of range 1..%d", i, in[i].stop, S);
+            if (!(std::fabs(in[i].H) <= 1.0)) return fail(ORT_EDOMAIN, "DomainError with %g: Domain: |H| <= 1.0", in[i].H);
+        }
+    }
+    const AimIn* din = reinterpret_cast<const AimIn*>(in);
+    AimOut* dout = reinterpret_cast<AimOut*>(out);
+    if (!devp) {
+        rc = to_device<AimIn>(ctx, SL_IN0, reinterpret_cast<const AimIn*>(in), (size_t)n, &din); if (rc) return rc;
+        rc = dev_out<AimOut>(ctx, SL_OUT0, (size_t)n, &dout); if (rc) return rc;
+    }
+    hipLaunchKernelGGL(k_aim, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, ctx->stream, n, din,
+                       fwd->mer, fwd->coef64, fwd->d_tlast, rev->mer, rev->coef64, rev->d_tlast, S, fwd->ncoef, dout);
+    HIP_TRY(hipGetLastError());
+    if (!devp) {
+        rc = from_device<AimOut>(ctx, reinterpret_cast<AimOut*>(out), dout, (size_t)n); if (rc) return rc;
+        HIP_TRY(hipStreamSynchronize(ctx->stream));
+    }
     return ORT_OK;
 }
 

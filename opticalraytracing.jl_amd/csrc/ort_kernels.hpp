@@ -471,6 +471,38 @@ struct MerSurf {   // row i+1 of the prescription as seen by loop iteration i
     int32_t finite, ncoef;
 };
 
+// One loop iteration of src/RayTracing.jl:151-167.  Returns ts[i] (after :160).
+__device__ __forceinline__ double mer_step(const MerSurf& s, const double* __restrict__ c, int layout_mode,
+                                           double& y, double& U, double& sprev)
+{
+    const double tcur = s.t - sprev;                              // ts[i] after :161
+    const double tU = ::tan(U);
+    y = y + tU * tcur;                                            // :152
+    double sg;
+    if (s.finite) {                                               // :76
+        const double beta = s.R - y * tU;                         // :77
+        const double y2 = y * y;                                  // :78
+        const double sec = 1.0 / ::cos(U);
+        const double D = beta * beta - y2 * (sec * sec + s.K);    // :79
+        sg = y2 / (beta + s.sgn * __builtin_sqrt(D));             // :81
+        sg = sg + (s.ncoef > 0 ? poly_eval<double>(c, s.ncoef, y) : 0.0);
+        sg = (D >= 0.0) ? sg : __builtin_nan("");                 // :80,83
+    } else sg = 0.0;                                              // :86
+    y = y + sg * tU;                                              // :158
+    sprev = sg;
+    double theta;
+    if (s.K == 0.0 && !layout_mode && s.ncoef == 0) {
+        theta = ::asin(y / s.R);                                  // :162, tilt(y, R) = y / R (:101)
+    } else {
+        double tl = s.sgn * y / __builtin_sqrt(s.R * s.R - y * y * (1.0 + s.K));   // :98
+        tl = tl + (s.ncoef > 0 ? poly_deriv<double>(c, s.ncoef, y) : 0.0);
+        theta = ::atan(tl);
+    }
+    const double sin_ip = s.n1 * ::sin(U + theta) / s.n2;         // :163
+    U = (fabs(sin_ip) <= 1.0) ? ::asin(sin_ip) - theta : __builtin_nan("");   // :164
+    return tcur + sg;                                             // ts[i] += s (:160)
+}
+
 __global__ __launch_bounds__(kBlock) void k_trace_meridional(const MerSurf* __restrict__ surf, const double* __restrict__ coefs,
                                                              int S, int ncoef, int layout_mode, double t_last,
                                                              int64_t nrays, const double* __restrict__ y_in,
@@ -489,38 +521,126 @@ __global__ __launch_bounds__(kBlock) void k_trace_meridional(const MerSurf* __re
     y_out[g] = y; U_out[g] = U;                                   // :150
     double sprev = 0.0;
     for (int i = 0; i < S; ++i) {
-        const MerSurf s = s_s[i];
-        const double* c = s_c + i * ncoef;
-        const double tcur = s.t - sprev;                          // ts[i] after :161
-        const double tU = ::tan(U);
-        y = y + tU * tcur;                                        // :152
-        double sg;
-        if (s.finite) {                                           // :76
-            const double beta = s.R - y * tU;                     // :77
-            const double y2 = y * y;                              // :78
-            const double sec = 1.0 / ::cos(U);
-            const double D = beta * beta - y2 * (sec * sec + s.K);    // :79
-            sg = y2 / (beta + s.sgn * __builtin_sqrt(D));         // :81
-            sg = sg + (s.ncoef > 0 ? poly_eval<double>(c, s.ncoef, y) : 0.0);
-            sg = (D >= 0.0) ? sg : __builtin_nan("");             // :80,83
-        } else sg = 0.0;                                          // :86
-        y = y + sg * tU;                                          // :158
-        if (ts_out) ts_out[(int64_t)i * ld + g] = tcur + sg;      // ts[i] += s (:160)
-        sprev = sg;
-        double theta;
-        if (s.K == 0.0 && !layout_mode && s.ncoef == 0) {
-            theta = ::asin(y / s.R);                              // :162, tilt(y, R) = y / R (:101)
-        } else {
-            double tl = s.sgn * y / __builtin_sqrt(s.R * s.R - y * y * (1.0 + s.K));   // :98
-            tl = tl + (s.ncoef > 0 ? poly_deriv<double>(c, s.ncoef, y) : 0.0);
-            theta = ::atan(tl);
-        }
-        const double sin_ip = s.n1 * ::sin(U + theta) / s.n2;     // :163
-        U = (fabs(sin_ip) <= 1.0) ? ::asin(sin_ip) - theta : __builtin_nan("");   // :164
+        const double tsi = mer_step(s_s[i], s_c + i * ncoef, layout_mode, y, U, sprev);
+        if (ts_out) ts_out[(int64_t)i * ld + g] = tsi;
         y_out[(int64_t)(i + 1) * ld + g] = y;                     // :165
         U_out[(int64_t)(i + 1) * ld + g] = U;                     // :166
     }
     if (ts_out) ts_out[(int64_t)S * ld + g] = t_last - sprev;     // ts[end] -= s (:161)
+}
+
+// ------------------------------------------------------------------------------------
+// Batched ray aiming (SURVEY §8f "next #1"): one thread per (system, field) runs the Newton
+// drivers of src/RayTracing.jl:223-240 (real marginal), :265-296 (real chief, on the reversed
+// system) and the edge-ray search of src/PupilSampling.jl:67-83 (restated as the same
+// FD-Newton, see api._trace_edge_rays), and emits the aiming scalars of
+// src/PupilSampling.jl:94-103.  Each trace is mer_step over the system's table.
+// ------------------------------------------------------------------------------------
+struct AimIn {
+    int32_t system;        // index into the forward and the reversed table batch
+    int32_t stop;          // system.stop
+    int32_t layout_fwd;    // Q16 flags of the forward / reversed prescriptions
+    int32_t layout_rev;
+    double H;              // |H| <= 1
+    double y_marg;         // system.marginal.y[1]          :225
+    double a_stop;         // system.a[stop]                :227
+    double chief_y_end;    // system.chief.y[end]           :279
+    double chief_u_end;    // system.chief.u[end]           :280
+    double f;              // system.f  (h' = u f, PupilSampling.jl:103)
+    double atol;           // sqrt(eps())
+};
+struct AimOut {
+    double U, y1, y2, y_EP, hprime, EP_t, Ubar;
+    int32_t iters;         // Newton iterations spent (all loops)
+    int32_t ok;            // 1 = every loop converged
+};
+
+struct MerEnd { double y_stop, y_last, U_last, z_last, z_prev; };
+
+__device__ inline MerEnd mer_trace_to(const MerSurf* __restrict__ surf, const double* __restrict__ coefs, int S, int ncoef,
+                                      int layout_mode, double t_last, double y, double U, int stop_idx)
+{
+    MerEnd e;
+    e.y_stop = __builtin_nan("");
+    double sprev = 0.0, z = 0.0, zp = 0.0;
+    for (int i = 0; i < S; ++i) {
+        const double tsi = mer_step(surf[i], coefs ? coefs + (int64_t)(i + 1) * ncoef : nullptr, layout_mode, y, U, sprev);
+        zp = z; z = (i == 0) ? tsi : z + tsi;                    // cumsum(ts)  (Types.jl:61-63)
+        if (i + 1 == stop_idx) e.y_stop = y;                     // ray.y[begin+stop]
+    }
+    zp = z; z = z + (t_last - sprev);                            // last ts entry
+    e.y_last = y; e.U_last = U; e.z_last = z; e.z_prev = zp;
+    return e;
+}
+
+__global__ __launch_bounds__(64) void k_aim(int n, const AimIn* __restrict__ in,
+                                            const MerSurf* __restrict__ fwd, const double* __restrict__ cfwd, const double* __restrict__ tl_fwd,
+                                            const MerSurf* __restrict__ rev, const double* __restrict__ crev, const double* __restrict__ tl_rev,
+                                            int S, int ncoef, AimOut* __restrict__ out)
+{
+    const int g = blockIdx.x * 64 + threadIdx.x;
+    if (g >= n) return;
+    const AimIn a = in[g];
+    const double eps = 1.4901161193847656e-08;                   // const ϵ = sqrt(eps()), RayTracing.jl:1
+    const int rows = S + 1;
+    const MerSurf* F = fwd + (int64_t)a.system * S;
+    const MerSurf* Rv = rev + (int64_t)a.system * S;
+    const double* cF = cfwd ? cfwd + (int64_t)a.system * rows * ncoef : nullptr;
+    const double* cR = crev ? crev + (int64_t)a.system * rows * ncoef : nullptr;
+    const double tlF = tl_fwd[a.system], tlR = tl_rev[a.system];
+    int iters = 0, ok = 1;
+    // ---- real chief ray on the reversed system (RayTracing.jl:278-286)
+    const int stop_rev = rows - a.stop;                          // :278
+    const double ybp = a.chief_y_end;                            // :279
+    double ubp = -a.chief_u_end;                                 // :280
+    MerEnd ray = mer_trace_to(Rv, cR, S, ncoef, a.layout_rev, tlR, ybp, ubp, stop_rev);
+    for (int it = 0; fabs(ray.y_stop) > a.atol; ++it) {          // :282 (NaN ends the loop like the reference)
+        if (it >= 200) { ok = 0; break; }
+        const double dy = mer_trace_to(Rv, cR, S, ncoef, a.layout_rev, tlR, ybp, ubp + eps, stop_rev).y_stop;   // :283
+        ubp -= ray.y_stop * eps / (dy - ray.y_stop);             // :284
+        ray = mer_trace_to(Rv, cR, S, ncoef, a.layout_rev, tlR, ybp, ubp, stop_rev);                            // :285
+        ++iters;
+    }
+    const double yb2 = ray.y_last;                               // ȳ[2] = reverse(ray.y)[1]           :287
+    const double ub1 = -ray.U_last;                              // ū[1] = -reverse(ray.u)[1]          :289
+    const double z2 = ray.z_last - ray.z_prev;                   // z[2] = ray.z[end] - ray.z[end-1]   :292
+    const double EP_t = -yb2 / ::tan(ub1) + z2;                  // :293
+    // ---- real marginal ray (RayTracing.jl:225-233)
+    double y = a.y_marg;
+    MerEnd mr = mer_trace_to(F, cF, S, ncoef, a.layout_fwd, tlF, y, 0.0, a.stop);
+    double dstop = mr.y_stop - a.a_stop;                         // stop_loss :117-120
+    for (int it = 0; fabs(dstop) > a.atol; ++it) {               // :229
+        if (it >= 200) { ok = 0; break; }
+        const double d2 = mer_trace_to(F, cF, S, ncoef, a.layout_fwd, tlF, y + eps, 0.0, a.stop).y_stop - a.a_stop;   // :230
+        y -= dstop * eps / (d2 - dstop);                         // :231
+        mr = mer_trace_to(F, cF, S, ncoef, a.layout_fwd, tlF, y, 0.0, a.stop);
+        dstop = mr.y_stop - a.a_stop;                            // :232
+        ++iters;
+    }
+    const double y_EP = fabs(y);                                 // PupilSampling.jl:98 (real_marginal.y[1])
+    // ---- field, edge rays (PupilSampling.jl:94-100)
+    const double U = a.H * ub1;                                  // :96
+    const double u = ::tan(U);                                   // :97
+    const double astop = fabs(a.a_stop);                         // :91
+    double ye[2] = { y_EP - u * EP_t, -y_EP - u * EP_t };        // :99
+    for (int e = 0; e < 2; ++e) {
+        const double target = e == 0 ? astop : -astop;
+        const double y0 = ye[e];
+        double yy = y0;
+        double d = mer_trace_to(F, cF, S, ncoef, a.layout_fwd, tlF, yy, U, a.stop).y_stop - target;
+        for (int it = 0; fabs(d) > a.atol && it < 100; ++it) {
+            const double dd = mer_trace_to(F, cF, S, ncoef, a.layout_fwd, tlF, yy + eps, U, a.stop).y_stop - target;
+            yy -= d * eps / (dd - d);
+            d = mer_trace_to(F, cF, S, ncoef, a.layout_fwd, tlF, yy, U, a.stop).y_stop - target;
+            ++iters;
+        }
+        if (!(fabs(d) <= 1e300)) yy = y0;                        // isnan(Δ) ? Inf : Δ keeps the start point (:72,78)
+        ye[e] = yy;
+    }
+    AimOut o;
+    o.U = U; o.y1 = ye[0]; o.y2 = ye[1]; o.y_EP = y_EP; o.hprime = u * a.f; o.EP_t = EP_t; o.Ubar = ub1;
+    o.iters = iters; o.ok = ok;
+    out[g] = o;
 }
 
 // ------------------------------------------------------------------------------------

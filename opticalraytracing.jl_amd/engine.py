@@ -158,6 +158,22 @@ class HipEngine:
                                                     ptr(yo), ptr(Uo), ptr(ts), N, flags))
         return yo, Uo, ts
 
+    # ---- batched aiming: RayTracing.jl:223-296 + PupilSampling.jl:67-83,94-103 ------------
+    def aim(self, fwd: Prescription, rev: Prescription, specs: Sequence[dict]) -> List[dict]:
+        n = len(specs)
+        ain = (_capi.ort_aim_in * n)()
+        for i, sp in enumerate(specs):
+            a = ain[i]
+            a.system, a.stop = int(sp["system"]), int(sp["stop"])
+            a.layout_fwd, a.layout_rev = int(bool(sp.get("layout_fwd", 0))), int(bool(sp.get("layout_rev", 0)))
+            a.H, a.y_marg, a.a_stop = float(sp["H"]), float(sp["y_marg"]), float(sp["a_stop"])
+            a.chief_y_end, a.chief_u_end = float(sp["chief_y_end"]), float(sp["chief_u_end"])
+            a.f, a.atol = float(sp["f"]), float(sp.get("atol", 1.4901161193847656e-08))
+        aout = (_capi.ort_aim_out * n)()
+        check(self.ctx.lib.ort_aim_f64(self.ctx.h, self.system(fwd).h, self.system(rev).h, n, ain, aout, self.base_flags))
+        return [dict(U=o.U, y1=o.y1, y2=o.y2, y_EP=o.y_EP, hprime=o.hprime, EP_t=o.EP_t, Ubar=o.Ubar,
+                     iters=o.iters, ok=bool(o.ok)) for o in aout]
+
     # ---- paraxial: raytrace(lens, y, ω, a; clip)  RayTracing.jl:127-143 ------------------
     def paraxial(self, tau, phi, y, w, a=None, clip: bool = False):
         tau = np.atleast_2d(f64(tau)); phi = np.atleast_2d(f64(phi))

@@ -119,3 +119,33 @@ def config3(api, k: int = 2048, engine=None):
         lay = api.Layout(M4[:, 0], M4[:, 1], M4[:, 2], M4[:, 3], [c for c in coef])
         systems.append(api.solve(lay, DG_A, DG_H, engine=engine))
     return square_pupil_bundles(api, systems, k)
+
+
+def config4(api, k: int = 512, nzoom: int = 32, engine=None, fields=(0.0, 0.5, 0.7, 0.85, 1.0),
+            lines=(0, 1, 2, 1, 2)):
+    """Zoom-lens sweep (BASELINE config 4): nzoom positions of the two air gaps around the stop
+    x 5 fields x 5 index columns (d, F, C and two repeats standing in for further lines),
+    k x k pupil.  One system per (zoom, line); bundles ordered (zoom, line, field)."""
+    systems = []
+    for z in range(nzoom):
+        gap = -1.5 + 3.0 * z / max(1, nzoom - 1)
+        for line in lines:
+            systems.append(api.solve(double_gauss(line, gap), DG_A, DG_H, engine=engine))
+    return square_pupil_bundles(api, systems, k, fields=fields)
+
+
+def config5(api, k: int = 256, ninst: int = 10 ** 4, engine=None, seed: int = 12345):
+    """Monte-Carlo tolerance run (BASELINE config 5): ninst perturbed Double-Gauss instances
+    (sigma_R/R = 1e-3, sigma_t = 10 um, sigma_n = 1e-4), one on-axis + one full-field
+    bundle each is left to the caller; returns the perturbed surface matrices [ninst][rows][3]."""
+    rng = np.random.default_rng(seed)
+    base = double_gauss(0)
+    rows = base.shape[0]
+    out = np.repeat(base[None], ninst, axis=0)
+    finite = np.isfinite(base[:, 0])
+    out[:, finite, 0] *= 1.0 + 1e-3 * rng.standard_normal((ninst, int(finite.sum())))
+    thick = base[:, 1] != 0.0
+    out[:, thick, 1] += 0.010 * rng.standard_normal((ninst, int(thick.sum())))
+    glass = base[:, 2] != 1.0
+    out[:, glass, 2] += 1e-4 * rng.standard_normal((ninst, int(glass.sum())))
+    return out

@@ -341,3 +341,164 @@ def test_device_pointer_path_full_size_properties(oracle_engine):
     assert np.all((s & 0xffff) == S + 1)
     kept = 1.0 - np.count_nonzero(s >> 16) / N
     assert abs(kept - math.pi / 4) < 0.05
+
+
+def test_config4_zoom_sweep_many_systems(hip_engine, oracle_engine):
+    """BASELINE config 4 shape at oracle size: 8 zoom positions x 5 index columns = 40 systems,
+    5 fields each = 200 bundles of 24 x 24 rays; every bundle reads ITS system's table."""
+    from opticalraytracing_jl_amd import api, workloads
+    pres, bundles, axes = workloads.config4(api, 24, nzoom=8, engine=oracle_engine)
+    assert pres.nsys == 40 and len(bundles) == 200
+    g = hip_engine.grid(pres, bundles, axes, 24, 24)
+    o = oracle_engine.grid(pres, bundles, axes, 24, 24)
+    for key in ("xv", "yv", "xs", "ys"):
+        assert np.array_equal(g[key], o[key], equal_nan=True), key
+    assert np.array_equal(g["status"], o["status"])
+    gf = hip_engine.full_trace_grid(pres, bundles[::17], axes, 24, 24)
+    of = oracle_engine.full_trace_grid(pres, bundles[::17], axes, 24, 24)
+    for a, b in zip(gf, of):
+        assert a["count"] == b["count"] and np.array_equal(a["ex"], b["ex"])
+        assert abs(a["rms"] - b["rms"]) <= TOL * b["rms"]
+
+
+def test_config5_monte_carlo_instances(oracle_engine):
+    """BASELINE config 5 shape: 500 perturbed instances (seed 12345) x 16 x 16 pupil on axis, one
+    launch; Float64 bit-exact against the oracle and the Float32 build within 1e-4."""
+    import ctypes as C
+    from opticalraytracing_jl_amd import _capi, workloads
+    eng = ort.default_engine()
+    mats = workloads.config5(None, ninst=500)
+    ninst, k = mats.shape[0], 16
+    R = np.concatenate([mats[:, :, 0], np.full((ninst, 1), math.inf)], axis=1)
+    t = np.concatenate([mats[:, :, 1], np.zeros((ninst, 1))], axis=1); t[:, -2] = 57.8
+    n = np.concatenate([mats[:, :, 2], np.ones((ninst, 1))], axis=1)
+    pres = Prescription(R, t, n)
+    ax = ort.linrange(-12.0, 12.0, k)
+    axes = np.concatenate([ax, ax])
+    bundles = [dict(system=i, stop=6, U=0.0, V=0.0, a_stop=10.229, yaxis_off=0, xaxis_off=k) for i in range(ninst)]
+    g = eng.grid(pres, bundles, axes, k, k)
+    o = oracle_engine.grid(pres, bundles, axes, k, k)
+    assert np.array_equal(g["xv"], o["xv"], equal_nan=True) and np.array_equal(g["yv"], o["yv"], equal_nan=True)
+    assert np.array_equal(g["status"], o["status"])
+    # Float32 build of the same launch
+    N, S = ninst * k * k, pres.rows - 1
+    xv = np.empty((S, N), dtype=np.float32); yv = np.empty((S, N), dtype=np.float32)
+    out = _capi.ort_grid_out_f32()
+    out.xv, out.yv, out.ld = xv.ctypes.data, yv.ctypes.data, N
+    a32 = axes.astype(np.float32)
+    sysd = eng.system(pres)
+    _capi.check(eng.ctx.lib.ort_trace_grid_f32(eng.ctx.h, sysd.h, ninst, _capi.make_bundles(bundles), a32.ctypes.data,
+                                               a32.size, k, k, C.byref(out), _capi.ORT_FAST_MATH))
+    assert cm.rel_err(xv, o["xv"], 1.0).max() <= 1e-4 and cm.rel_err(yv, o["yv"], 1.0).max() <= 1e-4
+
+
+def test_config3_full_size_aspheric_properties(oracle_engine):
+    """BASELINE config 3 at FULL size: 3 x 3 bundles x 2048 x 2048 pupil (37.7 M rays, S = 12),
+    4 aspheric surfaces, full_trace pipeline with stop-filter compaction, device pointers.
+    Properties: survivors ~ pi/4 of the pupil square; compacted first half equals the filtered
+    summary trace in ray order (checked on one bundle against a second, independent launch);
+    mirror halves exact; a strided sample of rays equals the oracle to 1e-12."""
+    import ctypes as C
+    import torch
+    from opticalraytracing_jl_amd import _capi, api, workloads
+    eng = ort.default_engine()
+    k = 2048
+    pres, bundles, axes = workloads.config3(api, k, engine=oracle_engine)
+    nb, rpb = len(bundles), k * k
+    dev = torch.device("cuda:0")
+    d_axes = torch.from_numpy(axes).to(dev)
+    cap = 2 * rpb
+    ex = torch.empty((nb, cap), dtype=torch.float64, device=dev); ey = torch.empty_like(ex)
+    rho = torch.empty_like(ex); th = torch.empty_like(ex)
+    cnt = torch.empty(nb, dtype=torch.int64, device=dev); rms = torch.empty(nb, dtype=torch.float64, device=dev)
+    sysd = eng.system(pres)
+    barr = _capi.make_bundles(bundles)
+    torch.cuda.synchronize()
+    _capi.check(eng.ctx.lib.ort_full_trace_f64(eng.ctx.h, sysd.h, nb, barr, d_axes.data_ptr(), axes.size, k, k,
+                                               ex.data_ptr(), ey.data_ptr(), rho.data_ptr(), th.data_ptr(),
+                                               cnt.data_ptr(), rms.data_ptr(), _capi.ORT_DEVICE_PTRS))
+    eng.ctx.synchronize()
+    c = cnt.cpu().numpy(); r = rms.cpu().numpy()
+    assert np.all(c % 2 == 0) and np.all(np.abs(c / 2 / rpb - math.pi / 4) < 0.10)
+    assert np.all(np.isfinite(r)) and np.all(r > 0)
+    # bundle 4: summary trace + host filter == compacted first half, in order; mirror exact
+    b = 4
+    xf = torch.empty(rpb, dtype=torch.float64, device=dev); yf = torch.empty_like(xf)
+    xs = torch.empty_like(xf); ys = torch.empty_like(xf); st = torch.empty(rpb, dtype=torch.int32, device=dev)
+    out = _capi.ort_grid_out_f64()
+    out.xf, out.yf, out.xs, out.ys, out.status = xf.data_ptr(), yf.data_ptr(), xs.data_ptr(), ys.data_ptr(), st.data_ptr()
+    one = _capi.make_bundles([bundles[b]])
+    _capi.check(eng.ctx.lib.ort_trace_grid_f64(eng.ctx.h, sysd.h, 1, one, d_axes.data_ptr(), axes.size, k, k,
+                                               C.byref(out), _capi.ORT_DEVICE_PTRS))
+    eng.ctx.synchronize()
+    keep = (st >> 16) == 0
+    m = int(c[b]) // 2
+    assert int(keep.sum()) == m
+    assert torch.equal(ex[b, :m], xf[keep]) and torch.equal(ey[b, :m], yf[keep] - bundles[b]["hprime"])
+    assert torch.equal(ex[b, m:2 * m], -ex[b, :m]) and torch.equal(ey[b, m:2 * m], ey[b, :m])
+    assert torch.equal(rho[b, m:2 * m], rho[b, :m]) and float(rho[b, :m].max()) == 1.0
+    # RMS from the returned vectors (float64 on the device) == returned RMS
+    X, Y = ex[b, :2 * m], ey[b, :2 * m]
+    sig = torch.sqrt((((X - X.mean()) ** 2).sum() + ((Y - Y.mean()) ** 2).sum()) / (2 * m))
+    assert abs(float(sig) - r[b]) <= 1e-12 * r[b]
+    # strided sample vs the oracle (aspheric rows: analytic vs complex-step derivative)
+    idx = np.arange(0, rpb, 9973)
+    bd = bundles[b]
+    yy = axes[bd["yaxis_off"] + idx // k]; xx = axes[bd["xaxis_off"] + idx % k]
+    sub = Prescription(pres.R[bd["system"]], pres.t[bd["system"]], pres.n[bd["system"]], pres.K[bd["system"]],
+                       pres.coef[bd["system"]][None])
+    u = np.full(idx.size, math.tan(bd["U"])); v = np.zeros(idx.size)
+    ox, oy, os_ = oracle_engine.skew(sub, yy, xx, u, v, slopes=True, want_status=True)
+    ti = torch.from_numpy(idx).to(dev)
+    assert cm.rel_err(xf[ti].cpu().numpy(), ox[-1], 1.0).max() <= 1e-12
+    assert cm.rel_err(yf[ti].cpu().numpy(), oy[-1], 1.0).max() <= 1e-12
+    assert np.array_equal(st[ti].cpu().numpy() & 0xffff, os_)
+
+
+def test_device_aiming_matches_host_driven(hip_engine, oracle_engine):
+    """ort_aim_f64 (one thread per (system, field) running the Newton loops on the device)
+    == the same loops driven from the host over the device meridional kernel (identical device
+    arithmetic -> identical iterates), and == the oracle-driven aiming to the Newton tolerance."""
+    from opticalraytracing_jl_amd import api, workloads
+    systems = [ort.solve(workloads.double_gauss(line, g), cm.DG_A, cm.DG_H, engine=oracle_engine)
+               for line, g in ((0, 0.0), (1, 0.4), (2, -0.7))]
+    M4, coef = cm.double_gauss_aspheric()
+    systems.append(ort.solve(ort.Layout(M4[:, 0], M4[:, 1], M4[:, 2], M4[:, 3], [c for c in coef]), cm.DG_A, cm.DG_H,
+                             engine=oracle_engine))
+    fields = (0.0, 0.7, 1.0)
+    dev = ort.full_trace_aim_batch(systems, fields, engine=hip_engine)
+    for si, s in enumerate(systems):
+        for fi, H in enumerate(fields):
+            host = ort.full_trace_aim(s.layout, s, H, engine=hip_engine)
+            orc = ort.full_trace_aim(s.layout, s, H, engine=oracle_engine)
+            d = dev[si][fi]
+            # U, y_EP: same device arithmetic on both routes -> identical.  tan(U) is ocml in the kernel
+            # and libm on the host route, so h' may differ in the last ulp and the edge-ray Newton
+            # (stopped at |residual| <= sqrt(eps)) may stop on a neighbouring iterate.
+            assert d.U == host.U and d.y_EP == host.y_EP, (si, H)
+            assert abs(d.hprime - host.hprime) <= 1e-14 * max(1.0, abs(host.hprime))
+            for key in ("y1", "y2"):
+                assert abs(getattr(d, key) - getattr(host, key)) <= 1e-7, (si, H, key)
+            for key in ("U", "y_EP", "hprime"):
+                assert abs(getattr(d, key) - getattr(orc, key)) <= 1e-9 * max(1.0, abs(getattr(orc, key))), (si, H, key)
+            for key in ("y1", "y2"):
+                assert abs(getattr(d, key) - getattr(orc, key)) <= 1e-7, (si, H, key)
+            assert d.stop == host.stop and d.a_stop == host.a_stop and d.focus == host.focus
+
+
+def test_full_trace_batch_end_to_end(hip_engine, oracle_engine):
+    """full_trace for (system x field) batches: aiming kernel + full_trace pipeline on the GPU
+    == per-call full_trace through the oracle (aiming tolerance sqrt(eps) -> 1e-7 on errors)."""
+    from opticalraytracing_jl_amd import workloads
+    sg = [ort.solve(workloads.double_gauss(l), cm.DG_A, cm.DG_H, engine=hip_engine) for l in (0, 1)]
+    so = [ort.solve(workloads.double_gauss(l), cm.DG_A, cm.DG_H, engine=oracle_engine) for l in (0, 1)]
+    errs = ort.full_trace_batch(sg, (0.0, 1.0), 48, engine=hip_engine)
+    for si in range(2):
+        for fi, H in enumerate((0.0, 1.0)):
+            ref = ort.full_trace(so[si], H, 48, engine=oracle_engine)
+            got = errs[si][fi]
+            assert len(got.x) == len(ref.x)
+            assert np.abs(got.x - ref.x).max() <= 1e-7 and np.abs(got.y - ref.y).max() <= 1e-7
+            assert abs(got.RMS - ref.RMS) <= 1e-7
+    with pytest.raises(ort.DomainError):
+        ort.full_trace_batch(sg, (1.2,), 16, engine=hip_engine)
