@@ -192,6 +192,21 @@ typedef struct ort_aim_out {
 int ort_aim_f64(ort_ctx *ctx, const ort_system *fwd, const ort_system *rev, int n,
                 const ort_aim_in *in, ort_aim_out *out, unsigned flags);
 
+/* ---- batched first-order solve + Seidel sums ------------------------------------------------
+ * solve(surfaces, a, h′) (src/RayTracing.jl:302-335: Lens(), the two paraxial traces, stop
+ * selection, marginal / chief construction) and aberrations(surfaces, system, λ, δn)
+ * (src/SeidelAberrations.jl:6-53), one thread per system; for Monte-Carlo runs over perturbed
+ * instances.  R, t, n : [nsys][rows]; a : [nsys][rows-1]; dn : [nsys][rows] or NULL; hprime : [nsys]. */
+typedef struct ort_first_order {
+    double f, EBFD, EFFD, N, FOV, EP_D, EP_t, XP_D, XP_t, H;
+    double y_marg, chief_y_end, chief_u_end, nu_end, BFD, PN;
+    double W040, W131, W222, W220, W311, W020, W111, W220P;     /* waves at lambda */
+    int32_t stop, k;
+} ort_first_order;
+int ort_first_order_f64(ort_ctx *ctx, int nsys, int rows, const double *R, const double *t, const double *n,
+                        const double *a, const double *dn, const double *hprime, double lambda,
+                        ort_first_order *out, unsigned flags);
+
 /* ---- paraxial y-nu trace: raytrace(lens, y, ω, a; clip) --------------------------------
  * src/RayTracing.jl:127-143 (+ transfer/refract :55-69).  nlens lenses of k rows each
  * (Lens.M columns τ, ϕ: [nlens][k]); a: [nlens][k] or NULL (fill(Inf)); rays_per_lens rays

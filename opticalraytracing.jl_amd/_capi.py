@@ -64,6 +64,13 @@ class ort_aim_out(C.Structure):
     ]
 
 
+class ort_first_order(C.Structure):
+    _fields_ = [(k, C.c_double) for k in (
+        "f", "EBFD", "EFFD", "N", "FOV", "EP_D", "EP_t", "XP_D", "XP_t", "H",
+        "y_marg", "chief_y_end", "chief_u_end", "nu_end", "BFD", "PN",
+        "W040", "W131", "W222", "W220", "W311", "W020", "W111", "W220P")] + [("stop", C.c_int32), ("k", C.c_int32)]
+
+
 class ort_grid_out_f64(C.Structure):
     _fields_ = [
         ("xv", C.c_void_p), ("yv", C.c_void_p), ("ld", C.c_int64),
@@ -102,6 +109,7 @@ SIGNATURES = {
     "ort_trace_grid_f32": (_i, [_p, _p, _i, C.POINTER(ort_bundle), _p, _l, _i, _i, C.POINTER(ort_grid_out_f32), _u]),
     "ort_full_trace_f64": (_i, [_p, _p, _i, C.POINTER(ort_bundle), _p, _l, _i, _i, _p, _p, _p, _p, _p, _p, _u]),
     "ort_aim_f64": (_i, [_p, _p, _p, _i, C.POINTER(ort_aim_in), C.POINTER(ort_aim_out), _u]),
+    "ort_first_order_f64": (_i, [_p, _i, _i, _p, _p, _p, _p, _p, _p, C.c_double, C.POINTER(ort_first_order), _u]),
     "ort_trace_meridional_f64": (_i, [_p, _p, _i, _l, _p, _p, _p, _p, _p, _l, _u]),
     "ort_trace_paraxial_f64": (_i, [_p, _i, _i, _p, _p, _p, _l, _p, _p, _p, _p, _l, _u]),
     "ort_abcd_f64": (_i, [_p, _i, _i, _p, _p, _p, _u]),

@@ -1,0 +1,213 @@
+"""Consumers of the traced rays that the reference keeps next to the hot path (SURVEY §8f
+rows 3-4): Seidel sums, paraxial vignetting table, transverse-ray-error polynomials, the
+meridional fan `TSA` and its least-squares fit `SA`.
+
+These are O(rows) host arithmetic per system in the reference too (no per-ray loop), so they
+stay host code here; every *trace* they need (paraxial, meridional fan) goes through the GPU
+engine.  The batched, one-thread-per-system device form of the first-order solve + Seidel sums
+for Monte-Carlo runs is `HipEngine.first_order` (csrc `k_first_order`).
+Citations are into /root/reference/.
+"""
+from __future__ import annotations
+
+import math
+from dataclasses import dataclass
+from typing import Optional
+
+import numpy as np
+
+from . import api
+from .api import (Chief, DomainError, K_RAYS, LAMBDA, Layout, Marginal, RealRay, RealRayT, System, surface_ray,
+                  surface_to_focus, trace_chief_ray, trace_marginal_ray, transfer_real)
+
+
+@dataclass
+class Aberration:                                                      # Types.jl:143-167
+    W040: float
+    W131: float
+    W222: float
+    W220: float
+    W311: float
+    W020: float
+    W111: float
+    W220P: float
+    W220M: float
+    W220T: float
+    spherical: np.ndarray
+    coma: np.ndarray
+    astigmatism: np.ndarray
+    sagittal: np.ndarray
+    distortion: np.ndarray
+    axial: np.ndarray
+    lateral: np.ndarray
+    petzval: np.ndarray
+    medial: np.ndarray
+    tangential: np.ndarray
+    lam: float
+    field_sign: int
+    system: object
+
+    def __call__(self, rho, theta, H):                                 # SeidelAberrations.jl:61-76
+        H = abs(H)
+        if not H <= 1.0:
+            raise DomainError(f"DomainError with {H}: Domain: |H| ≤ 1.0")
+        if not 0.0 <= rho <= 1.0:
+            raise DomainError(f"DomainError with {rho}: Domain: 0.0 ≤ ρ ≤ 1.0")
+        H *= self.field_sign
+        c = math.cos(theta)
+        return (self.W040 * rho ** 4 + self.W131 * H * rho ** 3 * c + self.W222 * H ** 2 * rho ** 2 * c ** 2 +
+                self.W220 * H ** 2 * rho ** 2 + self.W311 * H ** 3 * rho * c + self.W020 * rho ** 2 +
+                self.W111 * H * rho * c)
+
+
+def aberrations(surfaces, system=None, lam: float = LAMBDA, dn=None) -> Aberration:
+    """Third-order wavefront coefficients from Seidel sums (SeidelAberrations.jl:6-59)."""
+    if isinstance(surfaces, System) and system is None:                # :55-59
+        system = surfaces
+        surfaces = system.layout
+    M = np.asarray(surfaces.M if isinstance(surfaces, Layout) else surfaces, dtype=np.float64)
+    if dn is None:
+        dn = np.zeros(M.shape[0])
+    dn = np.asarray(dn, dtype=np.float64)
+    marginal, chief, H = system.marginal, system.chief, system.H
+    R = M[1:, 0]
+    n = marginal.n
+    y = surface_ray(marginal.y)
+    yb = surface_ray(chief.y)
+    nu, nub, u = marginal.nu, chief.nu, marginal.u
+    j = np.arange(len(R))
+
+    def delta(x, yv, i):                                               # :4
+        return x[i + 1] / yv[i + 1] - x[i] / yv[i]
+
+    A = np.array([nu[i] + n[i] * y[i] / R[i] for i in j])
+    Ab = np.array([(H + A[i] * yb[i]) / y[i] for i in j])
+    yD = np.array([y[i] * delta(u, n, i) for i in j])
+    yd = np.array([y[i] * delta(dn, n, i) for i in j])
+    Dn2 = np.array([(1 / n[i + 1]) ** 2 - (1 / n[i]) ** 2 for i in j])
+    P = np.array([((1 / n[i + 1]) - (1 / n[i])) / R[i] for i in j])
+    yj = y[: len(j)]
+    ybj = yb[: len(j)]
+    spherical = -A ** 2 * yD / (8 * lam)
+    coma = -A * Ab * yD / (2 * lam)
+    astigmatism = -Ab ** 2 * yD / (2 * lam)
+    petzval = -H ** 2 * P / (4 * lam)
+    sagittal = petzval + astigmatism / 2
+    distortion = -Ab * (Ab ** 2 * yj * Dn2 - (H + Ab * yj) * ybj * P) / (2 * lam)
+    axial = A * yd / (2 * lam)
+    lateral = Ab * yd / lam
+    medial = petzval + astigmatism
+    tangential = petzval + 1.5 * astigmatism
+    W040, W131, W222, W311 = spherical.sum(), coma.sum(), astigmatism.sum(), distortion.sum()
+    W220P = petzval.sum()
+    return Aberration(W040, W131, W222, W220P + 0.5 * W222, W311, axial.sum(), lateral.sum(), W220P,
+                      W220P + W222, W220P + 1.5 * W222, spherical, coma, astigmatism, sagittal, distortion,
+                      axial, lateral, petzval, medial, tangential, lam, int(np.sign(chief.y[-1])), system)
+
+
+class RayError:
+    """Transverse ray error polynomials (SeidelAberrations.jl:78-114).  kind: api.Tangential /
+    api.Sagittal / api.Skew."""
+
+    def __init__(self, kind, W: Aberration):
+        self.kind, self.W = kind, W
+        self.nu = W.system.marginal.nu[-1]
+        self.field_sign = W.field_sign
+
+    def _err(self, x, y, H):
+        if not math.hypot(x, y) <= 1.0:
+            raise DomainError("Domain: hypot(x, y) ≤ 1.0")
+        H = abs(H)
+        if not H <= 1.0:
+            raise DomainError("Domain: |H| ≤ 1.0")
+        H *= self.field_sign
+        W = self.W
+        ey = (4 * W.W040 * (x ** 2 * y + y ** 3) + W.W131 * H * (x ** 2 + 3 * y ** 2) + 2 * W.W222 * H ** 2 * y +
+              2 * W.W220 * H ** 2 * y + W.W311 * H ** 3 + 2 * W.W020 * y + W.W111 * H) * W.lam / self.nu
+        ex = (4 * W.W040 * (y ** 2 * x + x ** 3) + W.W131 * H * (2 * x * y) + 2 * W.W220 * H ** 2 * x +
+              2 * W.W020 * x) * W.lam / self.nu
+        return ex, ey
+
+    def __call__(self, *args):
+        if self.kind is api.Tangential:
+            return self._err(0, args[0], args[1])[1]
+        if self.kind is api.Sagittal:
+            return self._err(args[0], 0, args[1])[0]
+        return self._err(*args)
+
+
+@dataclass
+class Vignetting:                                                      # Types.jl:169-176
+    M: np.ndarray
+    FOV: np.ndarray
+    un: bool
+    limit: list
+    partial: list
+    full: list
+
+
+def vignetting(system, a=None) -> Vignetting:                          # Vignetting.jl:1-30
+    a = np.asarray(system.a if a is None else a, dtype=np.float64)
+    marginal, chief, stop = system.marginal, system.chief, system.stop
+    yb = np.abs(surface_ray(chief.y))
+    y = np.abs(surface_ray(marginal.y))
+    vig = np.empty((len(a), 5))
+    vig[:, 0] = a
+    vig[:, 1] = y
+    vig[:, 2] = y + yb
+    vig[:, 3] = yb
+    vig[:, 4] = yb - y
+    limited, unvig = vig[:, 1].copy(), vig[:, 2].copy()
+    half, full_v = vig[:, 3], vig[:, 4]
+    half[half < y] = np.nan
+    full_v[full_v < y] = np.nan
+    approx = np.isclose(a, unvig, rtol=math.sqrt(np.finfo(float).eps), atol=0.0)
+    a_unvig = (a >= unvig) | approx
+    un = bool(a_unvig.all())
+    with np.errstate(divide="ignore", invalid="ignore"):
+        min_un = min((a[i] - y[i]) / yb[i] for i in range(len(a)) if i != stop - 1)
+        min_half = np.min(a / yb)
+        min_full = np.min((a + y) / yb)
+    FOV = np.empty((3, 3))
+    for i, s in enumerate((min_un, min_half, min_full)):
+        ub = abs(chief.u[0] * s)
+        FOV[i] = (2 * math.degrees(math.atan(ub)), ub, abs(chief.y[-1] * s))
+    limit = [int(i) + 1 for i in np.nonzero((a < limited) & ~approx)[0]]
+    with np.errstate(invalid="ignore"):
+        full = [int(i) + 1 for i in np.nonzero(a <= vig[:, 4])[0]]
+    partial = [int(i) + 1 for i in np.nonzero(~a_unvig)[0] if int(i) + 1 not in full]
+    return Vignetting(vig, FOV, un, limit, partial, full)
+
+
+def TSA(surfaces, system=None, k_rays: int = K_RAYS, engine=None):
+    """Transverse spherical aberration fan (SeidelAberrations.jl:116-137): k_rays - 1 meridional
+    rays traced in ONE launch of the device kernel."""
+    if isinstance(surfaces, System) and system is None:
+        system = surfaces
+        surfaces = system.layout
+    pm = system.marginal
+    rm = trace_marginal_ray(surfaces, system, engine=engine)
+    rc = trace_chief_ray(surfaces, system, engine=engine)
+    XP_t = rc.z[-1] - rc.z[-2]
+    y_EP = api.linrange(rm.y[0] / k_rays, rm.y[0], k_rays)
+    y_XP = np.empty(k_rays)
+    eps = np.empty(k_rays)
+    BFD = pm.z[-1] - pm.z[-2]
+    t = surface_to_focus(BFD, rm, pm)
+    y_XP[-1] = rm.y[-2] + math.tan(rm.u[-1]) * XP_t
+    eps[-1] = transfer_real(rm, t)
+    rays = api.raytrace(surfaces, y_EP[:-1], 0.0, RealRay, engine=engine)
+    for i, ray in enumerate(rays):
+        tt = surface_to_focus(BFD, ray)
+        y_XP[i] = ray.y[-1] + math.tan(ray.u[-1]) * XP_t
+        eps[i] = transfer_real(ray, tt)
+    return y_XP, eps
+
+
+def SA(y, eps, degree: int):                                           # SeidelAberrations.jl:139-146
+    if degree % 2 == 0 or degree < 3:
+        raise DomainError(f"DomainError with {degree}: Required: isodd(degree) && degree ≥ 3")
+    y = np.asarray(y, dtype=np.float64)
+    yp = y / y.max()
+    A = np.column_stack([yp ** k for k in range(3, degree + 1, 2)])
+    return np.linalg.lstsq(A, np.asarray(eps, dtype=np.float64), rcond=None)[0]

@@ -731,6 +731,38 @@ int ort_aim_f64(ort_ctx* ctx, const ort_system* fwd, const ort_system* rev, int 
 }
 
 // --------------------------------------------------------------------------------------
+int ort_first_order_f64(ort_ctx* ctx, int nsys, int rows, const double* R, const double* t, const double* n,
+                        const double* a, const double* dn, const double* hprime, double lambda,
+                        ort_first_order* out, unsigned flags)
+{
+    static_assert(sizeof(ort_first_order) == sizeof(FirstOrderOut), "ABI struct mismatch");
+    int rc = check_ctx(ctx); if (rc) return rc;
+    if (nsys <= 0 || rows < 2 || rows > ORT_MAX_ROWS || !R || !t || !n || !a || !hprime || !out || !(lambda > 0.0))
+        return fail(ORT_EINVAL, "bad first_order arguments");
+    const bool devp = flags & ORT_DEVICE_PTRS;
+    const double *dR = R, *dt = t, *dnn = n, *da = a, *ddn = dn, *dh = hprime;
+    FirstOrderOut* dout = reinterpret_cast<FirstOrderOut*>(out);
+    const size_t nr = (size_t)nsys * rows;
+    if (!devp) {
+        rc = to_device<double>(ctx, SL_IN0, R, nr, &dR); if (rc) return rc;
+        rc = to_device<double>(ctx, SL_IN1, t, nr, &dt); if (rc) return rc;
+        rc = to_device<double>(ctx, SL_IN2, n, nr, &dnn); if (rc) return rc;
+        rc = to_device<double>(ctx, SL_IN3, a, (size_t)nsys * (rows - 1), &da); if (rc) return rc;
+        if (dn) { rc = to_device<double>(ctx, SL_TAB0, dn, nr, &ddn); if (rc) return rc; }
+        rc = to_device<double>(ctx, SL_TAB1, hprime, (size_t)nsys, &dh); if (rc) return rc;
+        rc = dev_out<FirstOrderOut>(ctx, SL_OUT0, (size_t)nsys, &dout); if (rc) return rc;
+    }
+    hipLaunchKernelGGL(k_first_order, dim3((unsigned)((nsys + 63) / 64)), dim3(64), 0, ctx->stream,
+                       nsys, rows, dR, dt, dnn, da, ddn, dh, lambda, dout);
+    HIP_TRY(hipGetLastError());
+    if (!devp) {
+        rc = from_device<FirstOrderOut>(ctx, reinterpret_cast<FirstOrderOut*>(out), dout, (size_t)nsys); if (rc) return rc;
+        HIP_TRY(hipStreamSynchronize(ctx->stream));
+    }
+    return ORT_OK;
+}
+
+// --------------------------------------------------------------------------------------
 int ort_trace_paraxial_f64(ort_ctx* ctx, int nlens, int k, const double* tau, const double* phi, const double* a,
                            int64_t rays_per_lens, const double* y, const double* w,
                            double* rt_y, double* rt_w, int64_t ld, unsigned flags)

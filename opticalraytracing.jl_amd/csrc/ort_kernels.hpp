@@ -680,6 +680,113 @@ __global__ __launch_bounds__(kBlock) void k_trace_paraxial(int k, const double* 
 }
 
 // ------------------------------------------------------------------------------------
+// Batched first-order solve + Seidel sums (SURVEY §8f "next #3"): one thread per system runs
+// Lens(surfaces) (src/RayTracing.jl:38-53), the two paraxial traces and the marginal / chief
+// construction of `_solve` (:208-221, :246-263, :302-323) and the third-order sums of
+// `aberrations` (src/SeidelAberrations.jl:6-53).  O(rows) work per system: for Monte-Carlo
+// tolerance runs (BASELINE config 5) thousands of instances go out as one launch.
+// ------------------------------------------------------------------------------------
+struct FirstOrderOut {
+    double f, EBFD, EFFD, N, FOV, EP_D, EP_t, XP_D, XP_t, H;
+    double y_marg, chief_y_end, chief_u_end, nu_end, BFD, PN;
+    double W040, W131, W222, W220, W311, W020, W111, W220P;
+    int32_t stop, k;
+};
+
+__global__ __launch_bounds__(64) void k_first_order(int nsys, int rows, const double* __restrict__ Rg, const double* __restrict__ tg,
+                                                    const double* __restrict__ ng, const double* __restrict__ ag,
+                                                    const double* __restrict__ dng, const double* __restrict__ hp,
+                                                    double lam, FirstOrderOut* __restrict__ out)
+{
+    const int g = blockIdx.x * 64 + threadIdx.x;
+    if (g >= nsys) return;
+    const double* R = Rg + (int64_t)g * rows;
+    const double* t = tg + (int64_t)g * rows;
+    const double* n = ng + (int64_t)g * rows;
+    const double* a = ag + (int64_t)g * (rows - 1);
+    const double* dn = dng ? dng + (int64_t)g * rows : nullptr;
+    const double h = hp[g];
+    double tau[kMaxRows], phi[kMaxRows];
+    double y1[kMaxRows + 2], w1[kMaxRows + 2], y2[kMaxRows + 1], w2[kMaxRows + 1];
+    // Lens(surfaces)  RayTracing.jl:38-53
+    for (int i = 0; i < rows; ++i) {
+        const double ti = (i == 0 && !__builtin_isfinite(t[0])) ? 0.0 : t[i];      // :42
+        tau[i] = ti / n[i];                                                          // :43
+        phi[i] = (i < rows - 1) ? (n[i + 1] - n[i]) / R[i + 1] : 0.0;               // :45,50
+    }
+    const double tl = t[rows - 1];
+    const int k = (tl == 0.0 || !__builtin_isfinite(tl)) ? rows - 1 : rows;          // :47-48
+    // paraxial traces (1, 0) and (0, 1)  :127-141
+    {
+        double ya = 1.0, wa = 0.0, yb = 0.0, wb = 1.0;
+        y1[0] = ya; w1[0] = wa; y2[0] = yb; w2[0] = wb;
+        for (int i = 0; i < k; ++i) {
+            const bool fin = __builtin_isfinite(tau[i]);
+            ya = fin ? ya + wa * tau[i] : ya;  wa = wa - ya * phi[i];
+            yb = fin ? yb + wb * tau[i] : yb;  wb = wb - yb * phi[i];
+            y1[i + 1] = ya; w1[i + 1] = wa; y2[i + 1] = yb; w2[i + 1] = wb;
+        }
+    }
+    FirstOrderOut o;
+    o.k = k;
+    o.f = -(1.0 / w1[k]);                                                            // :213
+    o.EBFD = y1[k] * o.f;                                                            // :214
+    int stop = 0; double s = a[0] / y1[1];
+    for (int i = 1; i < k; ++i) { const double sv = a[i] / y1[i + 1]; if (sv < s) { s = sv; stop = i; } }   // findmin :215-216
+    o.stop = stop + 1;
+    for (int i = 0; i <= k; ++i) { y1[i] *= s; w1[i] *= s; }                         // :217
+    w1[k + 1] = w1[k]; y1[k + 1] = (w1[k] == 0.0) ? y1[k] : 0.0;                     // extend :202-206
+    // chief  :246-263
+    const double y_stop = y1[stop + 1], y2_stop = y2[stop + 1];
+    const double nub = -w1[k + 1] * h / y1[1];                                       // :256
+    double yc[kMaxRows + 2], wc[kMaxRows + 2];
+    yc[0] = 0.0; wc[0] = nub;                                                        // :259
+    for (int i = 1; i <= k; ++i) {                                                   // :258
+        yc[i] = nub * (y2[i] - y1[i] * y2_stop / y_stop);
+        wc[i] = nub * (w2[i] - w1[i] * y2_stop / y_stop);
+    }
+    yc[k + 1] = h; wc[k + 1] = wc[k];                                                // :260
+    // _solve  :302-323
+    const double ybar = yc[1], nubp = wc[k + 1], ym = y1[0], ybpb = yc[k];
+    const double dp = o.EBFD - o.f;
+    const double d = (h - nubp * o.f - ybar) / nub;
+    o.EFFD = d - o.f;
+    o.PN = (n[rows - 1] - n[0]) * o.f;
+    o.EP_D = fabs(ym) * 2.0; o.EP_t = -ybar / nub;
+    o.H = nub * ym;
+    o.XP_D = fabs(2.0 * o.H / nubp); o.XP_t = -ybpb / nubp;
+    o.N = fabs(o.f / o.EP_D);
+    auto next = [&](int i) { return n[i < rows ? i : rows - 1]; };                   // n = [n; n[end]]  Types.jl:39
+    o.FOV = 2.0 * (::atan(fabs(wc[0] / next(0))) * 57.29577951308232);               // 2atand  :319
+    (void)dp;
+    o.y_marg = ym; o.chief_y_end = yc[k + 1]; o.chief_u_end = wc[k + 1] / next(k + 1); o.nu_end = w1[k + 1];
+    o.BFD = -y1[k] / (w1[k] / next(k));                                              // Types.jl:44 (t[end] of the marginal)
+    // aberrations  SeidelAberrations.jl:6-53
+    double W040 = 0, W131 = 0, W222 = 0, W311 = 0, W220P = 0, W020 = 0, W111 = 0;
+    for (int i = 0; i < rows - 1; ++i) {
+        const double ni = next(i), nj = next(i + 1), yi = y1[i + 1], ybi = yc[i + 1], Ri = R[i + 1];
+        const double ui = w1[i] / ni, uj = w1[i + 1] / nj;
+        const double A = w1[i] + ni * yi / Ri;
+        const double Ab = (o.H + A * ybi) / yi;
+        const double yD = yi * (uj / nj - ui / ni);
+        const double yd = dn ? yi * (dn[i + 1] / nj - dn[i] / ni) : 0.0;
+        const double inj = 1.0 / nj, ini = 1.0 / ni;
+        const double Dn2 = inj * inj - ini * ini;
+        const double P = (inj - ini) / Ri;
+        const double sph = -(A * A) * yD / (8.0 * lam);
+        const double coma = -A * Ab * yD / (2.0 * lam);
+        const double ast = -(Ab * Ab) * yD / (2.0 * lam);
+        const double ptz = -(o.H * o.H) * P / (4.0 * lam);
+        const double dist = -Ab * ((Ab * Ab) * yi * Dn2 - (o.H + Ab * yi) * ybi * P) / (2.0 * lam);
+        W040 += sph; W131 += coma; W222 += ast; W311 += dist; W220P += ptz;
+        W020 += A * yd / (2.0 * lam); W111 += Ab * yd / lam;
+    }
+    o.W040 = W040; o.W131 = W131; o.W222 = W222; o.W311 = W311; o.W220P = W220P;
+    o.W220 = W220P + 0.5 * W222; o.W020 = W020; o.W111 = W111;
+    out[g] = o;
+}
+
+// ------------------------------------------------------------------------------------
 // ABCD, src/TransferMatrix.jl:1-17.  One thread per lens / per vector.
 // ------------------------------------------------------------------------------------
 __device__ __forceinline__ void mm2(const double* A, const double* B, double* C)

@@ -174,6 +174,19 @@ class HipEngine:
         return [dict(U=o.U, y1=o.y1, y2=o.y2, y_EP=o.y_EP, hprime=o.hprime, EP_t=o.EP_t, Ubar=o.Ubar,
                      iters=o.iters, ok=bool(o.ok)) for o in aout]
 
+    # ---- batched first-order solve + Seidel sums: RayTracing.jl:302-323, SeidelAberrations.jl:6-53 --
+    def first_order(self, R, t, n, a, hprime, dn=None, lam: float = 587.5618e-6) -> List[dict]:
+        R, t, n = (np.atleast_2d(f64(v)) for v in (R, t, n))
+        nsys, rows = R.shape
+        a = np.ascontiguousarray(np.broadcast_to(f64(a), (nsys, rows - 1)))
+        hp = np.ascontiguousarray(np.broadcast_to(f64(hprime), (nsys,)))
+        dnp = None if dn is None else np.ascontiguousarray(np.broadcast_to(f64(dn), (nsys, rows)))
+        out = (_capi.ort_first_order * nsys)()
+        check(self.ctx.lib.ort_first_order_f64(self.ctx.h, nsys, rows, ptr(R), ptr(t), ptr(n), ptr(a), ptr(dnp), ptr(hp),
+                                               float(lam), out, self.base_flags))
+        names = [f[0] for f in _capi.ort_first_order._fields_]
+        return [{k: getattr(o, k) for k in names} for o in out]
+
     # ---- paraxial: raytrace(lens, y, ω, a; clip)  RayTracing.jl:127-143 ------------------
     def paraxial(self, tau, phi, y, w, a=None, clip: bool = False):
         tau = np.atleast_2d(f64(tau)); phi = np.atleast_2d(f64(phi))

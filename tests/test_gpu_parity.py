@@ -502,3 +502,30 @@ def test_full_trace_batch_end_to_end(hip_engine, oracle_engine):
             assert abs(got.RMS - ref.RMS) <= 1e-7
     with pytest.raises(ort.DomainError):
         ort.full_trace_batch(sg, (1.2,), 16, engine=hip_engine)
+
+
+def test_first_order_and_seidel_batch(hip_engine, oracle_engine):
+    """ort_first_order_f64 over 300 perturbed Double-Gauss instances (config 5's Monte-Carlo) +
+    the Cooke triplet with its dispersion vector: == solve() + aberrations() of the host mirror
+    (whose values are pinned to the reference's known answers on the CPU)."""
+    from opticalraytracing_jl_amd import analysis as an, workloads
+    mats = workloads.config5(None, ninst=300)
+    res = hip_engine.first_order(mats[:, :, 0], mats[:, :, 1], mats[:, :, 2], cm.DG_A, cm.DG_H)
+    for i in (0, 7, 123, 299):
+        s = ort.solve(mats[i].copy(), cm.DG_A, cm.DG_H, engine=oracle_engine)
+        ab = an.aberrations(mats[i], s)
+        r = res[i]
+        assert r["stop"] == s.stop and r["k"] == s.lens.M.shape[0]
+        for key, ref in (("f", s.f), ("EBFD", s.EBFD), ("EFFD", s.EFFD), ("N", s.N), ("FOV", s.FOV), ("H", s.H),
+                         ("EP_D", s.EP.D), ("EP_t", s.EP.t), ("XP_D", s.XP.D), ("XP_t", s.XP.t), ("PN", s.PN),
+                         ("y_marg", s.marginal.y[0]), ("chief_y_end", s.chief.y[-1]), ("chief_u_end", s.chief.u[-1]),
+                         ("nu_end", s.marginal.nu[-1]), ("BFD", s.marginal.z[-1] - s.marginal.z[-2]),
+                         ("W040", ab.W040), ("W131", ab.W131), ("W222", ab.W222), ("W220", ab.W220),
+                         ("W311", ab.W311), ("W220P", ab.W220P)):
+            assert abs(r[key] - ref) <= 1e-11 * max(1.0, abs(ref)), (i, key, r[key], ref)
+    surf = cm.cooke()
+    r = hip_engine.first_order(surf[:, 0], surf[:, 1], surf[:, 2], cm.COOKE_A, cm.COOKE_H, dn=cm.COOKE_DN)[0]
+    assert abs(r["f"] - 101.181) < 1e-3 and abs(r["EBFD"] - 77.405) < 1e-3 and r["stop"] == 5   # test/runtests.jl:53-60
+    s = ort.solve(cm.cooke(), cm.COOKE_A, cm.COOKE_H, engine=oracle_engine)
+    ab = an.aberrations(cm.cooke(), s, dn=cm.COOKE_DN)
+    assert abs(r["W020"] - ab.W020) <= 1e-11 and abs(r["W111"] - ab.W111) <= 1e-11
