@@ -120,6 +120,15 @@ __device__ __forceinline__ float dev_hypot(float a, float b) { return ::hypotf(a
 __device__ __forceinline__ double dev_atan2(double a, double b) { return ::atan2(a, b); }
 __device__ __forceinline__ float dev_atan2(float a, float b) { return ::atan2f(a, b); }
 
+// Member-wise copy of one record out of the constant address space (scalar loads).
+template <typename T>
+__device__ __forceinline__ void load_rec(SurfRec<T>& d, const __attribute__((address_space(4))) SurfRec<T>* s, int i)
+{
+    d.t = s[i].t; d.R = s[i].R; d.R2 = s[i].R2; d.sgn = s[i].sgn; d.opk = s[i].opk; d.eta = s[i].eta;
+    d.eta2 = s[i].eta2; d.K = s[i].K; d.invR = s[i].invR; d.ome2 = s[i].ome2; d.e2c2 = s[i].e2c2; d.ec = s[i].ec;
+    d.finite = s[i].finite; d.ncoef = s[i].ncoef; d.kind = s[i].kind; d.cls = s[i].cls;
+}
+
 // ------------------------------------------------------------------------------------
 // The hot kernel.  GRID: rays generated from bundle axes; otherwise read from lists.
 // HIST: write per-surface history.  SUMM: write image/stop hits + status.
@@ -214,8 +223,19 @@ __global__ __launch_bounds__(kBlock, ORT_MIN_WAVES) void k_trace(TraceParams<T> 
         vec_all = __all(two && al);
     }
 
+    // USE_LDS = false: the table is read through the CONSTANT address space with a wave-uniform
+    // address -> s_load into SGPRs (scalar cache), the next row prefetched while this one computes.
+    typedef const __attribute__((address_space(4))) SurfRec<T>* CRecPtr;
+    const CRecPtr crec = (CRecPtr)(uintptr_t)grec;
+    SurfRec<T> nxt;
+    if (!USE_LDS) load_rec<T>(nxt, crec, 0);
     for (int i = 0; i < S; ++i) {
-        const SurfRec<T>& rec = USE_LDS ? s_rec[i] : grec[i];
+        SurfRec<T> cur;
+        if (!USE_LDS) {
+            cur = nxt;
+            load_rec<T>(nxt, crec, (i + 1 < S) ? i + 1 : i);
+        }
+        const SurfRec<T>& rec = USE_LDS ? s_rec[i] : cur;
         const T* cf = USE_LDS ? (s_coef + i * ncoef) : (gcoef ? gcoef + (int64_t)(i + 1) * ncoef : nullptr);
         const int cls = __builtin_amdgcn_readfirstlane(rec.cls);     // wave-uniform -> scalar branch
         surface_step_n<T, MATH, kRPT>(ray, rec, cf, cls);
