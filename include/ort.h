@@ -230,6 +230,24 @@ int ort_abcd_reverse_transfer_f64(ort_ctx *ctx, const double *M, int64_t nv, con
                                   const double *tau_p, const double *tau, double *out,
                                   unsigned flags);
 
+/* ---- multi-GPU reassembly: ONE all-gather of image-plane hits over RCCL / xGMI -------------
+ * One process per GPU.  The path shards over independent bundles (no data-path collective); the
+ * only exchange is the reassembly of equal-size per-rank hit slabs in rank order — which, with
+ * contiguous rank-ordered shards, reproduces the reference's append order
+ * (src/PupilSampling.jl:134-137).  librccl.so is loaded on first use (dlopen), so the library has
+ * no link-time dependency on it.
+ *   rank 0: ort_comm_unique_id(id);  ship the 128 bytes to every rank (file, socket, MPI, ...)
+ *   all   : ort_comm_create(ctx, nranks, rank, id, &comm)
+ *   all   : ort_allgather_hits_f64(comm, xf, yf, count, gx, gy)      device pointers, async
+ *           gx, gy : [nranks*count], rank r's slab at r*count.                                  */
+typedef struct ort_comm ort_comm;
+#define ORT_UNIQUE_ID_BYTES 128
+int ort_comm_unique_id(void *id128);
+int ort_comm_create(ort_ctx *ctx, int nranks, int rank, const void *id128, ort_comm **out);
+int ort_comm_destroy(ort_comm *comm);
+int ort_allgather_hits_f64(ort_comm *comm, const double *xf, const double *yf, int64_t count,
+                           double *gx, double *gy);
+
 #ifdef __cplusplus
 }
 #endif

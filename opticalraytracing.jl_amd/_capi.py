@@ -115,6 +115,10 @@ SIGNATURES = {
     "ort_abcd_f64": (_i, [_p, _i, _i, _p, _p, _p, _u]),
     "ort_abcd_transfer_f64": (_i, [_p, _p, _l, _p, _p, _p, _p, _u]),
     "ort_abcd_reverse_transfer_f64": (_i, [_p, _p, _l, _p, _p, _p, _p, _u]),
+    "ort_comm_unique_id": (_i, [_p]),
+    "ort_comm_create": (_i, [_p, _i, _i, _p, C.POINTER(_p)]),
+    "ort_comm_destroy": (_i, [_p]),
+    "ort_allgather_hits_f64": (_i, [_p, _p, _p, _l, _p, _p]),
 }
 
 _lib: Optional[C.CDLL] = None

@@ -11,6 +11,8 @@
 
 #include <hip/hip_runtime.h>
 
+#include <dlfcn.h>
+
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
@@ -860,6 +862,105 @@ int ort_abcd_reverse_transfer_f64(ort_ctx* ctx, const double* M, int64_t nv, con
                                   const double* tau, double* out, unsigned flags)
 {
     return abcd_apply(ctx, M, nv, v, tau, tau_p, out, flags, 1);
+}
+
+// --------------------------------------------------------------------------------------
+// RCCL, loaded lazily.  Only the five entry points the reassembly needs.
+struct Id128 { char b[ORT_UNIQUE_ID_BYTES]; };   // ncclUniqueId, passed by value
+namespace {
+struct Rccl {
+    void* h = nullptr;
+    int (*GetUniqueId)(void*) = nullptr;
+    int (*CommInitRank)(void**, int, Id128, int) = nullptr;
+    int (*AllGather)(const void*, void*, size_t, int, void*, hipStream_t) = nullptr;
+    int (*CommDestroy)(void*) = nullptr;
+    const char* (*GetErrorString)(int) = nullptr;
+    int (*GroupStart)() = nullptr;
+    int (*GroupEnd)() = nullptr;
+};
+Rccl g_rccl;
+
+int rccl_load()
+{
+    if (g_rccl.h) return ORT_OK;
+    const char* names[] = {"librccl.so", "librccl.so.1", "/opt/rocm/lib/librccl.so.1"};
+    void* h = nullptr;
+    for (const char* n : names) { h = dlopen(n, RTLD_NOW | RTLD_GLOBAL); if (h) break; }
+    if (!h) return fail(ORT_EHIP, "cannot load librccl.so: %s", dlerror());
+    g_rccl.GetUniqueId = (int (*)(void*))dlsym(h, "ncclGetUniqueId");
+    g_rccl.CommInitRank = (int (*)(void**, int, Id128, int))dlsym(h, "ncclCommInitRank");
+    g_rccl.AllGather = (int (*)(const void*, void*, size_t, int, void*, hipStream_t))dlsym(h, "ncclAllGather");
+    g_rccl.CommDestroy = (int (*)(void*))dlsym(h, "ncclCommDestroy");
+    g_rccl.GetErrorString = (const char* (*)(int))dlsym(h, "ncclGetErrorString");
+    g_rccl.GroupStart = (int (*)())dlsym(h, "ncclGroupStart");
+    g_rccl.GroupEnd = (int (*)())dlsym(h, "ncclGroupEnd");
+    if (!g_rccl.GetUniqueId || !g_rccl.CommInitRank || !g_rccl.AllGather || !g_rccl.CommDestroy || !g_rccl.GroupStart || !g_rccl.GroupEnd)
+        return fail(ORT_EHIP, "librccl.so lacks a required symbol");
+    g_rccl.h = h;
+    return ORT_OK;
+}
+#define RCCL_TRY(expr)                                                                             \
+    do {                                                                                           \
+        int r_ = (expr);                                                                           \
+        if (r_ != 0) return fail(ORT_EHIP, "%s failed: %s", #expr,                                 \
+                                 g_rccl.GetErrorString ? g_rccl.GetErrorString(r_) : "rccl error"); \
+    } while (0)
+}  // namespace
+
+struct ort_comm {
+    ort_ctx* ctx = nullptr;
+    void* comm = nullptr;
+    int nranks = 0, rank = 0;
+};
+
+int ort_comm_unique_id(void* id128)
+{
+    if (!id128) return fail(ORT_EINVAL, "null id");
+    int rc = rccl_load(); if (rc) return rc;
+    RCCL_TRY(g_rccl.GetUniqueId(id128));
+    return ORT_OK;
+}
+
+int ort_comm_create(ort_ctx* ctx, int nranks, int rank, const void* id128, ort_comm** out)
+{
+    int rc = check_ctx(ctx); if (rc) return rc;
+    if (!out || !id128 || nranks < 1 || rank < 0 || rank >= nranks) return fail(ORT_EINVAL, "bad communicator arguments");
+    *out = nullptr;
+    rc = rccl_load(); if (rc) return rc;
+    Id128 id;
+    memcpy(id.b, id128, ORT_UNIQUE_ID_BYTES);
+    ort_comm* c = new (std::nothrow) ort_comm();
+    if (!c) return fail(ORT_ENOMEM, "out of host memory");
+    c->ctx = ctx; c->nranks = nranks; c->rank = rank;
+    int r = g_rccl.CommInitRank(&c->comm, nranks, id, rank);
+    if (r != 0) { delete c; return fail(ORT_EHIP, "ncclCommInitRank failed: %s", g_rccl.GetErrorString ? g_rccl.GetErrorString(r) : "?"); }
+    *out = c;
+    return ORT_OK;
+}
+
+int ort_comm_destroy(ort_comm* comm)
+{
+    if (!comm) return ORT_OK;
+    if (comm->comm && g_rccl.CommDestroy) {
+        hipError_t e = hipSetDevice(comm->ctx->device); (void)e;
+        e = hipStreamSynchronize(comm->ctx->stream); (void)e;
+        g_rccl.CommDestroy(comm->comm);
+    }
+    delete comm;
+    return ORT_OK;
+}
+
+int ort_allgather_hits_f64(ort_comm* comm, const double* xf, const double* yf, int64_t count, double* gx, double* gy)
+{
+    if (!comm || !xf || !yf || !gx || !gy || count < 0) return fail(ORT_EINVAL, "bad all-gather arguments");
+    int rc = check_ctx(comm->ctx); if (rc) return rc;
+    if (count == 0) return ORT_OK;
+    const int ncclFloat64 = 8;
+    RCCL_TRY(g_rccl.GroupStart());           // x and y slabs fused into one RCCL launch
+    RCCL_TRY(g_rccl.AllGather(xf, gx, (size_t)count, ncclFloat64, comm->comm, comm->ctx->stream));
+    RCCL_TRY(g_rccl.AllGather(yf, gy, (size_t)count, ncclFloat64, comm->comm, comm->ctx->stream));
+    RCCL_TRY(g_rccl.GroupEnd());
+    return ORT_OK;
 }
 
 }  // extern "C"

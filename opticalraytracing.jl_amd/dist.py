@@ -83,3 +83,43 @@ def allreduce_moments(count, sx, sy, sxx, syy, group=None):
     buf = torch.stack([count.double(), sx.double(), sy.double(), sxx.double(), syy.double()])
     dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=group)
     return buf[0], buf[1], buf[2], buf[3], buf[4]
+
+
+class RcclComm:
+    """Native reassembly through the C ABI (ort_comm_* / ort_allgather_hits_f64): what a non-Python
+    host (the Julia shim) uses instead of torch.distributed.  `unique_id()` on rank 0, ship the
+    128 bytes to every rank by any means, then construct on every rank."""
+
+    def __init__(self, engine, nranks: int, rank: int, id_bytes: bytes):
+        import ctypes as C
+        from . import _capi
+        self._capi, self._C = _capi, C
+        self.engine, self.nranks, self.rank = engine, nranks, rank
+        buf = C.create_string_buffer(bytes(id_bytes), 128)
+        h = C.c_void_p()
+        _capi.check(engine.ctx.lib.ort_comm_create(engine.ctx.h, nranks, rank, buf, C.byref(h)))
+        self.h = h
+
+    @staticmethod
+    def unique_id() -> bytes:
+        import ctypes as C
+        from . import _capi
+        buf = C.create_string_buffer(128)
+        _capi.check(_capi.load().ort_comm_unique_id(buf))
+        return buf.raw
+
+    def allgather_hits(self, xf, yf):
+        """xf, yf: CUDA float64 tensors of equal length -> rank-ordered (gx, gy) of nranks*len."""
+        import torch
+        n = xf.numel()
+        gx = torch.empty(self.nranks * n, dtype=torch.float64, device=xf.device)
+        gy = torch.empty_like(gx)
+        self._capi.check(self.engine.ctx.lib.ort_allgather_hits_f64(self.h, xf.data_ptr(), yf.data_ptr(), n,
+                                                                    gx.data_ptr(), gy.data_ptr()))
+        self.engine.ctx.synchronize()
+        return gx, gy
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.engine.ctx.lib.ort_comm_destroy(self.h)
+            self.h = None

@@ -529,3 +529,44 @@ def test_first_order_and_seidel_batch(hip_engine, oracle_engine):
     s = ort.solve(cm.cooke(), cm.COOKE_A, cm.COOKE_H, engine=oracle_engine)
     ab = an.aberrations(cm.cooke(), s, dn=cm.COOKE_DN)
     assert abs(r["W020"] - ab.W020) <= 1e-11 and abs(r["W111"] - ab.W111) <= 1e-11
+
+
+def test_native_rccl_allgather_single_rank():
+    """ort_comm_* / ort_allgather_hits_f64 (librccl loaded lazily): a 1-rank communicator on the one
+    GPU of the test box — the all-gather must reproduce the slabs (multi-rank correctness of the
+    shard order is covered by the gloo test and is RCCL's contract)."""
+    import torch
+    from opticalraytracing_jl_amd import dist as odist
+    eng = ort.default_engine()
+    comm = odist.RcclComm(eng, 1, 0, odist.RcclComm.unique_id())
+    xf = torch.randn(100003, dtype=torch.float64, device="cuda:0")
+    yf = torch.randn(100003, dtype=torch.float64, device="cuda:0")
+    torch.cuda.synchronize()
+    gx, gy = comm.allgather_hits(xf, yf)
+    assert torch.equal(gx, xf) and torch.equal(gy, yf)
+    comm.close()
+
+
+def test_error_codes(hip_engine):
+    """Error behaviour at the boundary: bad arguments -> ORT_EINVAL with a message, |H| > 1 ->
+    ORT_EDOMAIN (the reference's DomainError, src/PupilSampling.jl:88-89); no exceptions cross the ABI."""
+    from opticalraytracing_jl_amd import _capi
+    pres = Prescription.from_matrix(cm.cooke())
+    with pytest.raises(_capi.OrtError) as e:
+        hip_engine.skew(pres, [1.0], [0.0], [0.0], [0.0], isys=3)
+    assert e.value.code == -1 and "out of range" in str(e.value)
+    with pytest.raises(_capi.OrtError) as e:
+        hip_engine.grid(pres, [dict(system=0, stop=99, U=0.0, V=0.0, yaxis_off=0, xaxis_off=4)], np.zeros(8), 4, 4)
+    assert e.value.code == -1
+    with pytest.raises(_capi.OrtError) as e:
+        hip_engine.grid(pres, [dict(system=0, stop=0, U=0.0, V=0.0, yaxis_off=0, xaxis_off=6)], np.zeros(8), 4, 4)
+    assert e.value.code == -1 and "axis" in str(e.value)
+    s = ort.solve(cm.cooke(), cm.COOKE_A, cm.COOKE_H, engine=hip_engine)
+    spec = dict(system=0, stop=s.stop, H=1.5, y_marg=s.marginal.y[0], a_stop=s.a[s.stop - 1],
+                chief_y_end=s.chief.y[-1], chief_u_end=s.chief.u[-1], f=s.f)
+    with pytest.raises(_capi.OrtError) as e:
+        hip_engine.aim(pres, pres, [spec])
+    assert e.value.code == _capi.ORT_EDOMAIN
+    big = np.zeros((70, 3)); big[:, 2] = 1.0
+    with pytest.raises(_capi.OrtError):
+        hip_engine.skew(Prescription.from_matrix(big), [0.0], [0.0], [0.0], [0.0])      # rows > ORT_MAX_ROWS
