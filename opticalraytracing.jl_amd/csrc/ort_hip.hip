@@ -242,6 +242,11 @@ int upload_bundles(ort_ctx* ctx, const ort_system* sys, int nb, const ort_bundle
         d.stop = s.stop - 1;
         d.u = (T)std::tan(s.U);           // PupilSampling.jl:38
         d.v = (T)std::tan(s.V);           // :39
+        {   // k = normalize([v, u, 1])  (:40-41, Q6): sqrt of the sequential sum of squares, times inv(norm)
+            const T nrm = std::sqrt((d.v * d.v + d.u * d.u) + T(1));
+            const T inv = T(1) / nrm;
+            d.k0 = d.v * inv; d.k1 = d.u * inv; d.k2 = inv;
+        }
         d.a_stop = (T)s.a_stop;
         d.hprime = (T)s.hprime;
         d.ybar = (T)s.ybar;
@@ -276,6 +281,7 @@ int trace_grid_impl(ort_ctx* ctx, const ort_system* sys, int nb, const ort_bundl
     if (nb <= 0 || !bundles || !axes || ny <= 0 || nx <= 0 || !out) return fail(ORT_EINVAL, "bad grid arguments");
     const int S = sys->rows - 1;
     const int64_t rpb = (int64_t)ny * nx;
+    if (rpb > 0x7fffffffLL - kTile) return fail(ORT_EINVAL, "bundle of %lld rays is too large (max 2^31)", (long long)rpb);
     const int64_t N = rpb * nb;
     const bool hist = out->xv && out->yv;
     const bool summ = out->xf || out->yf || out->xs || out->ys || out->status;
@@ -592,6 +598,7 @@ int ort_full_trace_f64(ort_ctx* ctx, const ort_system* sys, int nb, const ort_bu
     for (int b = 0; b < nb; ++b)
         if (bundles[b].stop <= 0 || bundles[b].stop > S) return fail(ORT_EINVAL, "bundle %d: full_trace needs a stop index in 1..%d", b, S);
     const int64_t rpb = (int64_t)ny * nx;
+    if (rpb > 0x7fffffffLL - kTile) return fail(ORT_EINVAL, "bundle of %lld rays is too large (max 2^31)", (long long)rpb);
     const int64_t N = rpb * nb;
     const bool devp = flags & ORT_DEVICE_PTRS;
 

@@ -42,6 +42,7 @@ struct DevBundle {
     int32_t system;
     int32_t stop;       // 0-based loop index captured as the stop hit, -1 = none
     T u, v;             // slopes tan U, tan V (host libm)
+    T k0, k1, k2;       // normalize([v, u, 1]) — the same for every ray of the bundle (:40-41), done once on the host
     T a_stop, hprime;
     T ybar, z0;
     int64_t yoff, xoff;
@@ -148,9 +149,11 @@ __global__ __launch_bounds__(kBlock, ORT_MIN_WAVES) void k_trace(TraceParams<T> 
     int64_t j0;          // first ray of this thread inside its bundle / list
     int64_t gbase;       // global index of ray j0
     int64_t limit;       // rays in this bundle / list
+    unsigned tile_base = 0;   // first ray of this workgroup's tile inside its bundle (wave-uniform)
     if (GRID) {
         b = blockIdx.x / p.tiles_per_bundle;
         const int tile = blockIdx.x - b * p.tiles_per_bundle;
+        tile_base = (unsigned)tile * (unsigned)kTile;
         sysid = p.bundles[b].system;
         j0 = (int64_t)tile * kTile + (int64_t)tid * kRPT;
         limit = p.rpb;
@@ -190,17 +193,30 @@ __global__ __launch_bounds__(kBlock, ORT_MIN_WAVES) void k_trace(TraceParams<T> 
         T y, x, u, v;
         if (GRID) {
             const DevBundle<T>& bd = p.bundles[b];
-            const int iy = (int)(jj / p.nx);
-            const int ix = (int)(jj - (int64_t)iy * p.nx);
+            // (iy, ix) of ray jj without a per-lane 64-bit division: the tile's first ray is
+            // divided once in scalar registers, lanes walk forward from there.
+            unsigned iy, ix;
+            if (live[r] && p.nx >= 64) {
+                const unsigned iy0 = tile_base / (unsigned)p.nx;         // wave-uniform: scalar division
+                ix = (tile_base - iy0 * (unsigned)p.nx) + (unsigned)(tid * kRPT + r);
+                iy = iy0;
+                while (ix >= (unsigned)p.nx) { ix -= (unsigned)p.nx; ++iy; }
+            } else {
+                iy = (unsigned)((uint32_t)jj / (uint32_t)p.nx);
+                ix = (unsigned)jj - iy * (unsigned)p.nx;
+            }
             y = p.axes[bd.yoff + iy];
             x = p.axes[bd.xoff + ix];
+            stopi = bd.stop; hprime = bd.hprime; a_stop = bd.a_stop;
             if (p.raybasis) {                        // PupilSampling.jl:124-127 (Q8)
                 u = dev_tan((bd.ybar - y) / bd.z0);
                 v = dev_tan(-x / bd.z0);
-            } else {
-                u = bd.u; v = bd.v;
+            } else {                                 // shared field angles: direction cosines are bundle-uniform
+                ray[r].y = y; ray[r].x = x; ray[r].u = bd.u; ray[r].v = bd.v; ray[r].sprev = T(0);
+                ray[r].k0 = bd.k0; ray[r].k1 = bd.k1; ray[r].k2 = bd.k2;
+                st[r] = S + 1; xs_[r] = T(0); ys_[r] = T(0);
+                continue;
             }
-            stopi = bd.stop; hprime = bd.hprime; a_stop = bd.a_stop;
         } else {
             y = p.ly[jj]; x = p.lx[jj];
             u = p.lU[jj]; v = p.lV[jj];

@@ -1,0 +1,38 @@
+"""GPU box: per-ray fixed cost vs per-surface cost of the trace kernel (truncated Double-Gauss, S = 1..12)."""
+import ctypes as C, math, sys, numpy as np, torch
+sys.path.insert(0, "/root/repo")
+import opticalraytracing_jl_amd as ort
+from opticalraytracing_jl_amd import _capi, api, workloads, Prescription
+eng = ort.default_engine()
+dev = torch.device("cuda:0")
+k = 1024
+full = workloads.double_gauss(0)
+ext = np.vstack([full, [math.inf, 0.0, 1.0]]); ext[-2, 1] = 57.8
+for policy in ("fast", "ieee"):
+    res = []
+    for S in (1, 2, 4, 6, 8, 10, 12):
+        M = ext[:S + 1]
+        pres = Prescription.from_matrix(M)
+        ax = api.linrange(-14.0, 14.0, k)
+        axes = np.concatenate([ax, ax])
+        nb = 9
+        bundles = [dict(system=0, stop=0, U=0.05 * (b % 3), V=0.0, yaxis_off=0, xaxis_off=k) for b in range(nb)]
+        N = nb * k * k
+        xv = torch.empty((S, N), dtype=torch.float64, device=dev); yv = torch.empty_like(xv)
+        out = _capi.ort_grid_out_f64(); out.xv, out.yv, out.ld = xv.data_ptr(), yv.data_ptr(), N
+        d_axes = torch.from_numpy(axes).to(dev)
+        sysd = eng.system(pres); barr = _capi.make_bundles(bundles)
+        fl = _capi.ORT_DEVICE_PTRS | (_capi.ORT_FAST_MATH if policy == "fast" else 0)
+        def step():
+            _capi.check(eng.ctx.lib.ort_trace_grid_f64(eng.ctx.h, sysd.h, nb, barr, d_axes.data_ptr(), axes.size, k, k, C.byref(out), fl))
+        for _ in range(3): step()
+        torch.cuda.synchronize()
+        eng.ctx.timer_start()
+        for _ in range(20): step()
+        ms = eng.ctx.timer_stop() / 20
+        res.append((S, ms))
+        del xv, yv
+    print(policy, " ".join(f"S={s}:{m:.4f}ms" for s, m in res))
+    (s1, m1), (s2, m2) = res[0], res[-1]
+    slope = (m2 - m1) / (s2 - s1)
+    print(f"   per-surface {slope:.4f} ms, intercept {m1 - slope * s1:.4f} ms  (store floor per surface {9*k*k*16/6.07e12*1e3:.4f} ms)")
