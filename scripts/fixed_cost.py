@@ -36,3 +36,42 @@ for policy in ("fast", "ieee"):
     (s1, m1), (s2, m2) = res[0], res[-1]
     slope = (m2 - m1) / (s2 - s1)
     print(f"   per-surface {slope:.4f} ms, intercept {m1 - slope * s1:.4f} ms  (store floor per surface {9*k*k*16/6.07e12*1e3:.4f} ms)")
+
+# the bench's own bundles (3 systems x 3 fields, pupil box from the paraxial solve) through the same harness
+pres, bundles, axes = workloads.config2(api, k, engine=eng)
+nb = len(bundles); N = nb * k * k; S = pres.rows - 1
+xv = torch.empty((S, N), dtype=torch.float64, device=dev); yv = torch.empty_like(xv)
+out = _capi.ort_grid_out_f64(); out.xv, out.yv, out.ld = xv.data_ptr(), yv.data_ptr(), N
+d_axes = torch.from_numpy(axes).to(dev); sysd = eng.system(pres); barr = _capi.make_bundles(bundles)
+for variant, bl in (("config2 as is", bundles), ("config2, fields forced to U=0", [dict(b, U=0.0) for b in bundles])):
+    barr = _capi.make_bundles(bl)
+    fl = _capi.ORT_DEVICE_PTRS | _capi.ORT_FAST_MATH
+    def step():
+        _capi.check(eng.ctx.lib.ort_trace_grid_f64(eng.ctx.h, sysd.h, nb, barr, d_axes.data_ptr(), axes.size, k, k, C.byref(out), fl))
+    for _ in range(3): step()
+    torch.cuda.synchronize(); eng.ctx.timer_start()
+    for _ in range(30): step()
+    ms = eng.ctx.timer_stop() / 30
+    nanfrac = float(torch.isnan(xv[-1]).float().mean())
+    print(f"{variant}: {ms:.4f} ms, NaN fraction at the image row {nanfrac:.4f}")
+
+# cross test: which ingredient of config2 costs the extra time?
+import copy
+ax14 = api.linrange(-14.0, 14.0, k)
+def run(tag, pres_, bl, axes_):
+    d_ax = torch.from_numpy(np.ascontiguousarray(axes_)).to(dev); sd = eng.system(pres_); ba = _capi.make_bundles(bl)
+    def step():
+        _capi.check(eng.ctx.lib.ort_trace_grid_f64(eng.ctx.h, sd.h, len(bl), ba, d_ax.data_ptr(), axes_.size, k, k, C.byref(out), _capi.ORT_DEVICE_PTRS | _capi.ORT_FAST_MATH))
+    for _ in range(3): step()
+    torch.cuda.synchronize(); eng.ctx.timer_start()
+    for _ in range(30): step()
+    print(f"{tag}: {eng.ctx.timer_stop() / 30:.4f} ms")
+axes14 = np.concatenate([ax14, ax14])
+b14 = [dict(b, yaxis_off=0, xaxis_off=k) for b in bundles]
+run("config2 systems+fields, +-14 axes", pres, b14, axes14)
+one = Prescription(pres.R[0], pres.t[0], pres.n[0])
+run("config2 axes+fields, system 0 only", one, [dict(b, system=0) for b in bundles], axes)
+run("config2 axes, system 0, U=0.05*(b%3)", one, [dict(b, system=0, U=0.05 * (i % 3)) for i, b in enumerate(bundles)], axes)
+ax167 = api.linrange(-16.7, 16.7, k)
+run("system 0, +-16.7 axes, U=0.05*(b%3)", one, [dict(system=0, stop=0, U=0.05 * (i % 3), V=0.0, yaxis_off=0, xaxis_off=k) for i in range(9)], np.concatenate([ax167, ax167]))
+run("system 0, +-14 axes, U=0.05*(b%3)", one, [dict(system=0, stop=0, U=0.05 * (i % 3), V=0.0, yaxis_off=0, xaxis_off=k) for i in range(9)], axes14)
