@@ -166,6 +166,54 @@ __device__ __forceinline__ void ray_init(Ray<T>& r, T y, T x, T u, T v)
     }
 }
 
+// ---- correctly rounded FP64 division and square root for MATH_IEEE --------------------------
+// hipcc expands `a / b` to  div_scale x2, rcp, two Newton steps on the reciprocal, q0 = a r,
+// rem = fma(-b, q0, a), div_fmas(rem, r, q0), div_fixup  and `sqrt(x)` to a range-scaling
+// ldexp pair around  rsq + one Goldschmidt step + two residual corrections.  The scaling only acts
+// for |exponents| beyond 2^±767 / quotients near the range limits, never reached by lens
+// geometry in millimetres, so the same sequences without it give the SAME bits; div_fixup and
+// the class test keep 0, inf and NaN operands exact.  What this buys: the two quotients that share a
+// denominator (tilt: sgn x / sqrt(D), sgn y / sqrt(D); slopes: k1 / k3, k0 / k3) share ONE
+// refined reciprocal.  Bit-identity with the CPU oracle is asserted by tests/test_gpu_parity.py.
+__device__ __forceinline__ double ieee_rcp_refined(double b)
+{
+    double r = __builtin_amdgcn_rcp(b);
+    double e = __builtin_fma(-b, r, 1.0);
+    r = __builtin_fma(r, e, r);
+    e = __builtin_fma(-b, r, 1.0);
+    return __builtin_fma(r, e, r);
+}
+__device__ __forceinline__ double ieee_div_with(double a, double b, double r)
+{
+    const double q0 = a * r;
+    const double rem = __builtin_fma(-b, q0, a);
+    return __builtin_amdgcn_div_fixup(__builtin_fma(rem, r, q0), b, a);
+}
+__device__ __forceinline__ void ieee_div2(double a1, double a2, double b, double& q1, double& q2)
+{
+    const double r = ieee_rcp_refined(b);
+    q1 = ieee_div_with(a1, b, r);
+    q2 = ieee_div_with(a2, b, r);
+}
+__device__ __forceinline__ void ieee_div2(float a1, float a2, float b, float& q1, float& q2) { q1 = a1 / b; q2 = a2 / b; }
+__device__ __forceinline__ double ieee_div(double a, double b) { return ieee_div_with(a, b, ieee_rcp_refined(b)); }
+__device__ __forceinline__ float ieee_div(float a, float b) { return a / b; }
+__device__ __forceinline__ double ieee_sqrt(double x)
+{
+    const double y = __builtin_amdgcn_rsq(x);
+    double g = x * y;
+    double h = y * 0.5;
+    const double r = __builtin_fma(-h, g, 0.5);
+    g = __builtin_fma(g, r, g);
+    h = __builtin_fma(h, r, h);
+    double d = __builtin_fma(-g, g, x);
+    g = __builtin_fma(d, h, g);
+    d = __builtin_fma(-g, g, x);
+    g = __builtin_fma(d, h, g);
+    return __builtin_amdgcn_class(x, 0x260) ? x : g;          // +-0 and +inf return x; x < 0 -> NaN through rsq
+}
+__device__ __forceinline__ float ieee_sqrt(float x) { return __builtin_sqrtf(x); }
+
 // One loop iteration of src/PupilSampling.jl:45-63 in the reference's operation order.
 // FINITE = isfinite(R) (:2), HASP = the row carries polynomial coefficients: both are
 // wave-uniform, so the kernel branches on them ONCE per surface and runs this straight-line
@@ -182,7 +230,7 @@ __device__ __forceinline__ void surface_step_ieee(Ray<T>& r, const SurfRec<T>& s
         const T beta = (s.R - r.y * r.u) - r.x * r.v;            // :3
         const T r2 = r.x * r.x + r.y * r.y;                      // :4
         const T D = beta * beta - r2 * ((s.opk + r.u * r.u) + r.v * r.v);   // :5
-        sg = r2 / (beta + s.sgn * t_sqrt<T>(D));                 // :7
+        sg = ieee_div(r2, beta + s.sgn * ieee_sqrt(D));          // :7
         if (HASP) sg = sg + poly_eval<T>(coef, s.ncoef, r.y);
         else      sg = sg + T(0);
         sg = (D >= T(0)) ? sg : t_nan<T>();                      // :6,9
@@ -194,9 +242,9 @@ __device__ __forceinline__ void surface_step_ieee(Ray<T>& r, const SurfRec<T>& s
     r.sprev = sg;
     // tilt (:16-19), normal (:56-57)
     const T Dt = s.R2 - (r.x * r.x + r.y * r.y) * s.opk;
-    const T sq = t_sqrt<T>(Dt);
-    T tx = s.sgn * r.x / sq;
-    T ty = s.sgn * r.y / sq;
+    const T sq = ieee_sqrt(Dt);
+    T tx, ty;
+    ieee_div2(s.sgn * r.x, s.sgn * r.y, sq, tx, ty);             // one refined reciprocal, two quotients
     if (HASP) {
         tx = tx + poly_deriv<T>(coef, s.ncoef, r.x);             // Q2: p'(x) on the x slope
         ty = ty + poly_deriv<T>(coef, s.ncoef, r.y);
@@ -204,13 +252,13 @@ __device__ __forceinline__ void surface_step_ieee(Ray<T>& r, const SurfRec<T>& s
         tx = tx + T(0);
         ty = ty + T(0);
     }
-    const T nrm = t_sqrt<T>((tx * tx + ty * ty) + T(1));
-    const T inv = T(1) / nrm;
+    const T nrm = ieee_sqrt((tx * tx + ty * ty) + T(1));
+    const T inv = ieee_div(T(1), nrm);
     const T m0 = tx * inv, m1 = ty * inv, m2 = -inv;
     // refract! (:21-32)
     const T g = -((r.k0 * m0 + r.k1 * m1) + r.k2 * m2);
     const T D2 = T(1) - s.eta2 * (T(1) - g * g);
-    const T cf = s.eta * g - t_sqrt<T>(D2);
+    const T cf = s.eta * g - ieee_sqrt(D2);
     const bool ok = D2 >= T(0);                      // TIR / NaN: k untouched (Q1)
     const T n0 = s.eta * r.k0 + cf * m0;
     const T n1 = s.eta * r.k1 + cf * m1;
@@ -218,8 +266,7 @@ __device__ __forceinline__ void surface_step_ieee(Ray<T>& r, const SurfRec<T>& s
     r.k0 = ok ? n0 : r.k0;
     r.k1 = ok ? n1 : r.k1;
     r.k2 = ok ? n2 : r.k2;
-    r.u = r.k1 / r.k2;                               // :59
-    r.v = r.k0 / r.k2;                               // :60
+    ieee_div2(r.k1, r.k0, r.k2, r.u, r.v);           // :59-60
 }
 
 // MATH_FAST, row with a polynomial term: the reference's slope form (sag :1-14, tilt :16-19)
