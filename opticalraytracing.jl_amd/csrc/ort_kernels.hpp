@@ -214,7 +214,7 @@ __global__ __launch_bounds__(kBlock, ORT_MIN_WAVES) void k_trace(TraceParams<T> 
             } else {                                 // shared field angles: direction cosines are bundle-uniform
                 ray[r].y = y; ray[r].x = x; ray[r].u = bd.u; ray[r].v = bd.v; ray[r].sprev = T(0);
                 ray[r].k0 = bd.k0; ray[r].k1 = bd.k1; ray[r].k2 = bd.k2;
-                st[r] = S + 1; xs_[r] = T(0); ys_[r] = T(0);
+                st[r] = 1; xs_[r] = T(0); ys_[r] = T(0);
                 continue;
             }
         } else {
@@ -223,7 +223,7 @@ __global__ __launch_bounds__(kBlock, ORT_MIN_WAVES) void k_trace(TraceParams<T> 
             if (!p.slopes_given) { u = dev_tan(u); v = dev_tan(v); }   // :38-39
         }
         ray_init<T, MATH>(ray[r], y, x, u, v);
-        st[r] = S + 1;
+        st[r] = 1;
         xs_[r] = T(0); ys_[r] = T(0);
     }
     const bool two = (kRPT > 1) && live[kRPT - 1];
@@ -258,7 +258,9 @@ __global__ __launch_bounds__(kBlock, ORT_MIN_WAVES) void k_trace(TraceParams<T> 
         if (SUMM || FT) {
 #pragma unroll
             for (int r = 0; r < kRPT; ++r) {
-                if (st[r] == S + 1 && (t_isnan(ray[r].x) || t_isnan(ray[r].y))) st[r] = i + 1;
+                // NaN is sticky (every later transfer propagates it), so the 1-based index of the first
+                // NaN surface is 1 + the number of surfaces with ordered (x, y): one v_cmp_o + one add.
+                st[r] += __builtin_isunordered(ray[r].x, ray[r].y) ? 0 : 1;
                 if (i == stopi) { xs_[r] = ray[r].x; ys_[r] = ray[r].y; }
             }
         }
