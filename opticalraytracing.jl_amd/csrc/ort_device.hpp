@@ -280,17 +280,20 @@ __device__ __forceinline__ void surface_step_fast_poly(Ray<T>& r, const SurfRec<
     const T tcur = s.t - r.sprev;
     r.y = t_fma<T>(u, tcur, r.y);
     r.x = t_fma<T>(v, tcur, r.x);
-    const T beta = t_fma<T>(-r.x, v, t_fma<T>(-r.y, u, s.R));
-    const T r2 = t_fma<T>(r.x, r.x, r.y * r.y);
-    const T A = t_fma<T>(v, v, t_fma<T>(u, u, s.opk));
-    const T D = t_fma<T>(beta, beta, -(r2 * A));
-    T sg = r2 * fast_rcp(beta + s.sgn * fast_sqrt<T>(D)) + poly_eval<T>(coef, s.ncoef, r.y);
-    sg = (D >= T(0)) ? sg : t_nan<T>();
-    r.y = t_fma<T>(sg, u, r.y);
-    r.x = t_fma<T>(sg, v, r.x);
+    T sg = T(0), is = T(0);
+    if (s.finite) {                                  // wave-uniform (:2)
+        const T beta = t_fma<T>(-r.x, v, t_fma<T>(-r.y, u, s.R));
+        const T r2 = t_fma<T>(r.x, r.x, r.y * r.y);
+        const T A = t_fma<T>(v, v, t_fma<T>(u, u, s.opk));
+        const T D = t_fma<T>(beta, beta, -(r2 * A));
+        sg = r2 * fast_rcp(beta + s.sgn * fast_sqrt<T>(D)) + poly_eval<T>(coef, s.ncoef, r.y);
+        sg = (D >= T(0)) ? sg : t_nan<T>();
+        r.y = t_fma<T>(sg, u, r.y);
+        r.x = t_fma<T>(sg, v, r.x);
+        const T rr = t_fma<T>(r.x, r.x, r.y * r.y);
+        is = s.sgn * fast_rsqrt(t_fma<T>(-rr, s.opk, s.R2));
+    }                                                // flat row: sag = 0 without p(y) (:12), tilt = p' only (:18)
     r.sprev = sg;
-    const T rr = t_fma<T>(r.x, r.x, r.y * r.y);
-    const T is = s.sgn * fast_rsqrt(t_fma<T>(-rr, s.opk, s.R2));
     const T tx = t_fma<T>(r.x, is, poly_deriv<T>(coef, s.ncoef, r.x));   // Q2
     const T ty = t_fma<T>(r.y, is, poly_deriv<T>(coef, s.ncoef, r.y));
     const T inv = fast_rsqrt(t_fma<T>(tx, tx, t_fma<T>(ty, ty, T(1))));

@@ -575,3 +575,79 @@ def test_error_codes(hip_engine):
     big = np.zeros((70, 3)); big[:, 2] = 1.0
     with pytest.raises(_capi.OrtError):
         hip_engine.skew(Prescription.from_matrix(big), [0.0], [0.0], [0.0], [0.0])      # rows > ORT_MAX_ROWS
+
+
+def _random_system(rng, rows, aspheric):
+    R = rng.uniform(20.0, 500.0, rows) * rng.choice([-1.0, 1.0], rows)
+    R[rng.random(rows) < 0.2] = math.inf
+    R[0] = math.inf
+    t = rng.uniform(0.5, 12.0, rows); t[0] = rng.uniform(0.0, 5.0); t[-1] = 0.0
+    n = np.ones(rows)
+    glass = False
+    for i in range(1, rows):
+        glass = not glass if rng.random() < 0.7 else glass
+        n[i] = rng.uniform(1.45, 1.9) if glass else 1.0
+    K = np.zeros(rows); coef = np.zeros((rows, 7))
+    if aspheric:
+        for i in range(1, rows):
+            if math.isfinite(R[i]) and rng.random() < 0.4:
+                K[i] = rng.uniform(-1.5, 0.5)
+            if rng.random() < 0.25:
+                coef[i, 4] = rng.uniform(-2e-7, 2e-7); coef[i, 6] = rng.uniform(-5e-10, 5e-10)
+    return R, t, n, K, coef
+
+
+def test_random_systems_property(hip_engine, oracle_engine):
+    """120 random prescriptions (2-14 rows; flat rows, both curvature signs, conics, polynomial
+    terms, glass/air sequences that TIR and miss) x 1500 random skew rays each: the IEEE policy is
+    BIT-IDENTICAL to the oracle on every ray incl. NaN patterns and status; the fast policy agrees
+    to 1e-9 on all but a <=0.2 % fringe of rays sitting on a TIR / miss branch boundary."""
+    rng = np.random.default_rng(2024)
+    fast = ort.HipEngine(0, fast_math=True)
+    nfring = ntot = 0
+    for case in range(120):
+        rows = int(rng.integers(2, 15))
+        aspheric = case % 3 == 0
+        R, t, n, K, coef = _random_system(rng, rows, aspheric)
+        pres = Prescription(R, t, n, K if aspheric else None, coef[None] if aspheric else None)
+        m = 1500
+        y = rng.uniform(-6, 6, m); x = rng.uniform(-6, 6, m)
+        u = np.tan(rng.uniform(-0.1, 0.1, m)); v = np.tan(rng.uniform(-0.1, 0.1, m))
+        ox, oy, os_ = oracle_engine.skew(pres, y, x, u, v, slopes=True, want_status=True)
+        gx, gy, gs = hip_engine.skew(pres, y, x, u, v, slopes=True, want_status=True)
+        assert np.array_equal(gs, os_), case
+        if aspheric:      # analytic vs complex-step p'
+            assert cm.rel_err(gx, ox, 1.0).max() <= 1e-11 and cm.rel_err(gy, oy, 1.0).max() <= 1e-11, case
+        else:
+            assert np.array_equal(gx, ox, equal_nan=True) and np.array_equal(gy, oy, equal_nan=True), case
+        fx, fy, fs = fast.skew(pres, y, x, u, v, slopes=True, want_status=True)
+        sane = (os_ == rows) & (np.nanmax(np.abs(ox), axis=0) < 1e3) & (np.nanmax(np.abs(oy), axis=0) < 1e3)
+        err = np.maximum(cm.rel_err(fx, ox, 1.0).max(axis=0), cm.rel_err(fy, oy, 1.0).max(axis=0))
+        bad = (fs != os_) | (sane & (err > 1e-9))
+        nfring += int(bad.sum()); ntot += m
+    assert nfring <= 0.002 * ntot, (nfring, ntot)
+
+
+def test_random_systems_meridional_and_paraxial(hip_engine, oracle_engine):
+    """Random prescriptions through the meridional (plain-matrix and Layout{Aspheric} dispatch, Q16)
+    and paraxial (+clip) kernels: NaN patterns identical, values within 1e-10 (device trig)."""
+    rng = np.random.default_rng(77)
+    for case in range(40):
+        rows = int(rng.integers(2, 13))
+        aspheric = case % 2 == 0
+        R, t, n, K, coef = _random_system(rng, rows, aspheric)
+        pres = Prescription(R, t, n, K if aspheric else None, coef[None] if aspheric else None)
+        y = rng.uniform(-6, 6, 300); U = rng.uniform(-0.12, 0.12, 300)
+        g = hip_engine.meridional(pres, y, U, layout_mode=aspheric)
+        o = oracle_engine.meridional(pres, y, U, layout_mode=aspheric)
+        for a, b in zip(g, o):
+            assert np.array_equal(np.isnan(a), np.isnan(b)), case
+            assert cm.rel_err(a, b, 1.0).max() <= TOL, case
+        M = np.column_stack([R, t.copy(), n])
+        L = ort.Lens(M)
+        a_ap = rng.uniform(2.0, 9.0, L.M.shape[0])
+        for clip in (False, True):
+            gp = hip_engine.paraxial(L.M[:, 0], L.M[:, 1], y, U, a_ap, clip)
+            op = oracle_engine.paraxial(L.M[:, 0], L.M[:, 1], y, U, a_ap, clip)
+            assert np.array_equal(gp[0], op[0], equal_nan=True) and np.array_equal(gp[1], op[1], equal_nan=True), case
+        assert np.array_equal(hip_engine.abcd(L.M[:, 0], L.M[:, 1]), oracle_engine.abcd(L.M[:, 0], L.M[:, 1]))
