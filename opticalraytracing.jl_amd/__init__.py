@@ -18,7 +18,7 @@ from .api import (  # noqa: F401
     Aiming, Aspheric, Chief, DomainError, Layout, Lens, Marginal, ParaxialRay, Pupil, RayBasis,
     RealRay, RealRayError, RealRayT, Sagittal, Skew, Spherical, System, Tangential, TransferMatrix,
     VectorRealRay, compute_surfaces, extended_prescription, flatten, full_trace, full_trace_aim,
-    full_trace_aim_batch, full_trace_batch, full_trace_grid, reversed_layout, incidences, linrange, raytrace, reverse_transfer, sag, solve, surface_ray,
+    full_trace_aim_batch, full_trace_batch, full_trace_grid, reversed_layout, incidences, linrange, linrange_batch, raytrace, reverse_transfer, sag, solve, surface_ray,
     surface_to_focus, trace_chief_ray, trace_marginal_ray, transfer, transfer_real, wavegrad,
 )
 from .analysis import SA, TSA, Aberration, RayError, Vignetting, aberrations, vignetting  # noqa: F401

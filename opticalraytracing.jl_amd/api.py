@@ -54,15 +54,58 @@ def _eng(engine):
 # a + i (b - a)/(n - 1) with exact end points; exact rational arithmetic restates that.
 # Not pinned at the last ulp by any reference test ("parity unpinned").
 # ---------------------------------------------------------------------------------------
-def linrange(a: float, b: float, n: int) -> np.ndarray:
-    a = float(a); b = float(b)
+def _two_sum(a, b):
+    s = a + b
+    bb = s - a
+    return s, (a - (s - bb)) + (b - bb)
+
+
+def _split(a):
+    c = 134217729.0 * a                      # 2^27 + 1 (Dekker)
+    hi = c - (c - a)
+    return hi, a - hi
+
+
+def _two_prod(a, b):
+    p = a * b
+    ah, al = _split(a)
+    bh, bl = _split(b)
+    return p, ((ah * bh - p) + ah * bl + al * bh) + al * bl
+
+
+def linrange_batch(a, b, n: int) -> np.ndarray:
+    """Row r = range(a[r], b[r], n): x_i = (a (m - i) + b i) / m with m = n - 1.  The numerator is
+    exact in double-double (integer weights), the quotient is carried to ~106 bits (what Julia's
+    TwicePrecision range carries) and is EXACT whenever the true value is a short binary fraction,
+    so ties (i/m dyadic, e.g. 81/108) round half-to-even like exact arithmetic; end points exact."""
+    a = np.atleast_1d(np.asarray(a, dtype=np.float64))[:, None]
+    b = np.atleast_1d(np.asarray(b, dtype=np.float64))[:, None]
     if n == 1:
-        return np.array([a])
-    fa, fb = Fraction(a), Fraction(b)
-    step = (fb - fa) / (n - 1)
-    out = np.array([float(fa + i * step) for i in range(n)], dtype=np.float64)
-    out[0], out[-1] = a, b
+        return a.copy()
+    m = float(n - 1)
+    i = np.arange(n, dtype=np.float64)[None, :]
+    A = np.broadcast_to(a, (a.shape[0], n)); B = np.broadcast_to(b, (b.shape[0], n))
+    p1h, p1l = _two_prod(A, m - i)
+    p2h, p2l = _two_prod(B, i)
+    sh, se = _two_sum(p1h, p2h)
+    se = se + (p1l + p2l)
+    nh, nl = _two_sum(sh, se)
+    q1 = nh / m
+    ph, pl = _two_prod(q1, np.full_like(q1, m))
+    q2 = (((nh - ph) - pl) + nl) / m
+    out = q1 + q2
+    out[:, 0], out[:, -1] = a[:, 0], b[:, 0]
     return out
+
+
+def linrange(a: float, b: float, n: int) -> np.ndarray:
+    """Julia `range(a, b, n)` (see linrange_batch)."""
+    a = float(a); b = float(b)
+    if not (math.isfinite(a) and math.isfinite(b)) or abs(a) > 1e150 or abs(b) > 1e150:
+        fa, fb = Fraction(a), Fraction(b)     # exact rational fallback for extreme magnitudes
+        st = (fb - fa) / max(n - 1, 1)
+        return np.array([float(fa + i * st) for i in range(n)], dtype=np.float64)
+    return linrange_batch([a], [b], n)[0]
 
 
 # ---------------------------------------------------------------------------------------
@@ -702,8 +745,13 @@ def full_trace(*args, engine=None) -> RealRayError:
             H, rest = args[2], args[3:]
         k_rays = rest[0] if len(rest) > 0 else SPOT_RAYS
         focus = rest[1] if len(rest) > 1 else None
-    aim = full_trace_aim(surfaces, system, H, focus, engine=engine)
-    return full_trace_grid(surfaces, aim, int(k_rays), engine=engine)
+    eng = _eng(engine)
+    if hasattr(eng, "aim") and isinstance(system, System) and system.layout is surfaces:
+        # one aiming launch (ort_aim_f64) + one full_trace launch sequence instead of ~30 host-driven
+        # Newton launches: what makes a single reference-sized call (64 x 32 rays) latency-cheap
+        return full_trace_batch([system], [H], int(k_rays), focus, engine=eng)[0][0]
+    aim = full_trace_aim(surfaces, system, H, focus, engine=eng)
+    return full_trace_grid(surfaces, aim, int(k_rays), engine=eng)
 
 
 def _stack_prescriptions(press: Sequence[Prescription]) -> Prescription:
@@ -761,15 +809,18 @@ def full_trace_batch(systems: Sequence[System], fields: Sequence[float], k_rays:
     eng = _eng(engine)
     aims = full_trace_aim_batch(systems, fields, focus, engine=eng)
     k2 = k_rays // 2
-    press, bundles, axes, off = [], [], [], 0
+    press, bundles, off = [], [], 0
+    flat = [a for row in aims for a in row]
+    yax = linrange_batch([a.y1 for a in flat], [a.y2 for a in flat], k_rays)      # all bundles at once
+    xax = linrange_batch(np.zeros(len(flat)), [a.y_EP for a in flat], k2)
+    axes = np.concatenate([yax, xax], axis=1).ravel()                             # [bundle][y axis | x axis]
     for si, s in enumerate(systems):
         press.append(extended_prescription(s.layout, aims[si][0].focus))
         for a in aims[si]:
-            axes += [linrange(a.y1, a.y2, k_rays), linrange(0.0, a.y_EP, k2)]
             bundles.append(dict(system=si, stop=a.stop, U=a.U, V=0.0, a_stop=a.a_stop, hprime=a.hprime,
                                 yaxis_off=off, xaxis_off=off + k_rays))
             off += k_rays + k2
-    res = eng.full_trace_grid(_stack_prescriptions(press), bundles, np.concatenate(axes), k_rays, k2)
+    res = eng.full_trace_grid(_stack_prescriptions(press), bundles, axes, k_rays, k2)
     out, i = [], 0
     for si, s in enumerate(systems):
         row = []

@@ -651,3 +651,46 @@ def test_random_systems_meridional_and_paraxial(hip_engine, oracle_engine):
             op = oracle_engine.paraxial(L.M[:, 0], L.M[:, 1], y, U, a_ap, clip)
             assert np.array_equal(gp[0], op[0], equal_nan=True) and np.array_equal(gp[1], op[1], equal_nan=True), case
         assert np.array_equal(hip_engine.abcd(L.M[:, 0], L.M[:, 1]), oracle_engine.abcd(L.M[:, 0], L.M[:, 1]))
+
+
+def test_random_bundles_grid_and_full_trace(hip_engine, oracle_engine):
+    """Random multi-system batches, ragged grid shapes (odd nx, nx < 64, rays per bundle not a
+    multiple of the tile), random stop rows and stop radii: grid summary/history and the
+    full_trace pipeline (filter, ordered compaction, mirror, sigma) against the oracle."""
+    rng = np.random.default_rng(99)
+    for case in range(25):
+        rows = int(rng.integers(4, 12))
+        nsys = int(rng.integers(1, 5))
+        Rs, ts, ns = [], [], []
+        for _ in range(nsys):
+            R, t, n, _, _ = _random_system(rng, rows, False)
+            R[-1] = math.inf; t[-2] = rng.uniform(5.0, 30.0)          # image plane row
+            Rs.append(R); ts.append(t); ns.append(n)
+        pres = Prescription(np.array(Rs), np.array(ts), np.array(ns))
+        ny, nx = int(rng.integers(3, 70)), int(rng.integers(3, 90))
+        nb = int(rng.integers(1, 6))
+        axes, bundles, off = [], [], 0
+        for b in range(nb):
+            a = rng.uniform(3.0, 7.0)
+            axes += [ort.linrange(a, -a, ny), ort.linrange(0.0, a, nx)]
+            stop = int(rng.integers(1, rows - 1))
+            bundles.append(dict(system=int(rng.integers(0, nsys)), stop=stop, U=float(rng.uniform(-0.1, 0.1)), V=0.0,
+                                a_stop=float(rng.uniform(2.0, 8.0)), hprime=float(rng.uniform(-3, 3)),
+                                yaxis_off=off, xaxis_off=off + ny))
+            off += ny + nx
+        axes = np.concatenate(axes)
+        g = hip_engine.grid(pres, bundles, axes, ny, nx)
+        o = oracle_engine.grid(pres, bundles, axes, ny, nx)
+        for key in ("xv", "yv", "xf", "yf", "xs", "ys"):
+            assert np.array_equal(g[key], o[key], equal_nan=True), (case, key)
+        assert np.array_equal(g["status"], o["status"]), case
+        gf = hip_engine.full_trace_grid(pres, bundles, axes, ny, nx)
+        of = oracle_engine.full_trace_grid(pres, bundles, axes, ny, nx)
+        for a, b in zip(gf, of):
+            assert a["count"] == b["count"], case
+            if b["count"]:
+                assert np.array_equal(a["ex"], b["ex"]) and np.array_equal(a["ey"], b["ey"]), case
+                assert cm.rel_err(a["rho"], b["rho"], 1e-3).max() <= TOL and cm.rel_err(a["theta"], b["theta"], 1e-3).max() <= TOL
+                assert abs(a["rms"] - b["rms"]) <= TOL * max(b["rms"], 1e-6), case
+            else:
+                assert math.isnan(a["rms"])
