@@ -129,6 +129,13 @@ def load() -> C.CDLL:
     global _lib
     if _lib is not None:
         return _lib
+    if not os.path.exists(LIB_PATH) and not os.environ.get("ORT_HIP_LIB"):
+        # a source-only checkout: compile the extension in-tree (hipcc cross-compiles gfx950 in seconds)
+        try:
+            from . import build as _build
+            _build.build(verbose=False)
+        except Exception as exc:  # fall through to the loud failure below
+            sys.stderr.write(f"[ort] in-tree build of the HIP extension failed: {exc}\n")
     if not os.path.exists(LIB_PATH):
         raise ImportError(
             f"{LIB_PATH} is missing: the HIP extension is not built. Run "
