@@ -150,7 +150,9 @@ int ort_trace_grid_f32(ort_ctx *ctx, const ort_system *sys, int nb, const ort_bu
  * one RealRayError (Types.jl:184-192) per bundle.  Aiming scalars (y1, y2, y_EP through
  * the axes; U, h', stop, a_stop through the bundle) are inputs.
  * ex, ey, rho, theta : [nb][2*ny*nx] (bundle b starts at b*2*ny*nx; count[b] entries valid)
- * count : [nb] = 2*survivors;  rms : [nb];  traced : [nb] rays traced (may be NULL)      */
+ * count : [nb] = 2*survivors;  rms : [nb].
+ * ex = ey = rho = theta = NULL: spot statistics only (count, rms) — nothing but 16 B per bundle
+ * leaves the device (the all-reduce-of-moments alternative to gathering hits).      */
 int ort_full_trace_f64(ort_ctx *ctx, const ort_system *sys, int nb, const ort_bundle *bundles,
                        const double *axes, int64_t axes_len, int ny, int nx,
                        double *ex, double *ey, double *rho, double *theta,

@@ -1,0 +1,115 @@
+"""Vectorised drivers for many-system runs (BASELINE configs 4-5): the per-system host logic of
+api.py (`solve` -> `full_trace`) restated over arrays so that 10^4 perturbed instances cost a
+handful of launches and no per-instance Python:
+
+    first-order solve + Seidel sums   ort_first_order_f64   one thread per instance
+    real-ray aiming                   ort_aim_f64           one thread per (instance, field)
+    pupil grid trace + spot stats     ort_full_trace_f64    statistics-only mode (16 B per bundle out)
+
+Reference lines: solve src/RayTracing.jl:302-335, aberrations src/SeidelAberrations.jl:6-53,
+full_trace src/PupilSampling.jl:85-147.  Plain spherical prescriptions [ninst][rows][3].
+"""
+from __future__ import annotations
+
+import ctypes as C
+import math
+from typing import Dict, Sequence
+
+import numpy as np
+
+from . import _capi
+from .api import DomainError, EPS, LAMBDA, SPOT_RAYS, _eng, linrange_batch
+from .engine import Prescription
+
+_FO_FIELDS = [f[0] for f in _capi.ort_first_order._fields_]
+
+
+def first_order_arrays(engine, mats: np.ndarray, a, hprime, dn=None, lam: float = LAMBDA) -> Dict[str, np.ndarray]:
+    """ort_first_order_f64 over [ninst][rows][3] -> dict of [ninst] arrays."""
+    mats = np.ascontiguousarray(mats, dtype=np.float64)
+    ninst, rows, _ = mats.shape
+    R = np.ascontiguousarray(mats[:, :, 0]); t = np.ascontiguousarray(mats[:, :, 1]); n = np.ascontiguousarray(mats[:, :, 2])
+    a = np.ascontiguousarray(np.broadcast_to(np.asarray(a, dtype=np.float64), (ninst, rows - 1)))
+    hp = np.ascontiguousarray(np.broadcast_to(np.asarray(hprime, dtype=np.float64), (ninst,)))
+    dnp = None if dn is None else np.ascontiguousarray(np.broadcast_to(np.asarray(dn, dtype=np.float64), (ninst, rows)))
+    out = (_capi.ort_first_order * ninst)()
+    _capi.check(engine.ctx.lib.ort_first_order_f64(engine.ctx.h, ninst, rows, _capi.ptr(R), _capi.ptr(t), _capi.ptr(n),
+                                                   _capi.ptr(a), _capi.ptr(dnp), _capi.ptr(hp), float(lam), out,
+                                                   engine.base_flags))
+    dt = np.dtype([(k, np.float64) for k in _FO_FIELDS[:-2]] + [("stop", np.int32), ("k", np.int32)])
+    arr = np.frombuffer(out, dtype=dt, count=ninst)
+    return {k: np.array(arr[k]) for k in _FO_FIELDS}
+
+
+def tolerance_run(mats: np.ndarray, a, hprime, fields: Sequence[float] = (0.0,), k_rays: int = SPOT_RAYS,
+                  dn=None, engine=None) -> Dict[str, np.ndarray]:
+    """Seidel + spot-size Monte-Carlo over perturbed instances: for every instance the first-order
+    properties and third-order sums, and for every (instance, field) the RMS spot radius of
+    `full_trace(system, H, k_rays)` (stop-filtered, mirrored, about the centroid) and its ray count.
+    Returns arrays: first-order keys [ninst], `rms`, `count` [ninst][nfields]."""
+    eng = _eng(engine)
+    mats = np.ascontiguousarray(mats, dtype=np.float64)
+    ninst, rows, _ = mats.shape
+    fields = np.abs(np.asarray(fields, dtype=np.float64))
+    if not np.all(fields <= 1.0):
+        raise DomainError("Domain: |H| ≤ 1.0")
+    nf = len(fields)
+    a_arr = np.ascontiguousarray(np.broadcast_to(np.asarray(a, dtype=np.float64), (ninst, rows - 1)))
+    fo = first_order_arrays(eng, mats, a_arr, hprime, dn)
+    if not np.all(fo["k"] == rows - 1):
+        raise ValueError("tolerance_run expects prescriptions whose last thickness is 0 (image space)")
+    R, t, n = mats[:, :, 0], mats[:, :, 1].copy(), mats[:, :, 2]
+    t[:, 0] = np.where(np.isfinite(t[:, 0]), t[:, 0], 0.0)                      # Lens() mutation (Q19)
+    BFD = fo["BFD"]
+    # forward / reversed prescriptions (RayTracing.jl:267-277; K, p are zero here)
+    fwd = Prescription(R, t, n)
+    rev_R = -np.concatenate([np.full((ninst, 1), math.inf), R[:, :0:-1]], axis=1)
+    rev_t = t[:, ::-1].copy(); rev_t[:, 0] = BFD
+    rev_n = n[:, ::-1].copy()
+    rev = Prescription(rev_R, rev_t, rev_n, np.zeros_like(rev_R))
+    # aiming: one thread per (instance, field)
+    na = ninst * nf
+    ain = (_capi.ort_aim_in * na)()
+    dt_in = np.dtype([("system", np.int32), ("stop", np.int32), ("layout_fwd", np.int32), ("layout_rev", np.int32),
+                      ("H", np.float64), ("y_marg", np.float64), ("a_stop", np.float64), ("chief_y_end", np.float64),
+                      ("chief_u_end", np.float64), ("f", np.float64), ("atol", np.float64)])
+    spec = np.frombuffer(ain, dtype=dt_in, count=na)
+    inst = np.repeat(np.arange(ninst, dtype=np.int32), nf)
+    stop = fo["stop"][inst]
+    spec["system"] = inst; spec["stop"] = stop; spec["layout_fwd"] = 0; spec["layout_rev"] = 1
+    spec["H"] = np.tile(fields, ninst); spec["y_marg"] = fo["y_marg"][inst]
+    a_stop = a_arr[inst, stop - 1]
+    spec["a_stop"] = a_stop; spec["chief_y_end"] = fo["chief_y_end"][inst]; spec["chief_u_end"] = fo["chief_u_end"][inst]
+    spec["f"] = fo["f"][inst]; spec["atol"] = EPS
+    aout = (_capi.ort_aim_out * na)()
+    _capi.check(eng.ctx.lib.ort_aim_f64(eng.ctx.h, eng.system(fwd).h, eng.system(rev).h, na, ain, aout, eng.base_flags))
+    dt_out = np.dtype([(k, np.float64) for k in ("U", "y1", "y2", "y_EP", "hprime", "EP_t", "Ubar")] +
+                      [("iters", np.int32), ("ok", np.int32)])
+    aim = np.frombuffer(aout, dtype=dt_out, count=na)
+    if not np.all(aim["ok"] == 1):
+        raise RuntimeError(f"ray aiming did not converge for {int(np.sum(aim['ok'] != 1))} (instance, field) pairs")
+    # extended prescriptions (PupilSampling.jl:111-114) and the pupil grids (:121-122)
+    ext = Prescription(np.concatenate([R, np.full((ninst, 1), math.inf)], axis=1),
+                       np.concatenate([t[:, :-1], BFD[:, None], np.zeros((ninst, 1))], axis=1),
+                       np.concatenate([n, np.ones((ninst, 1))], axis=1))
+    k2 = k_rays // 2
+    yax = linrange_batch(aim["y1"], aim["y2"], k_rays)
+    xax = linrange_batch(np.zeros(na), aim["y_EP"], k2)
+    axes = np.ascontiguousarray(np.concatenate([yax, xax], axis=1)).ravel()
+    barr = (_capi.ort_bundle * na)()
+    dt_b = np.dtype([("system", np.int32), ("stop", np.int32), ("U", np.float64), ("V", np.float64), ("a_stop", np.float64),
+                     ("hprime", np.float64), ("ybar", np.float64), ("z0", np.float64), ("yaxis_off", np.int64),
+                     ("xaxis_off", np.int64)])
+    bd = np.frombuffer(barr, dtype=dt_b, count=na)
+    off = np.arange(na, dtype=np.int64) * (k_rays + k2)
+    bd["system"] = inst; bd["stop"] = stop; bd["U"] = aim["U"]; bd["V"] = 0.0; bd["a_stop"] = np.abs(a_stop)
+    bd["hprime"] = aim["hprime"]; bd["ybar"] = 0.0; bd["z0"] = 1.0; bd["yaxis_off"] = off; bd["xaxis_off"] = off + k_rays
+    count = np.zeros(na, dtype=np.int64); rms = np.zeros(na)
+    _capi.check(eng.ctx.lib.ort_full_trace_f64(eng.ctx.h, eng.system(ext).h, na, barr, _capi.ptr(axes), axes.size, k_rays, k2,
+                                               None, None, None, None, _capi.ptr(count), _capi.ptr(rms), eng.base_flags))
+    out = dict(fo)
+    out["rms"] = rms.reshape(ninst, nf)
+    out["count"] = count.reshape(ninst, nf)
+    out["U"] = np.array(aim["U"]).reshape(ninst, nf)
+    out["aim_iters"] = np.array(aim["iters"]).reshape(ninst, nf)
+    return out

@@ -592,8 +592,10 @@ int ort_full_trace_f64(ort_ctx* ctx, const ort_system* sys, int nb, const ort_bu
     typedef double T;
     int rc = check_ctx(ctx); if (rc) return rc;
     rc = check_sys(ctx, sys); if (rc) return rc;
-    if (nb <= 0 || !bundles || !axes || ny <= 0 || nx <= 0 || !ex || !ey || !rho || !theta || !count || !rms)
+    if (nb <= 0 || !bundles || !axes || ny <= 0 || nx <= 0 || !count || !rms)
         return fail(ORT_EINVAL, "bad full_trace arguments");
+    const bool stats_only = !ex && !ey && !rho && !theta;        // spot statistics without the error vectors
+    if (!stats_only && (!ex || !ey || !rho || !theta)) return fail(ORT_EINVAL, "ex, ey, rho, theta: all or none");
     const int S = sys->rows - 1;
     for (int b = 0; b < nb; ++b)
         if (bundles[b].stop <= 0 || bundles[b].stop > S) return fail(ORT_EINVAL, "bundle %d: full_trace needs a stop index in 1..%d", b, S);
@@ -627,10 +629,12 @@ int ort_full_trace_f64(ort_ctx* ctx, const ort_system* sys, int nb, const ort_bu
 
     T *dex = ex, *dey = ey, *drho = rho, *dth = theta; int64_t* dcount = count; double* drms = rms;
     if (!devp) {
-        rc = dev_out<T>(ctx, SL_OUT0, (size_t)2 * N, &dex); if (rc) return rc;
-        rc = dev_out<T>(ctx, SL_OUT1, (size_t)2 * N, &dey); if (rc) return rc;
-        rc = dev_out<T>(ctx, SL_OUT2, (size_t)2 * N, &drho); if (rc) return rc;
-        rc = dev_out<T>(ctx, SL_OUT4, (size_t)2 * N, &dth); if (rc) return rc;
+        if (!stats_only) {
+            rc = dev_out<T>(ctx, SL_OUT0, (size_t)2 * N, &dex); if (rc) return rc;
+            rc = dev_out<T>(ctx, SL_OUT1, (size_t)2 * N, &dey); if (rc) return rc;
+            rc = dev_out<T>(ctx, SL_OUT2, (size_t)2 * N, &drho); if (rc) return rc;
+            rc = dev_out<T>(ctx, SL_OUT4, (size_t)2 * N, &dth); if (rc) return rc;
+        }
         rc = dev_out<int64_t>(ctx, SL_RES0, (size_t)nb, &dcount); if (rc) return rc;
         rc = dev_out<double>(ctx, SL_RES1, (size_t)nb, &drms); if (rc) return rc;
     }
@@ -649,7 +653,7 @@ int ort_full_trace_f64(ort_ctx* ctx, const ort_system* sys, int nb, const ort_bu
         rc = from_device<int64_t>(ctx, count, dcount, (size_t)nb); if (rc) return rc;
         rc = from_device<double>(ctx, rms, drms, (size_t)nb); if (rc) return rc;
         HIP_TRY(hipStreamSynchronize(ctx->stream));
-        for (int b = 0; b < nb; ++b) {
+        for (int b = 0; b < nb && !stats_only; ++b) {
             const size_t off = (size_t)b * 2 * rpb, cnt = (size_t)count[b];
             if (!cnt) continue;
             rc = from_device<T>(ctx, ex + off, dex + off, cnt); if (rc) return rc;

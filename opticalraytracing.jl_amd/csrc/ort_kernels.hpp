@@ -457,11 +457,13 @@ __global__ __launch_bounds__(kBlock) void k_ft_scatter(const T* __restrict__ w_e
         if (keep[r]) {
             const int64_t o = base + k;
             const T rh = rr[r] / (T)a.rmax;                           // :142
-            ex[o] = e_x[r];  ey[o] = e_y[r];  rho[o] = rh;  theta[o] = th[r];
-            ex[o + a.m] = -e_x[r];                                    // :141
-            ey[o + a.m] = e_y[r];                                     // :140
-            rho[o + a.m] = rh;                                        // :143
-            theta[o + a.m] = (T)3.141592653589793 - th[r];            // :144
+            if (ex) {                                                     // NULL outputs: statistics only
+                ex[o] = e_x[r];  ey[o] = e_y[r];  rho[o] = rh;  theta[o] = th[r];
+                ex[o + a.m] = -e_x[r];                                    // :141
+                ey[o + a.m] = e_y[r];                                     // :140
+                rho[o + a.m] = rh;                                        // :143
+                theta[o + a.m] = (T)3.141592653589793 - th[r];            // :144
+            }
             const double dx1 = (double)e_x[r] - a.mux, dx2 = -(double)e_x[r] - a.mux;
             const double dy = (double)e_y[r] - a.muy;
             sq += (dx1 * dx1 + dx2 * dx2) + (dy * dy + dy * dy);

@@ -694,3 +694,26 @@ def test_random_bundles_grid_and_full_trace(hip_engine, oracle_engine):
                 assert abs(a["rms"] - b["rms"]) <= TOL * max(b["rms"], 1e-6), case
             else:
                 assert math.isnan(a["rms"])
+
+
+def test_tolerance_run_config5_pipeline(hip_engine, oracle_engine):
+    """BASELINE config 5 end to end (Seidel + spot Monte-Carlo): 400 perturbed instances x 2 fields,
+    three launches-worth of device work and no per-instance host code; spot-checked against the
+    per-instance route (solve -> aberrations -> full_trace) through the oracle."""
+    from opticalraytracing_jl_amd import analysis as an, batch, workloads
+    mats = workloads.config5(None, ninst=400)
+    res = batch.tolerance_run(mats, cm.DG_A, cm.DG_H, fields=(0.0, 1.0), k_rays=32, engine=hip_engine)
+    assert res["rms"].shape == (400, 2) and np.all(np.isfinite(res["rms"])) and np.all(res["count"] > 0)
+    for i in (0, 57, 399):
+        s = ort.solve(mats[i].copy(), cm.DG_A, cm.DG_H, engine=oracle_engine)
+        ab = an.aberrations(mats[i], s)
+        assert abs(res["f"][i] - s.f) <= 1e-11 * abs(s.f) and res["stop"][i] == s.stop
+        assert abs(res["W040"][i] - ab.W040) <= 1e-10 * max(1.0, abs(ab.W040))
+        for fi, H in enumerate((0.0, 1.0)):
+            e = ort.full_trace(s, H, 32, engine=oracle_engine)
+            assert res["count"][i, fi] == len(e.x)
+            assert abs(res["rms"][i, fi] - e.RMS) <= 1e-7
+    # the perturbations move the spot size: the run resolves a distribution, not a constant
+    assert res["rms"][:, 0].std() > 1e-5
+    with pytest.raises(ort.DomainError):
+        batch.tolerance_run(mats[:2], cm.DG_A, cm.DG_H, fields=(1.01,), engine=hip_engine)
