@@ -70,3 +70,44 @@ def test_extended_prescription():
     lay = ort.Layout(cm.cooke())
     pres = ort.extended_prescription(lay, 77.4)
     assert pres.rows == 9 and pres.t[0, -2] == 77.4 and math.isinf(pres.R[0, -1]) and pres.n[0, -1] == 1.0
+
+
+def test_full_trace_raybasis_route(oracle_engine):
+    """full_trace(surfaces, ray_basis): finite-conjugate branch of src/PupilSampling.jl:104-108,124-127
+    (per-ray U = (ybar - y)/z0, V = -x/z0 placed in the ANGLE slots, Q8) — runs end to end and is
+    consistent with tracing the same rays explicitly."""
+    surf = cm.cooke()
+    s = ort.solve(surf, cm.COOKE_A, cm.COOKE_H, engine=oracle_engine)
+    rays = ort.raytrace(s, -8.0, -400.0)                       # RayBasis for an object 400 mm in front
+    assert isinstance(rays, ort.RayBasis)
+    lay = ort.Layout(surf)
+    aim = ort.full_trace_aim(lay, rays, 1.0, engine=oracle_engine)
+    assert aim.raybasis and aim.z0 == rays.marginal.z[0]
+    err = ort.full_trace(surf, rays, 16, engine=oracle_engine)  # (surfaces, ray_basis, k_rays)
+    assert err.H == 1.0 and len(err.x) == len(err.y) and len(err.x) > 0 and math.isfinite(err.RMS)
+    # the same grid traced explicitly with the per-ray angles reproduces the first survivor
+    pres = ort.extended_prescription(lay, aim.focus)
+    yax, xax = ort.linrange(aim.y1, aim.y2, 16), ort.linrange(0.0, aim.y_EP, 8)
+    U = (aim.ybar - yax[0]) / aim.z0; V = -xax[0] / aim.z0
+    xv, yv = oracle_engine.skew(pres, yax[0], xax[0], U, V)
+    if np.hypot(xv[aim.stop - 1, 0], yv[aim.stop - 1, 0]) <= aim.a_stop:
+        assert err.x[0] == xv[-1, 0] and err.y[0] == yv[-1, 0] - aim.hprime
+
+
+def test_real_trace_keyword_forms(oracle_engine):
+    """raytrace(surfaces, y, U, RealRay; K, p) with explicit keywords == the Layout{Aspheric} method
+    for K (both take atan, Q16: K != 0), and a zero polynomial row behaves like `zero`."""
+    P = cm.parabola_M()
+    lay = ort.Layout(P, profile=ort.Aspheric)
+    r1 = ort.raytrace(lay, 12.0, 0.0, ort.RealRay, engine=oracle_engine)
+    r2 = ort.raytrace(P[:, :3], 12.0, 0.0, ort.RealRay, K=P[:, 3], engine=oracle_engine)
+    assert np.array_equal(r1.y, r2.y) and np.array_equal(r1.u, r2.u)
+    surf = cm.cooke()
+    base = ort.raytrace(surf, 3.0, 0.02, ort.RealRay, engine=oracle_engine)
+    zero_p = ort.raytrace(surf, 3.0, 0.02, ort.RealRay, p=[None] * 8, engine=oracle_engine)
+    assert np.array_equal(base.y, zero_p.y)
+    bent = ort.raytrace(surf, 3.0, 0.02, ort.RealRay, p=[None, [0, 0, 0, 0, 1e-5]] + [None] * 6, engine=oracle_engine)
+    assert not np.array_equal(base.y, bent.y) and np.allclose(base.y, bent.y, atol=0.1)
+    xv, yv = ort.raytrace(surf, 3.0, 1.0, 0.02, 0.0, ort.VectorRealRay, K=np.zeros(8), engine=oracle_engine)
+    xv0, yv0 = ort.raytrace(surf, 3.0, 1.0, 0.02, 0.0, ort.VectorRealRay, engine=oracle_engine)
+    assert np.array_equal(xv, xv0) and np.array_equal(yv, yv0)
