@@ -145,6 +145,15 @@ int ort_trace_grid_f32(ort_ctx *ctx, const ort_system *sys, int nb, const ort_bu
                        const float *axes, int64_t axes_len, int ny, int nx,
                        const ort_grid_out_f32 *out, unsigned flags);
 
+/* ---- pupil axes on the device: range(y1, y2, ny), range(x1, x2, nx) per bundle ---------------
+ * (src/PupilSampling.jl:121-122).  ends : [nb][4] = {y_first, y_last, x_first, x_last};
+ * axes : [nb][ny + nx] (bundle b: y axis at b*(ny+nx), x axis at b*(ny+nx)+ny).  Double-double
+ * evaluation of a + i (b - a)/(n - 1): correctly rounded, ties to even, end points exact — what
+ * Julia's TwicePrecision `range` is built to give (not pinned at the last ulp by any reference
+ * test; a Julia host that needs bit-identical grids passes collect(range(...)) instead).        */
+int ort_make_axes_f64(ort_ctx *ctx, int nb, int ny, int nx, const double *ends, double *axes,
+                      unsigned flags);
+
 /* ---- full_trace: src/PupilSampling.jl:121-146 + sigma :169-173 ------------------------
  * grid -> trace -> stop filter -> order-preserving append -> mirror -> rho, theta -> RMS,
  * one RealRayError (Types.jl:184-192) per bundle.  Aiming scalars (y1, y2, y_EP through

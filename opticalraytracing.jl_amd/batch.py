@@ -18,7 +18,7 @@ from typing import Dict, Sequence
 import numpy as np
 
 from . import _capi
-from .api import DomainError, EPS, LAMBDA, SPOT_RAYS, _eng, linrange_batch
+from .api import DomainError, EPS, LAMBDA, SPOT_RAYS, _eng
 from .engine import Prescription
 
 _FO_FIELDS = [f[0] for f in _capi.ort_first_order._fields_]
@@ -93,9 +93,6 @@ def tolerance_run(mats: np.ndarray, a, hprime, fields: Sequence[float] = (0.0,),
                        np.concatenate([t[:, :-1], BFD[:, None], np.zeros((ninst, 1))], axis=1),
                        np.concatenate([n, np.ones((ninst, 1))], axis=1))
     k2 = k_rays // 2
-    yax = linrange_batch(aim["y1"], aim["y2"], k_rays)
-    xax = linrange_batch(np.zeros(na), aim["y_EP"], k2)
-    axes = np.ascontiguousarray(np.concatenate([yax, xax], axis=1)).ravel()
     barr = (_capi.ort_bundle * na)()
     dt_b = np.dtype([("system", np.int32), ("stop", np.int32), ("U", np.float64), ("V", np.float64), ("a_stop", np.float64),
                      ("hprime", np.float64), ("ybar", np.float64), ("z0", np.float64), ("yaxis_off", np.int64),
@@ -104,9 +101,33 @@ def tolerance_run(mats: np.ndarray, a, hprime, fields: Sequence[float] = (0.0,),
     off = np.arange(na, dtype=np.int64) * (k_rays + k2)
     bd["system"] = inst; bd["stop"] = stop; bd["U"] = aim["U"]; bd["V"] = 0.0; bd["a_stop"] = np.abs(a_stop)
     bd["hprime"] = aim["hprime"]; bd["ybar"] = 0.0; bd["z0"] = 1.0; bd["yaxis_off"] = off; bd["xaxis_off"] = off + k_rays
-    count = np.zeros(na, dtype=np.int64); rms = np.zeros(na)
-    _capi.check(eng.ctx.lib.ort_full_trace_f64(eng.ctx.h, eng.system(ext).h, na, barr, _capi.ptr(axes), axes.size, k_rays, k2,
-                                               None, None, None, None, _capi.ptr(count), _capi.ptr(rms), eng.base_flags))
+    ends = np.ascontiguousarray(np.stack([aim["y1"], aim["y2"], np.zeros(na), aim["y_EP"]], axis=1))
+    lib, h = eng.ctx.lib, eng.ctx.h
+    try:
+        import torch
+        dev = torch.device("cuda", eng.ctx.device)
+    except Exception:          # no torch: host buffers (axes cross PCIe twice)
+        torch = None
+    if torch is not None:
+        # device-resident run: axes are generated on the GPU from 32 B of end points per bundle and
+        # only (count, rms) come back — 16 B per bundle
+        d_ends = torch.from_numpy(ends).to(dev)
+        d_axes = torch.empty(na * (k_rays + k2), dtype=torch.float64, device=dev)
+        d_count = torch.empty(na, dtype=torch.int64, device=dev)
+        d_rms = torch.empty(na, dtype=torch.float64, device=dev)
+        torch.cuda.synchronize(dev)
+        fl = eng.base_flags | _capi.ORT_DEVICE_PTRS
+        _capi.check(lib.ort_make_axes_f64(h, na, k_rays, k2, d_ends.data_ptr(), d_axes.data_ptr(), fl))
+        _capi.check(lib.ort_full_trace_f64(h, eng.system(ext).h, na, barr, d_axes.data_ptr(), d_axes.numel(), k_rays, k2,
+                                           None, None, None, None, d_count.data_ptr(), d_rms.data_ptr(), fl))
+        eng.ctx.synchronize()
+        count, rms = d_count.cpu().numpy(), d_rms.cpu().numpy()
+    else:
+        axes = np.empty(na * (k_rays + k2))
+        _capi.check(lib.ort_make_axes_f64(h, na, k_rays, k2, _capi.ptr(ends), _capi.ptr(axes), eng.base_flags))
+        count = np.zeros(na, dtype=np.int64); rms = np.zeros(na)
+        _capi.check(lib.ort_full_trace_f64(h, eng.system(ext).h, na, barr, _capi.ptr(axes), axes.size, k_rays, k2,
+                                           None, None, None, None, _capi.ptr(count), _capi.ptr(rms), eng.base_flags))
     out = dict(fo)
     out["rms"] = rms.reshape(ninst, nf)
     out["count"] = count.reshape(ninst, nf)

@@ -584,6 +584,29 @@ int ort_trace_grid_f32(ort_ctx* ctx, const ort_system* sys, int nb, const ort_bu
 }
 
 // --------------------------------------------------------------------------------------
+int ort_make_axes_f64(ort_ctx* ctx, int nb, int ny, int nx, const double* ends, double* axes, unsigned flags)
+{
+    int rc = check_ctx(ctx); if (rc) return rc;
+    if (nb <= 0 || ny <= 0 || nx <= 0 || !ends || !axes) return fail(ORT_EINVAL, "bad make_axes arguments");
+    const bool devp = flags & ORT_DEVICE_PTRS;
+    const int64_t total = (int64_t)nb * (ny + nx);
+    const double* dends = ends; double* daxes = axes;
+    if (!devp) {
+        rc = to_device<double>(ctx, SL_IN0, ends, (size_t)nb * 4, &dends); if (rc) return rc;
+        rc = dev_out<double>(ctx, SL_OUT0, (size_t)total, &daxes); if (rc) return rc;
+    }
+    const int64_t blocks = (total + kBlock - 1) / kBlock;
+    if (blocks > 0x7fffffffLL) return fail(ORT_EINVAL, "launch too large");
+    hipLaunchKernelGGL(k_make_axes, dim3((unsigned)blocks), dim3(kBlock), 0, ctx->stream, nb, ny, nx, dends, daxes);
+    HIP_TRY(hipGetLastError());
+    if (!devp) {
+        rc = from_device<double>(ctx, axes, daxes, (size_t)total); if (rc) return rc;
+        HIP_TRY(hipStreamSynchronize(ctx->stream));
+    }
+    return ORT_OK;
+}
+
+// --------------------------------------------------------------------------------------
 int ort_full_trace_f64(ort_ctx* ctx, const ort_system* sys, int nb, const ort_bundle* bundles,
                        const double* axes, int64_t axes_len, int ny, int nx,
                        double* ex, double* ey, double* rho, double* theta,

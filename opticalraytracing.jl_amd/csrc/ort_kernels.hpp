@@ -720,6 +720,49 @@ __global__ __launch_bounds__(kBlock) void k_trace_paraxial(int k, const double* 
 }
 
 // ------------------------------------------------------------------------------------
+// Pupil axes on the device: row b = [range(y_first, y_last, ny) | range(x_first, x_last, nx)]
+// (src/PupilSampling.jl:121-122).  x_i = (a (m - i) + b i) / m, m = n - 1, in double-double
+// arithmetic: exact numerator (integer weights, FMA products), quotient carried to ~106 bits and
+// EXACT whenever the true value is a short binary fraction, so ties round half-to-even — the same
+// algorithm, and the same bits, as the host mirror api.linrange_batch.
+// ------------------------------------------------------------------------------------
+__device__ __forceinline__ void dd_two_sum(double a, double b, double& s, double& e)
+{
+    s = a + b;
+    const double bb = s - a;
+    e = (a - (s - bb)) + (b - bb);
+}
+
+__device__ __forceinline__ double dd_range_elem(double a, double b, int n, int i)
+{
+    if (n <= 1 || i <= 0) return a;
+    if (i >= n - 1) return b;
+    const double m = (double)(n - 1), w2 = (double)i, w1 = m - w2;
+    const double p1 = a * w1, e1 = __builtin_fma(a, w1, -p1);
+    const double p2 = b * w2, e2 = __builtin_fma(b, w2, -p2);
+    double sh, se;
+    dd_two_sum(p1, p2, sh, se);
+    se = se + (e1 + e2);
+    double nh, nl;
+    dd_two_sum(sh, se, nh, nl);
+    const double q1 = nh / m;
+    const double ph = q1 * m, pl = __builtin_fma(q1, m, -ph);
+    const double q2 = (((nh - ph) - pl) + nl) / m;
+    return q1 + q2;
+}
+
+__global__ __launch_bounds__(kBlock) void k_make_axes(int nb, int ny, int nx, const double* __restrict__ ends,
+                                                      double* __restrict__ axes)
+{
+    const int64_t g = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    const int per = ny + nx;
+    if (g >= (int64_t)nb * per) return;
+    const int b = (int)(g / per), j = (int)(g - (int64_t)b * per);
+    const double* e = ends + (int64_t)b * 4;
+    axes[g] = (j < ny) ? dd_range_elem(e[0], e[1], ny, j) : dd_range_elem(e[2], e[3], nx, j - ny);
+}
+
+// ------------------------------------------------------------------------------------
 // Batched first-order solve + Seidel sums (SURVEY §8f "next #3"): one thread per system runs
 // Lens(surfaces) (src/RayTracing.jl:38-53), the two paraxial traces and the marginal / chief
 // construction of `_solve` (:208-221, :246-263, :302-323) and the third-order sums of

@@ -717,3 +717,19 @@ def test_tolerance_run_config5_pipeline(hip_engine, oracle_engine):
     assert res["rms"][:, 0].std() > 1e-5
     with pytest.raises(ort.DomainError):
         batch.tolerance_run(mats[:2], cm.DG_A, cm.DG_H, fields=(1.01,), engine=hip_engine)
+
+
+def test_device_axes_match_host_range(hip_engine):
+    """ort_make_axes_f64 == api.linrange_batch bit for bit (same double-double algorithm), incl. the
+    dyadic tie (81/108) that separates an approximate lerp from the exactly rounded one."""
+    import ctypes as C
+    from opticalraytracing_jl_amd import _capi, api
+    rng = np.random.default_rng(5)
+    nb, ny, nx = 200, 109, 64
+    ends = np.column_stack([rng.uniform(-50, 50, nb), rng.uniform(-50, 50, nb), np.zeros(nb), rng.uniform(1, 30, nb)])
+    ends[0, :2] = (20.595904298688694, -44.811747227337484)
+    axes = np.empty(nb * (ny + nx))
+    _capi.check(hip_engine.ctx.lib.ort_make_axes_f64(hip_engine.ctx.h, nb, ny, nx, ends.ctypes.data, axes.ctypes.data, 0))
+    axes = axes.reshape(nb, ny + nx)
+    assert np.array_equal(axes[:, :ny], api.linrange_batch(ends[:, 0], ends[:, 1], ny))
+    assert np.array_equal(axes[:, ny:], api.linrange_batch(ends[:, 2], ends[:, 3], nx))
