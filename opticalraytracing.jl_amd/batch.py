@@ -47,6 +47,18 @@ def tolerance_run(mats: np.ndarray, a, hprime, fields: Sequence[float] = (0.0,),
     properties and third-order sums, and for every (instance, field) the RMS spot radius of
     `full_trace(system, H, k_rays)` (stop-filtered, mirrored, about the centroid) and its ray count.
     Returns arrays: first-order keys [ninst], `rms`, `count` [ninst][nfields]."""
+    import os
+    import time
+    _t = [time.perf_counter()]
+    _trace = os.environ.get("ORT_TRACE_PHASES") == "1"
+
+    def _mark(name):
+        if _trace:
+            eng.ctx.synchronize()
+            now = time.perf_counter()
+            print(f"[tolerance_run] {name}: {(now - _t[0]) * 1e3:.2f} ms", flush=True)
+            _t[0] = now
+
     eng = _eng(engine)
     mats = np.ascontiguousarray(mats, dtype=np.float64)
     ninst, rows, _ = mats.shape
@@ -56,6 +68,7 @@ def tolerance_run(mats: np.ndarray, a, hprime, fields: Sequence[float] = (0.0,),
     nf = len(fields)
     a_arr = np.ascontiguousarray(np.broadcast_to(np.asarray(a, dtype=np.float64), (ninst, rows - 1)))
     fo = first_order_arrays(eng, mats, a_arr, hprime, dn)
+    _mark("first_order")
     if not np.all(fo["k"] == rows - 1):
         raise ValueError("tolerance_run expects prescriptions whose last thickness is 0 (image space)")
     R, t, n = mats[:, :, 0], mats[:, :, 1].copy(), mats[:, :, 2]
@@ -82,7 +95,11 @@ def tolerance_run(mats: np.ndarray, a, hprime, fields: Sequence[float] = (0.0,),
     spec["a_stop"] = a_stop; spec["chief_y_end"] = fo["chief_y_end"][inst]; spec["chief_u_end"] = fo["chief_u_end"][inst]
     spec["f"] = fo["f"][inst]; spec["atol"] = EPS
     aout = (_capi.ort_aim_out * na)()
-    _capi.check(eng.ctx.lib.ort_aim_f64(eng.ctx.h, eng.system(fwd).h, eng.system(rev).h, na, ain, aout, eng.base_flags))
+    _mark("aim specs (numpy)")
+    sf, sr = eng.system(fwd), eng.system(rev)
+    _mark("upload forward + reversed tables")
+    _capi.check(eng.ctx.lib.ort_aim_f64(eng.ctx.h, sf.h, sr.h, na, ain, aout, eng.base_flags))
+    _mark("aim kernel call")
     dt_out = np.dtype([(k, np.float64) for k in ("U", "y1", "y2", "y_EP", "hprime", "EP_t", "Ubar")] +
                       [("iters", np.int32), ("ok", np.int32)])
     aim = np.frombuffer(aout, dtype=dt_out, count=na)
@@ -103,6 +120,8 @@ def tolerance_run(mats: np.ndarray, a, hprime, fields: Sequence[float] = (0.0,),
     bd["hprime"] = aim["hprime"]; bd["ybar"] = 0.0; bd["z0"] = 1.0; bd["yaxis_off"] = off; bd["xaxis_off"] = off + k_rays
     ends = np.ascontiguousarray(np.stack([aim["y1"], aim["y2"], np.zeros(na), aim["y_EP"]], axis=1))
     lib, h = eng.ctx.lib, eng.ctx.h
+    se = eng.system(ext)
+    _mark("bundles (numpy) + upload extended tables")
     try:
         import torch
         dev = torch.device("cuda", eng.ctx.device)
@@ -118,7 +137,7 @@ def tolerance_run(mats: np.ndarray, a, hprime, fields: Sequence[float] = (0.0,),
         torch.cuda.synchronize(dev)
         fl = eng.base_flags | _capi.ORT_DEVICE_PTRS
         _capi.check(lib.ort_make_axes_f64(h, na, k_rays, k2, d_ends.data_ptr(), d_axes.data_ptr(), fl))
-        _capi.check(lib.ort_full_trace_f64(h, eng.system(ext).h, na, barr, d_axes.data_ptr(), d_axes.numel(), k_rays, k2,
+        _capi.check(lib.ort_full_trace_f64(h, se.h, na, barr, d_axes.data_ptr(), d_axes.numel(), k_rays, k2,
                                            None, None, None, None, d_count.data_ptr(), d_rms.data_ptr(), fl))
         eng.ctx.synchronize()
         count, rms = d_count.cpu().numpy(), d_rms.cpu().numpy()
@@ -126,8 +145,9 @@ def tolerance_run(mats: np.ndarray, a, hprime, fields: Sequence[float] = (0.0,),
         axes = np.empty(na * (k_rays + k2))
         _capi.check(lib.ort_make_axes_f64(h, na, k_rays, k2, _capi.ptr(ends), _capi.ptr(axes), eng.base_flags))
         count = np.zeros(na, dtype=np.int64); rms = np.zeros(na)
-        _capi.check(lib.ort_full_trace_f64(h, eng.system(ext).h, na, barr, _capi.ptr(axes), axes.size, k_rays, k2,
+        _capi.check(lib.ort_full_trace_f64(h, se.h, na, barr, _capi.ptr(axes), axes.size, k_rays, k2,
                                            None, None, None, None, _capi.ptr(count), _capi.ptr(rms), eng.base_flags))
+    _mark("axes + trace + statistics")
     out = dict(fo)
     out["rms"] = rms.reshape(ninst, nf)
     out["count"] = count.reshape(ninst, nf)

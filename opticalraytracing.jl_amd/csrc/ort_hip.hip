@@ -89,6 +89,7 @@ struct ort_system {
     MerSurf* mer = nullptr;        // [nsys][S]
     std::vector<double> t_last;    // t[rows-1] per system (meridional ts tail)
     double* d_tlast = nullptr;     // the same on the device (aiming kernel)
+    void* slab = nullptr;          // the one device allocation all of the above point into
 };
 
 namespace {
@@ -520,17 +521,34 @@ int ort_system_create(ort_ctx* ctx, int nsys, int rows, const double* R, const d
         sys->t_last[(size_t)s] = t[(size_t)s * rows + rows - 1];
     }
     sys->ctx = ctx; sys->nsys = nsys; sys->rows = rows; sys->ncoef = ncoef;
-    auto up = [&](void** dst, const void* src, size_t bytes) -> int {
-        HIP_TRY(hipMalloc(dst, bytes));
-        HIP_TRY(hipMemcpy(*dst, src, bytes, hipMemcpyHostToDevice));
-        return ORT_OK;
-    };
-    rc = up((void**)&sys->rec64, r64.data(), r64.size() * sizeof(SurfRec<double>));
-    if (!rc) rc = up((void**)&sys->rec32, r32.data(), r32.size() * sizeof(SurfRec<float>));
-    if (!rc) rc = up((void**)&sys->mer, mer.data(), mer.size() * sizeof(MerSurf));
-    if (!rc) rc = up((void**)&sys->d_tlast, sys->t_last.data(), sys->t_last.size() * sizeof(double));
-    if (!rc && ncoef > 0) rc = up((void**)&sys->coef64, c64.data(), c64.size() * sizeof(double));
-    if (!rc && ncoef > 0) rc = up((void**)&sys->coef32, c32.data(), c32.size() * sizeof(float));
+    // one device slab for every table of the batch (one hipMalloc, one staged copy): allocation
+    // calls dominate the upload of 10^4-instance batches otherwise
+    auto pad = [](size_t b) { return (b + 255) & ~(size_t)255; };
+    const size_t b_r64 = pad(r64.size() * sizeof(SurfRec<double>)), b_r32 = pad(r32.size() * sizeof(SurfRec<float>));
+    const size_t b_mer = pad(mer.size() * sizeof(MerSurf)), b_tl = pad(sys->t_last.size() * sizeof(double));
+    const size_t b_c64 = ncoef > 0 ? pad(c64.size() * sizeof(double)) : 0, b_c32 = ncoef > 0 ? pad(c32.size() * sizeof(float)) : 0;
+    const size_t total = b_r64 + b_r32 + b_mer + b_tl + b_c64 + b_c32;
+    std::vector<unsigned char> stage(total, 0);
+    size_t o = 0;
+    const size_t o_r64 = o; memcpy(stage.data() + o, r64.data(), r64.size() * sizeof(SurfRec<double>)); o += b_r64;
+    const size_t o_r32 = o; memcpy(stage.data() + o, r32.data(), r32.size() * sizeof(SurfRec<float>)); o += b_r32;
+    const size_t o_mer = o; memcpy(stage.data() + o, mer.data(), mer.size() * sizeof(MerSurf)); o += b_mer;
+    const size_t o_tl = o; memcpy(stage.data() + o, sys->t_last.data(), sys->t_last.size() * sizeof(double)); o += b_tl;
+    const size_t o_c64 = o; if (ncoef > 0) memcpy(stage.data() + o, c64.data(), c64.size() * sizeof(double)); o += b_c64;
+    const size_t o_c32 = o; if (ncoef > 0) memcpy(stage.data() + o, c32.data(), c32.size() * sizeof(float)); o += b_c32;
+    {
+        hipError_t e = hipMalloc(&sys->slab, total);
+        if (e == hipSuccess) e = hipMemcpy(sys->slab, stage.data(), total, hipMemcpyHostToDevice);
+        if (e != hipSuccess) { rc = fail(ORT_EHIP, "system upload failed: %s", hipGetErrorString(e)); }
+    }
+    if (!rc) {
+        unsigned char* base = static_cast<unsigned char*>(sys->slab);
+        sys->rec64 = reinterpret_cast<SurfRec<double>*>(base + o_r64);
+        sys->rec32 = reinterpret_cast<SurfRec<float>*>(base + o_r32);
+        sys->mer = reinterpret_cast<MerSurf*>(base + o_mer);
+        sys->d_tlast = reinterpret_cast<double*>(base + o_tl);
+        if (ncoef > 0) { sys->coef64 = reinterpret_cast<double*>(base + o_c64); sys->coef32 = reinterpret_cast<float*>(base + o_c32); }
+    }
     if (rc) { ort_system_destroy(sys); return rc; }
     *out = sys;
     return ORT_OK;
@@ -541,12 +559,7 @@ int ort_system_destroy(ort_system* sys)
     if (!sys) return ORT_OK;
     hipError_t e;
     if (sys->ctx) { e = hipSetDevice(sys->ctx->device); (void)e; e = hipStreamSynchronize(sys->ctx->stream); (void)e; }
-    if (sys->rec64) { e = hipFree(sys->rec64); (void)e; }
-    if (sys->rec32) { e = hipFree(sys->rec32); (void)e; }
-    if (sys->mer) { e = hipFree(sys->mer); (void)e; }
-    if (sys->d_tlast) { e = hipFree(sys->d_tlast); (void)e; }
-    if (sys->coef64) { e = hipFree(sys->coef64); (void)e; }
-    if (sys->coef32) { e = hipFree(sys->coef32); (void)e; }
+    if (sys->slab) { e = hipFree(sys->slab); (void)e; }
     delete sys;
     return ORT_OK;
 }
