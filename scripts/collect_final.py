@@ -10,7 +10,8 @@ traffic = {}
 for pol in ("fast", "ieee"):
     vals = {}
     for ctr in ("fetch", "write"):
-        fs = glob.glob(os.path.join(F, f"{ctr}_{pol}", "**", "*counter_collection.csv"), recursive=True)
+        fs = sorted(glob.glob(os.path.join(F, f"{ctr}_{pol}", "**", "*counter_collection.csv"), recursive=True),
+                    key=os.path.getmtime)[-1:]
         if not fs:
             continue
         acc = []
@@ -33,8 +34,9 @@ json.dump(traffic, open(os.path.join(P, "pmc_traffic.json"), "w"), indent=1)
 for src, dst in (("bench.json", f"{tag}_bench.json"),):
     if os.path.exists(os.path.join(F, src)):
         shutil.copy(os.path.join(F, src), os.path.join(P, dst))
-for f in glob.glob(os.path.join(F, "stats", "**", "*kernel_stats.csv"), recursive=True):
-    shutil.copy(f, os.path.join(P, f"{tag}_bench_kernel_stats.csv"))
+stats = sorted(glob.glob(os.path.join(F, "stats", "**", "*kernel_stats.csv"), recursive=True), key=os.path.getmtime)
+if stats:                      # newest run only (gpurun merges every run's files into gpurun_out/)
+    shutil.copy(stats[-1], os.path.join(P, f"{tag}_bench_kernel_stats.csv"))
 b = json.loads(open(os.path.join(F, "bench.json")).read().strip().splitlines()[-1])
 print("bench:", b["value"], b["roofline"]["kernel_ms"], b["roofline"]["frac"], b.get("cpu_baseline", {}).get("value"))
 for r in csv.DictReader(open(os.path.join(P, f"{tag}_bench_kernel_stats.csv"))):
