@@ -159,7 +159,7 @@ template <> struct Sel<float> {
 };
 
 // pick the kernel instantiation
-template <typename T, bool GRID, bool HIST, bool SUMM, bool FT>
+template <typename T, bool GRID, bool HIST, bool SUMM, int FT>
 int launch_trace(ort_ctx* ctx, const TraceParams<T>& p, int64_t blocks, unsigned flags)
 {
     if (blocks <= 0) return ORT_OK;
@@ -178,9 +178,9 @@ int launch_trace(ort_ctx* ctx, const TraceParams<T>& p, int64_t blocks, unsigned
 template <typename T, bool GRID>
 int launch_trace_modes(ort_ctx* ctx, const TraceParams<T>& p, int64_t blocks, bool hist, bool summ, unsigned flags)
 {
-    if (hist && summ)  return launch_trace<T, GRID, true, true, false>(ctx, p, blocks, flags);
-    if (hist && !summ) return launch_trace<T, GRID, true, false, false>(ctx, p, blocks, flags);
-    if (!hist && summ) return launch_trace<T, GRID, false, true, false>(ctx, p, blocks, flags);
+    if (hist && summ)  return launch_trace<T, GRID, true, true, FT_NONE>(ctx, p, blocks, flags);
+    if (hist && !summ) return launch_trace<T, GRID, true, false, FT_NONE>(ctx, p, blocks, flags);
+    if (!hist && summ) return launch_trace<T, GRID, false, true, FT_NONE>(ctx, p, blocks, flags);
     return fail(ORT_EINVAL, "no output requested");
 }
 
@@ -650,14 +650,34 @@ int ort_full_trace_f64(ort_ctx* ctx, const ort_system* sys, int nb, const ort_bu
     if (devp) p.axes = axes;
     else { rc = to_device<T>(ctx, SL_AXES, axes, (size_t)axes_len, &p.axes); if (rc) return rc; }
 
-    rc = dev_out<T>(ctx, SL_WEX, (size_t)N, &p.w_ex); if (rc) return rc;
-    rc = dev_out<T>(ctx, SL_WEY, (size_t)N, &p.w_ey); if (rc) return rc;
-    rc = dev_out<T>(ctx, SL_WR, (size_t)N, &p.w_r); if (rc) return rc;
-    rc = dev_out<T>(ctx, SL_WTH, (size_t)N, &p.w_th); if (rc) return rc;
     rc = dev_out<int32_t>(ctx, SL_TCNT, (size_t)tiles, &p.tile_cnt); if (rc) return rc;
     rc = dev_out<double>(ctx, SL_TSX, (size_t)tiles, &p.tile_sx); if (rc) return rc;
     rc = dev_out<double>(ctx, SL_TSY, (size_t)tiles, &p.tile_sy); if (rc) return rc;
     rc = dev_out<double>(ctx, SL_TRM, (size_t)tiles, &p.tile_rmax); if (rc) return rc;
+    if (stats_only) {
+        // one pass: trace + stop filter + per-tile (n, mean, M2), merged per bundle — no ray-sized buffer at all
+        rc = dev_out<double>(ctx, SL_TOFF, (size_t)tiles, &p.tile_m2x); if (rc) return rc;
+        rc = dev_out<double>(ctx, SL_TSQ, (size_t)tiles, &p.tile_m2y); if (rc) return rc;
+        int64_t* dcount = count; double* drms = rms;
+        if (!devp) {
+            rc = dev_out<int64_t>(ctx, SL_RES0, (size_t)nb, &dcount); if (rc) return rc;
+            rc = dev_out<double>(ctx, SL_RES1, (size_t)nb, &drms); if (rc) return rc;
+        }
+        rc = launch_trace<T, true, false, false, FT_STATS>(ctx, p, tiles, flags); if (rc) return rc;
+        hipLaunchKernelGGL(k_ft_stats_reduce, dim3((unsigned)nb), dim3(kBlock), 0, ctx->stream,
+                           p.tile_cnt, p.tile_sx, p.tile_sy, p.tile_m2x, p.tile_m2y, p.tile_rmax, p.tiles_per_bundle, dcount, drms);
+        HIP_TRY(hipGetLastError());
+        if (!devp) {
+            rc = from_device<int64_t>(ctx, count, dcount, (size_t)nb); if (rc) return rc;
+            rc = from_device<double>(ctx, rms, drms, (size_t)nb); if (rc) return rc;
+            HIP_TRY(hipStreamSynchronize(ctx->stream));
+        }
+        return ORT_OK;
+    }
+    rc = dev_out<T>(ctx, SL_WEX, (size_t)N, &p.w_ex); if (rc) return rc;
+    rc = dev_out<T>(ctx, SL_WEY, (size_t)N, &p.w_ey); if (rc) return rc;
+    rc = dev_out<T>(ctx, SL_WR, (size_t)N, &p.w_r); if (rc) return rc;
+    rc = dev_out<T>(ctx, SL_WTH, (size_t)N, &p.w_th); if (rc) return rc;
     int64_t* tile_off; double* tile_sq; FtBundleAgg* agg;
     rc = dev_out<int64_t>(ctx, SL_TOFF, (size_t)tiles, &tile_off); if (rc) return rc;
     rc = dev_out<double>(ctx, SL_TSQ, (size_t)tiles, &tile_sq); if (rc) return rc;
@@ -674,7 +694,7 @@ int ort_full_trace_f64(ort_ctx* ctx, const ort_system* sys, int nb, const ort_bu
         rc = dev_out<int64_t>(ctx, SL_RES0, (size_t)nb, &dcount); if (rc) return rc;
         rc = dev_out<double>(ctx, SL_RES1, (size_t)nb, &drms); if (rc) return rc;
     }
-    rc = launch_trace<T, true, false, false, true>(ctx, p, tiles, flags); if (rc) return rc;
+    rc = launch_trace<T, true, false, false, FT_FULL>(ctx, p, tiles, flags); if (rc) return rc;
     hipLaunchKernelGGL(k_ft_scan, dim3((unsigned)nb), dim3(kBlock), 0, ctx->stream,
                        p.tile_cnt, p.tile_sx, p.tile_sy, p.tile_rmax, p.tiles_per_bundle, tile_off, agg);
     HIP_TRY(hipGetLastError());

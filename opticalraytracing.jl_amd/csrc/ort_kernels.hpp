@@ -77,6 +77,7 @@ struct TraceParams {
     // full_trace dense workspace + tile aggregates
     T* w_ex; T* w_ey; T* w_r; T* w_th;
     int32_t* tile_cnt; double* tile_sx; double* tile_sy; double* tile_rmax;
+    double* tile_m2x; double* tile_m2y;     // FT_STATS: sums of squared deviations about the tile means
 };
 
 // Two adjacent rays of one lane: one 2*sizeof(T) streaming store when the address allows.
@@ -133,9 +134,12 @@ __device__ __forceinline__ void load_rec(SurfRec<T>& d, const __attribute__((add
 // ------------------------------------------------------------------------------------
 // The hot kernel.  GRID: rays generated from bundle axes; otherwise read from lists.
 // HIST: write per-surface history.  SUMM: write image/stop hits + status.
-// FT: full_trace epilogue (stop filter, dense workspace, tile aggregates).
+// FT: full_trace epilogue.  FT_FULL = stop filter + dense workspace + tile aggregates (survivors are
+// compacted by k_ft_scatter); FT_STATS = stop filter + per-tile (count, mean, M2, max r) only —
+// nothing ray-sized is written: the statistics-only route of ort_full_trace_f64.
+enum { FT_NONE = 0, FT_FULL = 1, FT_STATS = 2 };
 // ------------------------------------------------------------------------------------
-template <typename T, int MATH, bool USE_LDS, bool GRID, bool HIST, bool SUMM, bool FT>
+template <typename T, int MATH, bool USE_LDS, bool GRID, bool HIST, bool SUMM, int FT>
 __global__ __launch_bounds__(kBlock, ORT_MIN_WAVES) void k_trace(TraceParams<T> p)
 {
     __shared__ SurfRec<T> s_rec[USE_LDS ? kMaxRows : 1];
@@ -314,7 +318,7 @@ __global__ __launch_bounds__(kBlock, ORT_MIN_WAVES) void k_trace(TraceParams<T> 
             rv[r] = drop ? T(-1) : ri;                               // :136, -1 marks a dropped ray
             if (!drop) { ++cnt; sx += (double)exv[r]; sy += (double)eyv[r]; rmax = fmax(rmax, (double)ri); }
         }
-        if (live[0]) {
+        if (FT == FT_FULL && live[0]) {
             store_pair<T>(p.w_ex, gbase, two, exv[0], exv[kRPT - 1]);
             store_pair<T>(p.w_ey, gbase, two, eyv[0], eyv[kRPT - 1]);
             store_pair<T>(p.w_r, gbase, two, rv[0], rv[kRPT - 1]);
@@ -330,12 +334,94 @@ __global__ __launch_bounds__(kBlock, ORT_MIN_WAVES) void k_trace(TraceParams<T> 
         const int wave = tid >> 6;
         if ((tid & 63) == 0) { s_wcnt[wave] = cnt; s_wsx[wave] = sx; s_wsy[wave] = sy; s_wmax[wave] = rmax; }
         __syncthreads();
-        if (tid == 0) {
+        if (FT == FT_FULL) {
+            if (tid == 0) {
+                int c = 0; double ax = 0.0, ay = 0.0, mx = -1.0;
+                for (int w = 0; w < kBlock / 64; ++w) { c += s_wcnt[w]; ax += s_wsx[w]; ay += s_wsy[w]; mx = fmax(mx, s_wmax[w]); }
+                p.tile_cnt[blockIdx.x] = c; p.tile_sx[blockIdx.x] = ax; p.tile_sy[blockIdx.x] = ay;
+                p.tile_rmax[blockIdx.x] = mx;
+            }
+        } else {
+            // FT_STATS: two-pass INSIDE the tile (the tile's survivors are still in registers): tile means,
+            // then squared deviations about them; tiles are merged with Chan's update in k_ft_stats_reduce —
+            // as stable as the reference's two-pass sigma (:169-173), without a second pass over memory.
             int c = 0; double ax = 0.0, ay = 0.0, mx = -1.0;
             for (int w = 0; w < kBlock / 64; ++w) { c += s_wcnt[w]; ax += s_wsx[w]; ay += s_wsy[w]; mx = fmax(mx, s_wmax[w]); }
-            p.tile_cnt[blockIdx.x] = c; p.tile_sx[blockIdx.x] = ax; p.tile_sy[blockIdx.x] = ay;
-            p.tile_rmax[blockIdx.x] = mx;
+            const double mux = c ? ax / (double)c : 0.0, muy = c ? ay / (double)c : 0.0;
+            double qx = 0.0, qy = 0.0;
+#pragma unroll
+            for (int r = 0; r < kRPT; ++r) {
+                if (!(rv[r] < T(0))) {
+                    const double dx = (double)exv[r] - mux, dy = (double)eyv[r] - muy;
+                    qx += dx * dx; qy += dy * dy;
+                }
+            }
+            for (int off = 32; off > 0; off >>= 1) { qx += __shfl_down(qx, off); qy += __shfl_down(qy, off); }
+            __syncthreads();                                     // s_wsx / s_wsy are reused below
+            if ((tid & 63) == 0) { s_wsx[wave] = qx; s_wsy[wave] = qy; }
+            __syncthreads();
+            if (tid == 0) {
+                double tx = 0.0, ty = 0.0;
+                for (int w = 0; w < kBlock / 64; ++w) { tx += s_wsx[w]; ty += s_wsy[w]; }
+                p.tile_cnt[blockIdx.x] = c; p.tile_sx[blockIdx.x] = mux; p.tile_sy[blockIdx.x] = muy;
+                p.tile_m2x[blockIdx.x] = tx; p.tile_m2y[blockIdx.x] = ty; p.tile_rmax[blockIdx.x] = mx;
+            }
         }
+    }
+}
+
+// ------------------------------------------------------------------------------------
+// full_trace statistics-only, stage B: merge the per-tile (n, mean, M2) triples of a bundle with
+// Chan's pairwise update (fixed order: bitwise reproducible) and emit count and RMS of the
+// MIRRORED set [ex; -ex], [ey; ey] (src/PupilSampling.jl:140-141,169-173):
+//   mean_x = 0, M2x_total = 2 (M2x + n mx^2);  mean_y = my, M2y_total = 2 M2y;  RMS^2 = (.)/(2n).
+// ------------------------------------------------------------------------------------
+struct Moments { double n, mx, my, qx, qy, rmax; };
+
+__device__ __forceinline__ Moments chan_merge(const Moments& a, const Moments& b)
+{
+    if (b.n == 0.0) return a;
+    if (a.n == 0.0) return b;
+    Moments o;
+    o.n = a.n + b.n;
+    const double dx = b.mx - a.mx, dy = b.my - a.my, w = a.n * b.n / o.n;
+    o.mx = a.mx + dx * (b.n / o.n);
+    o.my = a.my + dy * (b.n / o.n);
+    o.qx = (a.qx + b.qx) + dx * dx * w;
+    o.qy = (a.qy + b.qy) + dy * dy * w;
+    o.rmax = fmax(a.rmax, b.rmax);
+    return o;
+}
+
+__global__ __launch_bounds__(kBlock) void k_ft_stats_reduce(const int32_t* __restrict__ tile_cnt, const double* __restrict__ tile_mx,
+                                                            const double* __restrict__ tile_my, const double* __restrict__ tile_m2x,
+                                                            const double* __restrict__ tile_m2y, const double* __restrict__ tile_rmax,
+                                                            int tiles_per_bundle, int64_t* __restrict__ count, double* __restrict__ rms)
+{
+    __shared__ Moments s_m[kBlock];
+    const int b = blockIdx.x, tid = threadIdx.x;
+    const int64_t base = (int64_t)b * tiles_per_bundle;
+    // contiguous chunk of tiles per thread, merged in tile order, then a fixed tree over the threads
+    const int per = (tiles_per_bundle + kBlock - 1) / kBlock;
+    Moments acc = {0.0, 0.0, 0.0, 0.0, 0.0, -1.0};
+    for (int q = 0; q < per; ++q) {
+        const int t = tid * per + q;
+        if (t < tiles_per_bundle) {
+            const Moments m = {(double)tile_cnt[base + t], tile_mx[base + t], tile_my[base + t], tile_m2x[base + t],
+                               tile_m2y[base + t], tile_rmax[base + t]};
+            acc = chan_merge(acc, m);
+        }
+    }
+    s_m[tid] = acc;
+    __syncthreads();
+    for (int off = 1; off < kBlock; off <<= 1) {
+        if ((tid & (2 * off - 1)) == 0 && tid + off < kBlock) s_m[tid] = chan_merge(s_m[tid], s_m[tid + off]);
+        __syncthreads();
+    }
+    if (tid == 0) {
+        const Moments m = s_m[0];
+        count[b] = 2 * (int64_t)m.n;
+        rms[b] = m.n > 0.0 ? sqrt(((m.qx + m.n * m.mx * m.mx) + m.qy) / m.n) : __builtin_nan("");
     }
 }
 

@@ -126,15 +126,19 @@ class HipEngine:
 
     # ---- full_trace grid stage: PupilSampling.jl:121-146,169-173 -------------------------
     def full_trace_grid(self, pres: Prescription, bundles: Sequence[dict], axes, ny: int, nx: int,
-                        raybasis: bool = False) -> List[dict]:
+                        raybasis: bool = False, stats_only: bool = False) -> List[dict]:
         axes = f64(axes).ravel()
         nb = len(bundles)
         cap = 2 * ny * nx
-        ex = np.empty((nb, cap)); ey = np.empty((nb, cap)); rho = np.empty((nb, cap)); th = np.empty((nb, cap))
         count = np.zeros(nb, dtype=np.int64); rms = np.zeros(nb)
         barr = _capi.make_bundles(bundles)
         flags = self.base_flags | (_capi.ORT_RAYBASIS if raybasis else 0)
         sysd = self.system(pres)
+        if stats_only:      # one pass, nothing ray-sized leaves (or is even written on) the device
+            check(self.ctx.lib.ort_full_trace_f64(self.ctx.h, sysd.h, nb, barr, ptr(axes), axes.size, ny, nx,
+                                                  None, None, None, None, ptr(count), ptr(rms), flags))
+            return [{"rms": float(rms[b]), "count": int(count[b])} for b in range(nb)]
+        ex = np.empty((nb, cap)); ey = np.empty((nb, cap)); rho = np.empty((nb, cap)); th = np.empty((nb, cap))
         check(self.ctx.lib.ort_full_trace_f64(self.ctx.h, sysd.h, nb, barr, ptr(axes), axes.size, ny, nx,
                                               ptr(ex), ptr(ey), ptr(rho), ptr(th), ptr(count), ptr(rms), flags))
         out = []

@@ -733,3 +733,26 @@ def test_device_axes_match_host_range(hip_engine):
     axes = axes.reshape(nb, ny + nx)
     assert np.array_equal(axes[:, :ny], api.linrange_batch(ends[:, 0], ends[:, 1], ny))
     assert np.array_equal(axes[:, ny:], api.linrange_batch(ends[:, 2], ends[:, 3], nx))
+
+
+def test_full_trace_stats_only_single_pass(hip_engine, oracle_engine):
+    """Statistics-only full_trace (one pass: per-tile (n, mean, M2) merged with Chan's update, no ray-sized
+    buffer) == the compacting pipeline and the oracle's two-pass sigma, incl. ragged tiles, several
+    tiles per bundle, an offset spot (|mean| >> sigma) and an empty bundle."""
+    pres, bundles, axes = _dg_bundles(oracle_engine, 130)                    # 33 tiles per bundle, last one ragged
+    full = hip_engine.full_trace_grid(pres, bundles, axes, 130, 130)
+    stat = hip_engine.full_trace_grid(pres, bundles, axes, 130, 130, stats_only=True)
+    orc = oracle_engine.full_trace_grid(pres, bundles, axes, 130, 130)
+    for f, s, o in zip(full, stat, orc):
+        assert s["count"] == f["count"] == o["count"]
+        assert abs(s["rms"] - o["rms"]) <= 1e-12 * o["rms"] and abs(f["rms"] - o["rms"]) <= 1e-12 * o["rms"]
+    # offset spot: h' far from the actual image height -> mean ey ~ 5 mm with sigma ~ 0.02 mm
+    off = [dict(b, hprime=b["hprime"] - 5.0) for b in bundles[:3]]
+    s2 = hip_engine.full_trace_grid(pres, off, axes, 130, 130, stats_only=True)
+    o2 = oracle_engine.full_trace_grid(pres, off, axes, 130, 130)
+    for s, o in zip(s2, o2):
+        assert abs(s["rms"] - o["rms"]) <= 1e-10 * o["rms"]
+    # a stop radius nothing passes: count 0, RMS NaN (maximum(r) of an empty set throws in the reference)
+    none = [dict(bundles[0], a_stop=-1.0)]
+    s3 = hip_engine.full_trace_grid(pres, none, axes, 130, 130, stats_only=True)[0]
+    assert s3["count"] == 0 and math.isnan(s3["rms"])
