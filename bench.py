@@ -37,7 +37,7 @@ def cpu_baseline(api, pres, bundles, axes, k_full: int, target_s: float = 12.0):
     """Oracle (C restatement of the reference loop, oracle/ort_oracle.c) timed on this box's host
     cores on a bounded sample of the SAME workload: the first bundles' pupil rows."""
     import numpy as np
-    from oracle.cpu import OracleEngine, _Sys, _p, lib
+    from oracle.cpu import _Sys, _p, lib
     L = lib()
     bd = bundles[0]
     s = _Sys(pres, bd["system"])

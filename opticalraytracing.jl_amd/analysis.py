@@ -12,13 +12,11 @@ from __future__ import annotations
 
 import math
 from dataclasses import dataclass
-from typing import Optional
-
 import numpy as np
 
 from . import api
-from .api import (Chief, DomainError, K_RAYS, LAMBDA, Layout, Marginal, RealRay, RealRayT, System, surface_ray,
-                  surface_to_focus, trace_chief_ray, trace_marginal_ray, transfer_real)
+from .api import (DomainError, K_RAYS, LAMBDA, Layout, RealRay, System, surface_ray, surface_to_focus,
+                  trace_chief_ray, trace_marginal_ray, transfer_real)
 
 
 @dataclass

@@ -11,7 +11,6 @@ full_trace src/PupilSampling.jl:85-147.  Plain spherical prescriptions [ninst][r
 """
 from __future__ import annotations
 
-import ctypes as C
 import math
 from typing import Dict, Sequence
 

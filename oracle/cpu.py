@@ -10,7 +10,7 @@ from __future__ import annotations
 import ctypes as C
 import os
 import subprocess
-from typing import List, Optional, Sequence
+from typing import List, Sequence
 
 import numpy as np
 

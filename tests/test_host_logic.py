@@ -5,7 +5,6 @@ import numpy as np
 import pytest
 
 import opticalraytracing_jl_amd as ort
-from opticalraytracing_jl_amd import api
 from oracle import cpu as oc
 from tests import common as cm
 
