@@ -24,4 +24,4 @@ for dt, fn in ((torch.float64, eng.ctx.lib.ort_trace_skew_f64), (torch.float32, 
         for _ in range(10): step()
         ms = eng.ctx.timer_stop() / 10
         w = 8 if dt == torch.float64 else 4
-        print(f"{str(dt):14s} {name:12s} {ms:.4f} ms  {N*S/ms/1e6:.3e} intersections/s  {(2*w*N*S + 4*w*N)/ms/1e6:.0f} GB/s (algorithmic)")
+        print(f"{str(dt):14s} {name:12s} {ms:.4f} ms  {N*S/(ms*1e-3):.3e} intersections/s  {(2*w*N*S + 4*w*N)/ms/1e6:.0f} GB/s (algorithmic)")
