@@ -153,3 +153,84 @@ def tolerance_run(mats: np.ndarray, a, hprime, fields: Sequence[float] = (0.0,),
     out["U"] = np.array(aim["U"]).reshape(ninst, nf)
     out["aim_iters"] = np.array(aim["iters"]).reshape(ninst, nf)
     return out
+
+
+def image_hits(mats: np.ndarray, a, hprime, fields: Sequence[float], k: int, engine=None, shard=None):
+    """Image-plane hit points of every (instance, field) bundle over the FULL square pupil k x k
+    (BASELINE config 4: zoom / wavelength sweeps): first-order solve and aiming on the device, pupil
+    boxes from the aimed marginal and chief rays, one summary-mode trace writing only (x_f, y_f,
+    status) — 20 B per ray.  Returns torch tensors on the engine's GPU: xf, yf [nb, k, k], status
+    [nb, k, k] (bit 16 = rejected by the stop filter), in bundle order (instance-major, field-minor).
+
+    shard = (rank, world): trace only this rank's contiguous slab of bundles (dist.shard_bounds) —
+    concatenating the ranks' outputs in rank order (dist.allgather_hits / ort_allgather_hits_f64)
+    reproduces the single-GPU result."""
+    import torch
+    from . import dist as odist
+    eng = _eng(engine)
+    mats = np.ascontiguousarray(mats, dtype=np.float64)
+    ninst, rows, _ = mats.shape
+    fields = np.abs(np.asarray(fields, dtype=np.float64))
+    if not np.all(fields <= 1.0):
+        raise DomainError("Domain: |H| ≤ 1.0")
+    nf = len(fields)
+    a_arr = np.ascontiguousarray(np.broadcast_to(np.asarray(a, dtype=np.float64), (ninst, rows - 1)))
+    fo = first_order_arrays(eng, mats, a_arr, hprime)
+    R, t, n = mats[:, :, 0], mats[:, :, 1].copy(), mats[:, :, 2]
+    t[:, 0] = np.where(np.isfinite(t[:, 0]), t[:, 0], 0.0)
+    BFD = fo["BFD"]
+    fwd = Prescription(R, t, n)
+    rev_R = -np.concatenate([np.full((ninst, 1), math.inf), R[:, :0:-1]], axis=1)
+    rev_t = t[:, ::-1].copy(); rev_t[:, 0] = BFD
+    rev = Prescription(rev_R, rev_t, n[:, ::-1].copy(), np.zeros_like(rev_R))
+    na = ninst * nf
+    lo, hi = (0, na) if shard is None else odist.shard_bounds(na, shard[1])[shard[0]]
+    nb = hi - lo
+    inst = np.repeat(np.arange(ninst, dtype=np.int32), nf)[lo:hi]
+    Hs = np.tile(fields, ninst)[lo:hi]
+    stop = fo["stop"][inst]
+    ain = (_capi.ort_aim_in * nb)()
+    dt_in = np.dtype([("system", np.int32), ("stop", np.int32), ("layout_fwd", np.int32), ("layout_rev", np.int32),
+                      ("H", np.float64), ("y_marg", np.float64), ("a_stop", np.float64), ("chief_y_end", np.float64),
+                      ("chief_u_end", np.float64), ("f", np.float64), ("atol", np.float64)])
+    spec = np.frombuffer(ain, dtype=dt_in, count=nb)
+    a_stop = a_arr[inst, stop - 1]
+    spec["system"] = inst; spec["stop"] = stop; spec["layout_fwd"] = 0; spec["layout_rev"] = 1; spec["H"] = Hs
+    spec["y_marg"] = fo["y_marg"][inst]; spec["a_stop"] = a_stop; spec["chief_y_end"] = fo["chief_y_end"][inst]
+    spec["chief_u_end"] = fo["chief_u_end"][inst]; spec["f"] = fo["f"][inst]; spec["atol"] = EPS
+    aout = (_capi.ort_aim_out * nb)()
+    _capi.check(eng.ctx.lib.ort_aim_f64(eng.ctx.h, eng.system(fwd).h, eng.system(rev).h, nb, ain, aout, eng.base_flags))
+    dt_out = np.dtype([(kk, np.float64) for kk in ("U", "y1", "y2", "y_EP", "hprime", "EP_t", "Ubar")] +
+                      [("iters", np.int32), ("ok", np.int32)])
+    aim = np.frombuffer(aout, dtype=dt_out, count=nb)
+    if not np.all(aim["ok"] == 1):
+        raise RuntimeError("ray aiming did not converge")
+    ext = Prescription(np.concatenate([R, np.full((ninst, 1), math.inf)], axis=1),
+                       np.concatenate([t[:, :-1], BFD[:, None], np.zeros((ninst, 1))], axis=1),
+                       np.concatenate([n, np.ones((ninst, 1))], axis=1))
+    barr = (_capi.ort_bundle * nb)()
+    dt_b = np.dtype([("system", np.int32), ("stop", np.int32), ("U", np.float64), ("V", np.float64), ("a_stop", np.float64),
+                     ("hprime", np.float64), ("ybar", np.float64), ("z0", np.float64), ("yaxis_off", np.int64),
+                     ("xaxis_off", np.int64)])
+    bd = np.frombuffer(barr, dtype=dt_b, count=nb)
+    off = np.arange(nb, dtype=np.int64) * (2 * k)
+    bd["system"] = inst; bd["stop"] = stop; bd["U"] = aim["U"]; bd["V"] = 0.0; bd["a_stop"] = np.abs(a_stop)
+    bd["hprime"] = aim["hprime"]; bd["ybar"] = 0.0; bd["z0"] = 1.0; bd["yaxis_off"] = off; bd["xaxis_off"] = off + k
+    # full square pupil: y from the aimed upper to lower edge ray, x symmetric about the axis
+    ends = np.ascontiguousarray(np.stack([aim["y1"], aim["y2"], -aim["y_EP"], aim["y_EP"]], axis=1))
+    dev = torch.device("cuda", eng.ctx.device)
+    d_ends = torch.from_numpy(ends).to(dev)
+    d_axes = torch.empty(nb * 2 * k, dtype=torch.float64, device=dev)
+    xf = torch.empty((nb, k, k), dtype=torch.float64, device=dev); yf = torch.empty_like(xf)
+    st = torch.empty((nb, k, k), dtype=torch.int32, device=dev)
+    torch.cuda.synchronize(dev)
+    fl = eng.base_flags | _capi.ORT_DEVICE_PTRS
+    lib, h = eng.ctx.lib, eng.ctx.h
+    _capi.check(lib.ort_make_axes_f64(h, nb, k, k, d_ends.data_ptr(), d_axes.data_ptr(), fl))
+    out = _capi.ort_grid_out_f64()
+    out.xf, out.yf, out.status = xf.data_ptr(), yf.data_ptr(), st.data_ptr()
+    import ctypes as C
+    _capi.check(lib.ort_trace_grid_f64(h, eng.system(ext).h, nb, barr, d_axes.data_ptr(), d_axes.numel(), k, k,
+                                       C.byref(out), fl))
+    eng.ctx.synchronize()
+    return xf, yf, st

@@ -756,3 +756,26 @@ def test_full_trace_stats_only_single_pass(hip_engine, oracle_engine):
     none = [dict(bundles[0], a_stop=-1.0)]
     s3 = hip_engine.full_trace_grid(pres, none, axes, 130, 130, stats_only=True)[0]
     assert s3["count"] == 0 and math.isnan(s3["rms"])
+
+
+def test_image_hits_config4_sharded(hip_engine, oracle_engine):
+    """BASELINE config 4 driver (batch.image_hits): every rank traces its contiguous slab of bundles;
+    the slabs concatenated in rank order equal the single launch (what the all-gather reassembles),
+    and a bundle equals the per-call route through the oracle."""
+    import torch
+    from opticalraytracing_jl_amd import batch, workloads
+    mats = np.array([workloads.double_gauss(line, g) for g in (-1.0, 0.0, 1.0) for line in (0, 1)])
+    fields = (0.0, 0.7, 1.0)
+    whole = batch.image_hits(mats, cm.DG_A, cm.DG_H, fields, 24, engine=hip_engine)
+    parts = [batch.image_hits(mats, cm.DG_A, cm.DG_H, fields, 24, engine=hip_engine, shard=(r, 4)) for r in range(4)]
+    for j in range(3):
+        cat = torch.cat([p[j] for p in parts])
+        assert torch.equal(torch.nan_to_num(cat.double()), torch.nan_to_num(whole[j].double()))
+    # bundle 4 = (system 1, field 0.7) against solve -> aim -> explicit trace through the oracle
+    s = ort.solve(mats[1].copy(), cm.DG_A, cm.DG_H, engine=oracle_engine)
+    aim = ort.full_trace_aim(s.layout, s, 0.7, engine=oracle_engine)
+    pres = ort.extended_prescription(s.layout, aim.focus)
+    yy = np.repeat(ort.linrange(aim.y1, aim.y2, 24), 24); xx = np.tile(ort.linrange(-aim.y_EP, aim.y_EP, 24), 24)
+    ox, oy = oracle_engine.skew(pres, yy, xx, np.full(576, math.tan(aim.U)), np.zeros(576), slopes=True)
+    assert np.abs(whole[0][4].cpu().numpy().ravel() - ox[-1]).max() <= 1e-6      # aiming tolerance sqrt(eps)
+    assert np.abs(whole[1][4].cpu().numpy().ravel() - oy[-1]).max() <= 1e-6
