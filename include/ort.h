@@ -218,6 +218,17 @@ int ort_first_order_f64(ort_ctx *ctx, int nsys, int rows, const double *R, const
                         const double *a, const double *dn, const double *hprime, double lambda,
                         ort_first_order *out, unsigned flags);
 
+/* ---- device-resident spot pipeline: full_trace(solve(surfaces, a, h′), H, k_rays).RMS -------
+ * for nsys spherical prescriptions x nfields fields in ONE call with no host round trip between
+ * the stages: first-order solve (src/RayTracing.jl:302-323), real-ray aiming (:223-296,
+ * src/PupilSampling.jl:67-83), pupil axes (:121-122), grid trace + stop filter + mirrored RMS
+ * (:123-146,169-173; statistics-only route).  R, t, n : [nsys][rows]; a : [nsys][rows-1];
+ * hprime : [nsys]; fields : [nfields]; count, rms : [nsys][nfields]; fo_out : [nsys] or NULL.
+ * The last thickness of every prescription must be 0 (image space), as in the reference's tests. */
+int ort_spot_batch_f64(ort_ctx *ctx, int nsys, int rows, const double *R, const double *t, const double *n,
+                       const double *a, const double *hprime, int nfields, const double *fields, int k_rays,
+                       ort_first_order *fo_out, int64_t *count, double *rms, unsigned flags);
+
 /* ---- paraxial y-nu trace: raytrace(lens, y, ω, a; clip) --------------------------------
  * src/RayTracing.jl:127-143 (+ transfer/refract :55-69).  nlens lenses of k rows each
  * (Lens.M columns τ, ϕ: [nlens][k]); a: [nlens][k] or NULL (fill(Inf)); rays_per_lens rays

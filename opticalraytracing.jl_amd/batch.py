@@ -155,6 +155,37 @@ def tolerance_run(mats: np.ndarray, a, hprime, fields: Sequence[float] = (0.0,),
     return out
 
 
+def spot_batch(mats: np.ndarray, a, hprime, fields: Sequence[float] = (0.0,), k_rays: int = SPOT_RAYS,
+               engine=None) -> Dict[str, np.ndarray]:
+    """`tolerance_run` as ONE C call (`ort_spot_batch_f64`): solve -> aiming -> pupil axes -> grid trace
+    -> spot statistics chained on the context's stream with every intermediate (first-order results,
+    forward / reversed / extended tables, aiming requests, bundles, axes) built and kept on the GPU.
+    In: 3 x [ninst][rows] prescriptions + semi-diameters; out: first-order struct per instance and
+    16 B (count, rms) per (instance, field)."""
+    eng = _eng(engine)
+    mats = np.ascontiguousarray(mats, dtype=np.float64)
+    ninst, rows, _ = mats.shape
+    fields = np.ascontiguousarray(np.abs(np.asarray(fields, dtype=np.float64)))
+    nf = len(fields)
+    R = np.ascontiguousarray(mats[:, :, 0]); t = np.ascontiguousarray(mats[:, :, 1]); n = np.ascontiguousarray(mats[:, :, 2])
+    a_arr = np.ascontiguousarray(np.broadcast_to(np.asarray(a, dtype=np.float64), (ninst, rows - 1)))
+    hp = np.ascontiguousarray(np.broadcast_to(np.asarray(hprime, dtype=np.float64), (ninst,)))
+    fo = (_capi.ort_first_order * ninst)()
+    count = np.zeros(ninst * nf, dtype=np.int64); rms = np.zeros(ninst * nf)
+    rc = eng.ctx.lib.ort_spot_batch_f64(eng.ctx.h, ninst, rows, _capi.ptr(R), _capi.ptr(t), _capi.ptr(n), _capi.ptr(a_arr),
+                                        _capi.ptr(hp), nf, _capi.ptr(fields), int(k_rays), fo, _capi.ptr(count),
+                                        _capi.ptr(rms), eng.base_flags)
+    if rc == _capi.ORT_EDOMAIN:
+        raise DomainError(eng.ctx.lib.ort_last_error().decode('utf-8', 'replace'))
+    _capi.check(rc)
+    dt = np.dtype([(k, np.float64) for k in _FO_FIELDS[:-2]] + [("stop", np.int32), ("k", np.int32)])
+    arr = np.frombuffer(fo, dtype=dt, count=ninst)
+    out = {k: np.array(arr[k]) for k in _FO_FIELDS}
+    out["rms"] = rms.reshape(ninst, nf)
+    out["count"] = count.reshape(ninst, nf)
+    return out
+
+
 def image_hits(mats: np.ndarray, a, hprime, fields: Sequence[float], k: int, engine=None, shard=None):
     """Image-plane hit points of every (instance, field) bundle over the FULL square pupil k x k
     (BASELINE config 4: zoom / wavelength sweeps): first-order solve and aiming on the device, pupil

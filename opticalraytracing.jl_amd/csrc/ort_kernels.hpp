@@ -956,6 +956,103 @@ __global__ __launch_bounds__(64) void k_first_order(int nsys, int rows, const do
 }
 
 // ------------------------------------------------------------------------------------
+// Device-resident spot pipeline (ort_spot_batch_f64): solve -> aim -> full_trace statistics for
+// many spherical prescriptions with NO host round trip between the stages.  These small kernels
+// do on the device what ort_system_create / api.py do on the host for one system at a time:
+// derive the per-surface records (forward + image row, and the reversed prescription of
+// src/RayTracing.jl:267-277), turn first-order results into aiming requests, and aiming results
+// into bundle descriptors and axis end points (src/PupilSampling.jl:94-122).
+// ------------------------------------------------------------------------------------
+template <typename T>
+__device__ __forceinline__ void make_rec(SurfRec<T>& r, T t, T Rv, T n1, T n2)
+{
+    r.t = t; r.R = Rv; r.R2 = Rv * Rv;
+    r.sgn = Rv > T(0) ? T(1) : (Rv < T(0) ? T(-1) : Rv);
+    r.opk = T(1); r.eta = n1 / n2; r.eta2 = r.eta * r.eta; r.K = T(0);
+    r.finite = __builtin_isfinite(Rv) ? 1 : 0;
+    r.invR = r.finite ? T(1) / Rv : T(0);
+    r.ome2 = T(1) - r.eta2; r.e2c2 = r.eta2 * (r.invR * r.invR); r.ec = r.eta * fabs(r.invR);
+    r.ncoef = 0;
+    r.kind = !r.finite ? KIND_FLAT : KIND_SPHERE;
+    if (r.kind == KIND_SPHERE && fabs((double)Rv) <= kCentreFormMaxR && sizeof(T) == 8) { r.kind = KIND_SPHERE_C; r.K = r.t + Rv; }
+    r.cls = (r.finite ? CLS_FINITE : 0) | ((r.eta != T(1)) ? CLS_REFR : 0) | (!(fabs(r.eta) <= T(1)) ? CLS_TIR : 0) |
+            (r.kind << CLS_KIND_SHIFT);
+}
+
+// one thread per (system, loop index i): extended skew table [nsys][rows], forward and reversed
+// meridional tables [nsys][rows-1], last thicknesses
+__global__ __launch_bounds__(kBlock) void k_build_tables(int nsys, int rows, const double* __restrict__ R, const double* __restrict__ t,
+                                                         const double* __restrict__ n, const FirstOrderOut* __restrict__ fo,
+                                                         SurfRec<double>* __restrict__ rec_ext, MerSurf* __restrict__ mer_fwd,
+                                                         MerSurf* __restrict__ mer_rev, double* __restrict__ tl_fwd,
+                                                         double* __restrict__ tl_rev)
+{
+    const int64_t g = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (g >= (int64_t)nsys * rows) return;
+    const int s = (int)(g / rows), i = (int)(g - (int64_t)s * rows);
+    const double* Rs = R + (int64_t)s * rows; const double* ts = t + (int64_t)s * rows; const double* ns = n + (int64_t)s * rows;
+    const double BFD = fo[s].BFD;
+    auto tt = [&](int j) { return (j == 0 && !__builtin_isfinite(ts[0])) ? 0.0 : ts[j]; };          // Lens() mutation (Q19)
+    // extended system (PupilSampling.jl:111-114): rows+1 rows, loop index i = 0..rows-1
+    {
+        const double te = (i == rows - 1) ? BFD : tt(i);                 // t[end-1] = focus
+        const double Re = (i + 1 < rows) ? Rs[i + 1] : __builtin_inf();
+        const double n1 = ns[i], n2 = (i + 1 < rows) ? ns[i + 1] : 1.0;
+        SurfRec<double> r;
+        make_rec<double>(r, te, Re, n1, n2);
+        rec_ext[(int64_t)s * rows + i] = r;
+    }
+    if (i < rows - 1) {
+        MerSurf m;
+        m.t = tt(i); m.R = Rs[i + 1]; m.sgn = m.R > 0 ? 1.0 : (m.R < 0 ? -1.0 : m.R); m.K = 0.0;
+        m.n1 = ns[i]; m.n2 = ns[i + 1]; m.finite = __builtin_isfinite(m.R) ? 1 : 0; m.ncoef = 0;
+        mer_fwd[(int64_t)s * (rows - 1) + i] = m;
+        // reversed (RayTracing.jl:267-271): rev_R = -[Inf; R[end:-1:2]], rev_t = reverse(t) with rev_t[1] = BFD
+        MerSurf q;
+        q.t = (i == 0) ? BFD : tt(rows - 1 - i);
+        q.R = -Rs[rows - 1 - i];                                         // rev_R[i+1] = -R[rows-1-i]
+        q.sgn = q.R > 0 ? 1.0 : (q.R < 0 ? -1.0 : q.R); q.K = 0.0;
+        q.n1 = ns[rows - 1 - i]; q.n2 = ns[rows - 2 - i]; q.finite = __builtin_isfinite(q.R) ? 1 : 0; q.ncoef = 0;
+        mer_rev[(int64_t)s * (rows - 1) + i] = q;
+    }
+    if (i == 0) { tl_fwd[s] = tt(rows - 1); tl_rev[s] = tt(0); }
+}
+
+__global__ __launch_bounds__(kBlock) void k_build_aim(int nsys, int nf, int rows, const FirstOrderOut* __restrict__ fo,
+                                                      const double* __restrict__ a, const double* __restrict__ fields,
+                                                      AimIn* __restrict__ ain)
+{
+    const int g = blockIdx.x * kBlock + threadIdx.x;
+    if (g >= nsys * nf) return;
+    const int s = g / nf, f = g - s * nf;
+    const FirstOrderOut o = fo[s];
+    AimIn q;
+    q.system = s; q.stop = o.stop; q.layout_fwd = 0; q.layout_rev = 1;
+    q.H = fabs(fields[f]); q.y_marg = o.y_marg; q.a_stop = a[(int64_t)s * (rows - 1) + o.stop - 1];
+    q.chief_y_end = o.chief_y_end; q.chief_u_end = o.chief_u_end; q.f = o.f; q.atol = 1.4901161193847656e-08;
+    ain[g] = q;
+}
+
+__global__ __launch_bounds__(kBlock) void k_build_bundles(int na, int k_rays, int k2, const AimIn* __restrict__ ain,
+                                                          const AimOut* __restrict__ aout, DevBundle<double>* __restrict__ bd,
+                                                          double* __restrict__ ends, int* __restrict__ fail_flag)
+{
+    const int g = blockIdx.x * kBlock + threadIdx.x;
+    if (g >= na) return;
+    const AimIn q = ain[g]; const AimOut o = aout[g];
+    if (!o.ok) atomicOr(fail_flag, 1);
+    DevBundle<double> d;
+    d.system = q.system; d.stop = q.stop - 1;
+    d.u = ::tan(o.U); d.v = 0.0;                                         // PupilSampling.jl:38-39 (V = 0, :115)
+    const double nrm = __builtin_sqrt((d.v * d.v + d.u * d.u) + 1.0), inv = 1.0 / nrm;
+    d.k0 = d.v * inv; d.k1 = d.u * inv; d.k2 = inv;
+    d.a_stop = fabs(q.a_stop); d.hprime = o.hprime; d.ybar = 0.0; d.z0 = 1.0;
+    d.yoff = (int64_t)g * (k_rays + k2); d.xoff = d.yoff + k_rays;
+    bd[g] = d;
+    ends[4 * (int64_t)g + 0] = o.y1; ends[4 * (int64_t)g + 1] = o.y2; ends[4 * (int64_t)g + 2] = 0.0; ends[4 * (int64_t)g + 3] = o.y_EP;
+}
+
+// ------------------------------------------------------------------------------------
 // ABCD, src/TransferMatrix.jl:1-17.  One thread per lens / per vector.
 // ------------------------------------------------------------------------------------
 __device__ __forceinline__ void mm2(const double* A, const double* B, double* C)

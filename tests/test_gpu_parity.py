@@ -719,6 +719,29 @@ def test_tolerance_run_config5_pipeline(hip_engine, oracle_engine):
         batch.tolerance_run(mats[:2], cm.DG_A, cm.DG_H, fields=(1.01,), engine=hip_engine)
 
 
+def test_spot_batch_single_call_matches_staged_pipeline(hip_engine):
+    """ort_spot_batch_f64 (solve -> aim -> axes -> trace -> statistics in one C call, every
+    intermediate device-resident) against the staged host-driven route of `tolerance_run`: same
+    kernels, so first-order results are bit-identical and the spot sizes differ only by the
+    device-vs-host tan() of the field angle (<= 1 ulp on u)."""
+    from opticalraytracing_jl_amd import batch, workloads
+    mats = workloads.config5(None, ninst=300)
+    fields = (0.0, 0.7, 1.0)
+    a = batch.tolerance_run(mats, cm.DG_A, cm.DG_H, fields=fields, k_rays=32, engine=hip_engine)
+    b = batch.spot_batch(mats, cm.DG_A, cm.DG_H, fields=fields, k_rays=32, engine=hip_engine)
+    for k in ("f", "BFD", "EP_t", "W040", "W131", "W222", "y_marg", "chief_u_end"):
+        assert np.array_equal(a[k], b[k]), k
+    assert np.array_equal(a["stop"], b["stop"])
+    assert np.array_equal(a["count"], b["count"])
+    assert np.all(np.abs(a["rms"] - b["rms"]) <= 1e-12 * np.maximum(a["rms"], 1e-3))
+    with pytest.raises(ort.DomainError):
+        batch.spot_batch(mats[:2], cm.DG_A, cm.DG_H, fields=(1.01,), engine=hip_engine)
+    from opticalraytracing_jl_amd import _capi
+    bad = mats[:2].copy(); bad[:, -1, 1] = 3.0
+    with pytest.raises(_capi.OrtError):
+        batch.spot_batch(bad, cm.DG_A, cm.DG_H, engine=hip_engine)
+
+
 def test_device_axes_match_host_range(hip_engine):
     """ort_make_axes_f64 == api.linrange_batch bit for bit (same double-double algorithm), incl. the
     dyadic tie (81/108) that separates an approximate lerp from the exactly rounded one."""
