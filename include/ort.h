@@ -166,6 +166,12 @@ int ort_full_trace_f64(ort_ctx *ctx, const ort_system *sys, int nb, const ort_bu
                        const double *axes, int64_t axes_len, int ny, int nx,
                        double *ex, double *ey, double *rho, double *theta,
                        int64_t *count, double *rms, unsigned flags);
+/* Float32 rays (BASELINE config 5 names Float32): the trace, the stop test and the error vectors are
+ * binary32; the centroid and RMS are still accumulated in binary64.                              */
+int ort_full_trace_f32(ort_ctx *ctx, const ort_system *sys, int nb, const ort_bundle *bundles,
+                       const float *axes, int64_t axes_len, int ny, int nx,
+                       float *ex, float *ey, float *rho, float *theta,
+                       int64_t *count, double *rms, unsigned flags);
 
 /* ---- meridional real-ray trace: raytrace(surfaces, y, U, RealRay; K, p) ---------------
  * src/RayTracing.jl:145-169.  y_out, U_out, ts_out : [rows][ld] (row 0 = input ray;
@@ -226,6 +232,11 @@ int ort_first_order_f64(ort_ctx *ctx, int nsys, int rows, const double *R, const
  * hprime : [nsys]; fields : [nfields]; count, rms : [nsys][nfields]; fo_out : [nsys] or NULL.
  * The last thickness of every prescription must be 0 (image space), as in the reference's tests. */
 int ort_spot_batch_f64(ort_ctx *ctx, int nsys, int rows, const double *R, const double *t, const double *n,
+                       const double *a, const double *hprime, int nfields, const double *fields, int k_rays,
+                       ort_first_order *fo_out, int64_t *count, double *rms, unsigned flags);
+/* same call with the pupil-grid trace in Float32 (solve and aiming stay Float64: they are O(rows)
+ * per system and decide the grid end points).                                                     */
+int ort_spot_batch_f32(ort_ctx *ctx, int nsys, int rows, const double *R, const double *t, const double *n,
                        const double *a, const double *hprime, int nfields, const double *fields, int k_rays,
                        ort_first_order *fo_out, int64_t *count, double *rms, unsigned flags);
 

@@ -156,13 +156,15 @@ def tolerance_run(mats: np.ndarray, a, hprime, fields: Sequence[float] = (0.0,),
 
 
 def spot_batch(mats: np.ndarray, a, hprime, fields: Sequence[float] = (0.0,), k_rays: int = SPOT_RAYS,
-               engine=None) -> Dict[str, np.ndarray]:
+               engine=None, dtype=np.float64) -> Dict[str, np.ndarray]:
     """`tolerance_run` as ONE C call (`ort_spot_batch_f64`): solve -> aiming -> pupil axes -> grid trace
     -> spot statistics chained on the context's stream with every intermediate (first-order results,
     forward / reversed / extended tables, aiming requests, bundles, axes) built and kept on the GPU.
     In: 3 x [ninst][rows] prescriptions + semi-diameters; out: first-order struct per instance and
-    16 B (count, rms) per (instance, field)."""
+    16 B (count, rms) per (instance, field).  dtype = np.float32 traces the pupil grid in binary32
+    (BASELINE config 5); solve, aiming and the statistics stay binary64."""
     eng = _eng(engine)
+    fn = eng.ctx.lib.ort_spot_batch_f64 if np.dtype(dtype) == np.float64 else eng.ctx.lib.ort_spot_batch_f32
     mats = np.ascontiguousarray(mats, dtype=np.float64)
     ninst, rows, _ = mats.shape
     fields = np.ascontiguousarray(np.abs(np.asarray(fields, dtype=np.float64)))
@@ -172,7 +174,7 @@ def spot_batch(mats: np.ndarray, a, hprime, fields: Sequence[float] = (0.0,), k_
     hp = np.ascontiguousarray(np.broadcast_to(np.asarray(hprime, dtype=np.float64), (ninst,)))
     fo = (_capi.ort_first_order * ninst)()
     count = np.zeros(ninst * nf, dtype=np.int64); rms = np.zeros(ninst * nf)
-    rc = eng.ctx.lib.ort_spot_batch_f64(eng.ctx.h, ninst, rows, _capi.ptr(R), _capi.ptr(t), _capi.ptr(n), _capi.ptr(a_arr),
+    rc = fn(eng.ctx.h, ninst, rows, _capi.ptr(R), _capi.ptr(t), _capi.ptr(n), _capi.ptr(a_arr),
                                         _capi.ptr(hp), nf, _capi.ptr(fields), int(k_rays), fo, _capi.ptr(count),
                                         _capi.ptr(rms), eng.base_flags)
     if rc == _capi.ORT_EDOMAIN:

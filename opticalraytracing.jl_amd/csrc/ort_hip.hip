@@ -392,6 +392,202 @@ int trace_list_impl(ort_ctx* ctx, const ort_system* sys, int isys, int64_t nrays
     return ORT_OK;
 }
 
+template <typename T>
+int full_trace_impl(ort_ctx* ctx, const ort_system* sys, int nb, const ort_bundle* bundles,
+                    const T* axes, int64_t axes_len, int ny, int nx, T* ex, T* ey, T* rho, T* theta,
+                    int64_t* count, double* rms, unsigned flags)
+{
+    int rc = check_ctx(ctx); if (rc) return rc;
+    rc = check_sys(ctx, sys); if (rc) return rc;
+    if (nb <= 0 || !bundles || !axes || ny <= 0 || nx <= 0 || !count || !rms)
+        return fail(ORT_EINVAL, "bad full_trace arguments");
+    const bool stats_only = !ex && !ey && !rho && !theta;        // spot statistics without the error vectors
+    if (!stats_only && (!ex || !ey || !rho || !theta)) return fail(ORT_EINVAL, "ex, ey, rho, theta: all or none");
+    const int S = sys->rows - 1;
+    for (int b = 0; b < nb; ++b)
+        if (bundles[b].stop <= 0 || bundles[b].stop > S) return fail(ORT_EINVAL, "bundle %d: full_trace needs a stop index in 1..%d", b, S);
+    const int64_t rpb = (int64_t)ny * nx;
+    if (rpb > 0x7fffffffLL - kTile) return fail(ORT_EINVAL, "bundle of %lld rays is too large (max 2^31)", (long long)rpb);
+    const int64_t N = rpb * nb;
+    const bool devp = flags & ORT_DEVICE_PTRS;
+
+    TraceParams<T> p;
+    memset(&p, 0, sizeof p);
+    p.recs = Sel<T>::rec(sys); p.coefs = Sel<T>::coef(sys); p.S = S; p.ncoef = sys->ncoef;
+    rc = upload_bundles<T>(ctx, sys, nb, bundles, ny, nx, axes_len, flags, &p.bundles); if (rc) return rc;
+    p.ny = ny; p.nx = nx; p.rpb = rpb; p.tiles_per_bundle = (int)((rpb + kTile - 1) / kTile);
+    p.raybasis = (flags & ORT_RAYBASIS) ? 1 : 0;
+    const int64_t tiles = (int64_t)nb * p.tiles_per_bundle;
+    if (devp) p.axes = axes;
+    else { rc = to_device<T>(ctx, SL_AXES, axes, (size_t)axes_len, &p.axes); if (rc) return rc; }
+
+    rc = dev_out<int32_t>(ctx, SL_TCNT, (size_t)tiles, &p.tile_cnt); if (rc) return rc;
+    rc = dev_out<double>(ctx, SL_TSX, (size_t)tiles, &p.tile_sx); if (rc) return rc;
+    rc = dev_out<double>(ctx, SL_TSY, (size_t)tiles, &p.tile_sy); if (rc) return rc;
+    rc = dev_out<double>(ctx, SL_TRM, (size_t)tiles, &p.tile_rmax); if (rc) return rc;
+    if (stats_only) {
+        // one pass: trace + stop filter + per-tile (n, mean, M2), merged per bundle — no ray-sized buffer at all
+        rc = dev_out<double>(ctx, SL_TOFF, (size_t)tiles, &p.tile_m2x); if (rc) return rc;
+        rc = dev_out<double>(ctx, SL_TSQ, (size_t)tiles, &p.tile_m2y); if (rc) return rc;
+        int64_t* dcount = count; double* drms = rms;
+        if (!devp) {
+            rc = dev_out<int64_t>(ctx, SL_RES0, (size_t)nb, &dcount); if (rc) return rc;
+            rc = dev_out<double>(ctx, SL_RES1, (size_t)nb, &drms); if (rc) return rc;
+        }
+        rc = launch_trace<T, true, false, false, FT_STATS>(ctx, p, tiles, flags); if (rc) return rc;
+        hipLaunchKernelGGL(k_ft_stats_reduce, dim3((unsigned)nb), dim3(kBlock), 0, ctx->stream,
+                           p.tile_cnt, p.tile_sx, p.tile_sy, p.tile_m2x, p.tile_m2y, p.tile_rmax, p.tiles_per_bundle, dcount, drms);
+        HIP_TRY(hipGetLastError());
+        if (!devp) {
+            rc = from_device<int64_t>(ctx, count, dcount, (size_t)nb); if (rc) return rc;
+            rc = from_device<double>(ctx, rms, drms, (size_t)nb); if (rc) return rc;
+            HIP_TRY(hipStreamSynchronize(ctx->stream));
+        }
+        return ORT_OK;
+    }
+    rc = dev_out<T>(ctx, SL_WEX, (size_t)N, &p.w_ex); if (rc) return rc;
+    rc = dev_out<T>(ctx, SL_WEY, (size_t)N, &p.w_ey); if (rc) return rc;
+    rc = dev_out<T>(ctx, SL_WR, (size_t)N, &p.w_r); if (rc) return rc;
+    rc = dev_out<T>(ctx, SL_WTH, (size_t)N, &p.w_th); if (rc) return rc;
+    int64_t* tile_off; double* tile_sq; FtBundleAgg* agg;
+    rc = dev_out<int64_t>(ctx, SL_TOFF, (size_t)tiles, &tile_off); if (rc) return rc;
+    rc = dev_out<double>(ctx, SL_TSQ, (size_t)tiles, &tile_sq); if (rc) return rc;
+    rc = dev_out<FtBundleAgg>(ctx, SL_AGG, (size_t)nb, &agg); if (rc) return rc;
+
+    T *dex = ex, *dey = ey, *drho = rho, *dth = theta; int64_t* dcount = count; double* drms = rms;
+    if (!devp) {
+        if (!stats_only) {
+            rc = dev_out<T>(ctx, SL_OUT0, (size_t)2 * N, &dex); if (rc) return rc;
+            rc = dev_out<T>(ctx, SL_OUT1, (size_t)2 * N, &dey); if (rc) return rc;
+            rc = dev_out<T>(ctx, SL_OUT2, (size_t)2 * N, &drho); if (rc) return rc;
+            rc = dev_out<T>(ctx, SL_OUT4, (size_t)2 * N, &dth); if (rc) return rc;
+        }
+        rc = dev_out<int64_t>(ctx, SL_RES0, (size_t)nb, &dcount); if (rc) return rc;
+        rc = dev_out<double>(ctx, SL_RES1, (size_t)nb, &drms); if (rc) return rc;
+    }
+    rc = launch_trace<T, true, false, false, FT_FULL>(ctx, p, tiles, flags); if (rc) return rc;
+    hipLaunchKernelGGL(k_ft_scan, dim3((unsigned)nb), dim3(kBlock), 0, ctx->stream,
+                       p.tile_cnt, p.tile_sx, p.tile_sy, p.tile_rmax, p.tiles_per_bundle, tile_off, agg);
+    HIP_TRY(hipGetLastError());
+    hipLaunchKernelGGL((k_ft_scatter<T>), dim3((unsigned)tiles), dim3(kBlock), 0, ctx->stream,
+                       p.w_ex, p.w_ey, p.w_r, p.w_th, rpb, p.tiles_per_bundle, tile_off, agg,
+                       dex, dey, drho, dth, tile_sq);
+    HIP_TRY(hipGetLastError());
+    hipLaunchKernelGGL(k_ft_finalize, dim3((unsigned)nb), dim3(kBlock), 0, ctx->stream,
+                       tile_sq, p.tiles_per_bundle, agg, dcount, drms);
+    HIP_TRY(hipGetLastError());
+    if (!devp) {
+        rc = from_device<int64_t>(ctx, count, dcount, (size_t)nb); if (rc) return rc;
+        rc = from_device<double>(ctx, rms, drms, (size_t)nb); if (rc) return rc;
+        HIP_TRY(hipStreamSynchronize(ctx->stream));
+        for (int b = 0; b < nb && !stats_only; ++b) {
+            const size_t off = (size_t)b * 2 * rpb, cnt = (size_t)count[b];
+            if (!cnt) continue;
+            rc = from_device<T>(ctx, ex + off, dex + off, cnt); if (rc) return rc;
+            rc = from_device<T>(ctx, ey + off, dey + off, cnt); if (rc) return rc;
+            rc = from_device<T>(ctx, rho + off, drho + off, cnt); if (rc) return rc;
+            rc = from_device<T>(ctx, theta + off, dth + off, cnt); if (rc) return rc;
+        }
+        HIP_TRY(hipStreamSynchronize(ctx->stream));
+    }
+    return ORT_OK;
+}
+
+template <typename T>
+int spot_batch_impl(ort_ctx* ctx, int nsys, int rows, const double* R, const double* t, const double* n,
+                       const double* a, const double* hprime, int nfields, const double* fields, int k_rays,
+                       ort_first_order* fo_out, int64_t* count, double* rms, unsigned flags)
+{
+    int rc = check_ctx(ctx); if (rc) return rc;
+    if (nsys <= 0 || rows < 2 || rows + 1 > ORT_MAX_ROWS || !R || !t || !n || !a || !hprime || nfields <= 0 || !fields ||
+        k_rays < 2 || !count || !rms)
+        return fail(ORT_EINVAL, "bad spot_batch arguments");
+    const bool devp = flags & ORT_DEVICE_PTRS;
+    if (!devp) for (int f = 0; f < nfields; ++f)
+        if (!(std::fabs(fields[f]) <= 1.0)) return fail(ORT_EDOMAIN, "DomainError with %g: Domain: |H| <= 1.0", fields[f]);
+    const int64_t na64 = (int64_t)nsys * nfields;
+    if (na64 > 0x7fffffffLL / 4) return fail(ORT_EINVAL, "too many (system, field) pairs");
+    const int na = (int)na64, k2 = k_rays / 2, S = rows;          // extended system: rows + 1 rows -> S = rows iterations
+    const int64_t rpb = (int64_t)k_rays * k2;
+    if (rpb > 0x7fffffffLL - kTile) return fail(ORT_EINVAL, "bundle of %lld rays is too large (max 2^31)", (long long)rpb);
+    const size_t nr = (size_t)nsys * rows;
+    if (!devp) for (int s = 0; s < nsys; ++s)
+        if (t[(size_t)s * rows + rows - 1] != 0.0)
+            return fail(ORT_EINVAL, "system %d: spot_batch expects a last thickness of 0 (image space)", s);
+    const double *dR = R, *dt = t, *dn = n, *da = a, *dh = hprime, *dfields = fields;
+    if (!devp) {
+        rc = to_device<double>(ctx, SL_IN0, R, nr, &dR); if (rc) return rc;
+        rc = to_device<double>(ctx, SL_IN1, t, nr, &dt); if (rc) return rc;
+        rc = to_device<double>(ctx, SL_IN2, n, nr, &dn); if (rc) return rc;
+        rc = to_device<double>(ctx, SL_SB_A, a, (size_t)nsys * (rows - 1), &da); if (rc) return rc;
+        rc = to_device<double>(ctx, SL_SB_HP, hprime, (size_t)nsys, &dh); if (rc) return rc;
+        rc = to_device<double>(ctx, SL_SB_FIELDS, fields, (size_t)nfields, &dfields); if (rc) return rc;
+    }
+    FirstOrderOut* d_fo; SurfRec<T>* d_rec; MerSurf *d_mf, *d_mr; double *d_tlf, *d_tlr, *d_ends; T* d_axes;
+    AimIn* d_ain; AimOut* d_aout; DevBundle<T>* d_bd; int* d_flag;
+    rc = dev_out<FirstOrderOut>(ctx, SL_SB_FO, (size_t)nsys, &d_fo); if (rc) return rc;
+    rc = dev_out<SurfRec<T>>(ctx, SL_SB_REC, nr, &d_rec); if (rc) return rc;
+    rc = dev_out<MerSurf>(ctx, SL_SB_MF, (size_t)nsys * (rows - 1), &d_mf); if (rc) return rc;
+    rc = dev_out<MerSurf>(ctx, SL_SB_MR, (size_t)nsys * (rows - 1), &d_mr); if (rc) return rc;
+    rc = dev_out<double>(ctx, SL_SB_TLF, (size_t)nsys, &d_tlf); if (rc) return rc;
+    rc = dev_out<double>(ctx, SL_SB_TLR, (size_t)nsys, &d_tlr); if (rc) return rc;
+    rc = dev_out<AimIn>(ctx, SL_SB_AIN, (size_t)na, &d_ain); if (rc) return rc;
+    rc = dev_out<AimOut>(ctx, SL_SB_AOUT, (size_t)na, &d_aout); if (rc) return rc;
+    rc = dev_out<DevBundle<T>>(ctx, SL_BUNDLES, (size_t)na, &d_bd); if (rc) return rc;
+    ctx->bundle_cache.clear();                                  // SL_BUNDLES no longer mirrors a host array
+    rc = dev_out<double>(ctx, SL_SB_ENDS, (size_t)na * 4, &d_ends); if (rc) return rc;
+    rc = dev_out<T>(ctx, SL_AXES, (size_t)na * (k_rays + k2), &d_axes); if (rc) return rc;
+    rc = dev_out<int>(ctx, SL_SB_FLAG, 1, &d_flag); if (rc) return rc;
+    TraceParams<T> p;
+    memset(&p, 0, sizeof p);
+    p.recs = d_rec; p.coefs = nullptr; p.S = S; p.ncoef = 0; p.bundles = d_bd; p.axes = d_axes;
+    p.ny = k_rays; p.nx = k2; p.rpb = rpb; p.tiles_per_bundle = (int)((rpb + kTile - 1) / kTile);
+    const int64_t tiles = (int64_t)na * p.tiles_per_bundle;
+    if (tiles > 0x7fffffffLL) return fail(ORT_EINVAL, "launch too large");
+    rc = dev_out<int32_t>(ctx, SL_TCNT, (size_t)tiles, &p.tile_cnt); if (rc) return rc;
+    rc = dev_out<double>(ctx, SL_TSX, (size_t)tiles, &p.tile_sx); if (rc) return rc;
+    rc = dev_out<double>(ctx, SL_TSY, (size_t)tiles, &p.tile_sy); if (rc) return rc;
+    rc = dev_out<double>(ctx, SL_TRM, (size_t)tiles, &p.tile_rmax); if (rc) return rc;
+    rc = dev_out<double>(ctx, SL_TOFF, (size_t)tiles, &p.tile_m2x); if (rc) return rc;
+    rc = dev_out<double>(ctx, SL_TSQ, (size_t)tiles, &p.tile_m2y); if (rc) return rc;
+    int64_t* dcount = count; double* drms = rms;
+    if (!devp) {
+        rc = dev_out<int64_t>(ctx, SL_RES0, (size_t)na, &dcount); if (rc) return rc;
+        rc = dev_out<double>(ctx, SL_RES1, (size_t)na, &drms); if (rc) return rc;
+    }
+    hipStream_t st = ctx->stream;
+    auto nblk = [](int64_t n, int b) { return dim3((unsigned)((n + b - 1) / b)); };
+    HIP_TRY(hipMemsetAsync(d_flag, 0, sizeof(int), st));
+    // solve (RayTracing.jl:302-323) -> tables -> aiming requests -> aiming (:223-296) -> bundles + axis end
+    // points (PupilSampling.jl:94-122) -> axes -> trace + stop filter + tile moments -> per-bundle RMS
+    hipLaunchKernelGGL(k_first_order, nblk(nsys, 64), dim3(64), 0, st, nsys, rows, dR, dt, dn, da, (const double*)nullptr, dh,
+                       587.5618e-6, d_fo);
+    hipLaunchKernelGGL((k_build_tables<T>), nblk((int64_t)nr, kBlock), dim3(kBlock), 0, st, nsys, rows, dR, dt, dn, d_fo, d_rec, d_mf, d_mr,
+                       d_tlf, d_tlr);
+    hipLaunchKernelGGL(k_build_aim, nblk(na, kBlock), dim3(kBlock), 0, st, nsys, nfields, rows, d_fo, da, dfields, d_ain);
+    hipLaunchKernelGGL(k_aim, nblk(na, 64), dim3(64), 0, st, na, d_ain, d_mf, (const double*)nullptr, d_tlf, d_mr,
+                       (const double*)nullptr, d_tlr, rows - 1, 0, d_aout);
+    hipLaunchKernelGGL((k_build_bundles<T>), nblk(na, kBlock), dim3(kBlock), 0, st, na, k_rays, k2, d_ain, d_aout, d_bd, d_ends, d_flag);
+    hipLaunchKernelGGL((k_make_axes<T>), nblk((int64_t)na * (k_rays + k2), kBlock), dim3(kBlock), 0, st, na, k_rays, k2, d_ends, d_axes);
+    HIP_TRY(hipGetLastError());
+    rc = launch_trace<T, true, false, false, FT_STATS>(ctx, p, tiles, flags); if (rc) return rc;
+    hipLaunchKernelGGL(k_ft_stats_reduce, dim3((unsigned)na), dim3(kBlock), 0, st,
+                       p.tile_cnt, p.tile_sx, p.tile_sy, p.tile_m2x, p.tile_m2y, p.tile_rmax, p.tiles_per_bundle, dcount, drms);
+    HIP_TRY(hipGetLastError());
+    if (devp) {
+        if (fo_out) HIP_TRY(hipMemcpyAsync(fo_out, d_fo, (size_t)nsys * sizeof(FirstOrderOut), hipMemcpyDeviceToDevice, st));
+        return ORT_OK;       // asynchronous; a failed aiming shows as NaN RMS of that bundle (and ok = 0 upstream)
+    }
+    int flag = 0;
+    HIP_TRY(hipMemcpyAsync(&flag, d_flag, sizeof(int), hipMemcpyDeviceToHost, st));
+    if (fo_out) { rc = from_device<FirstOrderOut>(ctx, reinterpret_cast<FirstOrderOut*>(fo_out), d_fo, (size_t)nsys); if (rc) return rc; }
+    rc = from_device<int64_t>(ctx, count, dcount, (size_t)na); if (rc) return rc;
+    rc = from_device<double>(ctx, rms, drms, (size_t)na); if (rc) return rc;
+    HIP_TRY(hipStreamSynchronize(st));
+    if (flag) return fail(ORT_EHIP, "ray aiming did not converge for at least one (system, field) pair");
+    return ORT_OK;
+}
+
 }  // namespace
 
 // ======================================================================================
@@ -612,7 +808,7 @@ int ort_make_axes_f64(ort_ctx* ctx, int nb, int ny, int nx, const double* ends, 
     }
     const int64_t blocks = (total + kBlock - 1) / kBlock;
     if (blocks > 0x7fffffffLL) return fail(ORT_EINVAL, "launch too large");
-    hipLaunchKernelGGL(k_make_axes, dim3((unsigned)blocks), dim3(kBlock), 0, ctx->stream, nb, ny, nx, dends, daxes);
+    hipLaunchKernelGGL((k_make_axes<double>), dim3((unsigned)blocks), dim3(kBlock), 0, ctx->stream, nb, ny, nx, dends, daxes);
     HIP_TRY(hipGetLastError());
     if (!devp) {
         rc = from_device<double>(ctx, axes, daxes, (size_t)total); if (rc) return rc;
@@ -627,101 +823,15 @@ int ort_full_trace_f64(ort_ctx* ctx, const ort_system* sys, int nb, const ort_bu
                        double* ex, double* ey, double* rho, double* theta,
                        int64_t* count, double* rms, unsigned flags)
 {
-    typedef double T;
-    int rc = check_ctx(ctx); if (rc) return rc;
-    rc = check_sys(ctx, sys); if (rc) return rc;
-    if (nb <= 0 || !bundles || !axes || ny <= 0 || nx <= 0 || !count || !rms)
-        return fail(ORT_EINVAL, "bad full_trace arguments");
-    const bool stats_only = !ex && !ey && !rho && !theta;        // spot statistics without the error vectors
-    if (!stats_only && (!ex || !ey || !rho || !theta)) return fail(ORT_EINVAL, "ex, ey, rho, theta: all or none");
-    const int S = sys->rows - 1;
-    for (int b = 0; b < nb; ++b)
-        if (bundles[b].stop <= 0 || bundles[b].stop > S) return fail(ORT_EINVAL, "bundle %d: full_trace needs a stop index in 1..%d", b, S);
-    const int64_t rpb = (int64_t)ny * nx;
-    if (rpb > 0x7fffffffLL - kTile) return fail(ORT_EINVAL, "bundle of %lld rays is too large (max 2^31)", (long long)rpb);
-    const int64_t N = rpb * nb;
-    const bool devp = flags & ORT_DEVICE_PTRS;
+    return full_trace_impl<double>(ctx, sys, nb, bundles, axes, axes_len, ny, nx, ex, ey, rho, theta, count, rms, flags);
+}
 
-    TraceParams<T> p;
-    memset(&p, 0, sizeof p);
-    p.recs = sys->rec64; p.coefs = sys->coef64; p.S = S; p.ncoef = sys->ncoef;
-    rc = upload_bundles<T>(ctx, sys, nb, bundles, ny, nx, axes_len, flags, &p.bundles); if (rc) return rc;
-    p.ny = ny; p.nx = nx; p.rpb = rpb; p.tiles_per_bundle = (int)((rpb + kTile - 1) / kTile);
-    p.raybasis = (flags & ORT_RAYBASIS) ? 1 : 0;
-    const int64_t tiles = (int64_t)nb * p.tiles_per_bundle;
-    if (devp) p.axes = axes;
-    else { rc = to_device<T>(ctx, SL_AXES, axes, (size_t)axes_len, &p.axes); if (rc) return rc; }
-
-    rc = dev_out<int32_t>(ctx, SL_TCNT, (size_t)tiles, &p.tile_cnt); if (rc) return rc;
-    rc = dev_out<double>(ctx, SL_TSX, (size_t)tiles, &p.tile_sx); if (rc) return rc;
-    rc = dev_out<double>(ctx, SL_TSY, (size_t)tiles, &p.tile_sy); if (rc) return rc;
-    rc = dev_out<double>(ctx, SL_TRM, (size_t)tiles, &p.tile_rmax); if (rc) return rc;
-    if (stats_only) {
-        // one pass: trace + stop filter + per-tile (n, mean, M2), merged per bundle — no ray-sized buffer at all
-        rc = dev_out<double>(ctx, SL_TOFF, (size_t)tiles, &p.tile_m2x); if (rc) return rc;
-        rc = dev_out<double>(ctx, SL_TSQ, (size_t)tiles, &p.tile_m2y); if (rc) return rc;
-        int64_t* dcount = count; double* drms = rms;
-        if (!devp) {
-            rc = dev_out<int64_t>(ctx, SL_RES0, (size_t)nb, &dcount); if (rc) return rc;
-            rc = dev_out<double>(ctx, SL_RES1, (size_t)nb, &drms); if (rc) return rc;
-        }
-        rc = launch_trace<T, true, false, false, FT_STATS>(ctx, p, tiles, flags); if (rc) return rc;
-        hipLaunchKernelGGL(k_ft_stats_reduce, dim3((unsigned)nb), dim3(kBlock), 0, ctx->stream,
-                           p.tile_cnt, p.tile_sx, p.tile_sy, p.tile_m2x, p.tile_m2y, p.tile_rmax, p.tiles_per_bundle, dcount, drms);
-        HIP_TRY(hipGetLastError());
-        if (!devp) {
-            rc = from_device<int64_t>(ctx, count, dcount, (size_t)nb); if (rc) return rc;
-            rc = from_device<double>(ctx, rms, drms, (size_t)nb); if (rc) return rc;
-            HIP_TRY(hipStreamSynchronize(ctx->stream));
-        }
-        return ORT_OK;
-    }
-    rc = dev_out<T>(ctx, SL_WEX, (size_t)N, &p.w_ex); if (rc) return rc;
-    rc = dev_out<T>(ctx, SL_WEY, (size_t)N, &p.w_ey); if (rc) return rc;
-    rc = dev_out<T>(ctx, SL_WR, (size_t)N, &p.w_r); if (rc) return rc;
-    rc = dev_out<T>(ctx, SL_WTH, (size_t)N, &p.w_th); if (rc) return rc;
-    int64_t* tile_off; double* tile_sq; FtBundleAgg* agg;
-    rc = dev_out<int64_t>(ctx, SL_TOFF, (size_t)tiles, &tile_off); if (rc) return rc;
-    rc = dev_out<double>(ctx, SL_TSQ, (size_t)tiles, &tile_sq); if (rc) return rc;
-    rc = dev_out<FtBundleAgg>(ctx, SL_AGG, (size_t)nb, &agg); if (rc) return rc;
-
-    T *dex = ex, *dey = ey, *drho = rho, *dth = theta; int64_t* dcount = count; double* drms = rms;
-    if (!devp) {
-        if (!stats_only) {
-            rc = dev_out<T>(ctx, SL_OUT0, (size_t)2 * N, &dex); if (rc) return rc;
-            rc = dev_out<T>(ctx, SL_OUT1, (size_t)2 * N, &dey); if (rc) return rc;
-            rc = dev_out<T>(ctx, SL_OUT2, (size_t)2 * N, &drho); if (rc) return rc;
-            rc = dev_out<T>(ctx, SL_OUT4, (size_t)2 * N, &dth); if (rc) return rc;
-        }
-        rc = dev_out<int64_t>(ctx, SL_RES0, (size_t)nb, &dcount); if (rc) return rc;
-        rc = dev_out<double>(ctx, SL_RES1, (size_t)nb, &drms); if (rc) return rc;
-    }
-    rc = launch_trace<T, true, false, false, FT_FULL>(ctx, p, tiles, flags); if (rc) return rc;
-    hipLaunchKernelGGL(k_ft_scan, dim3((unsigned)nb), dim3(kBlock), 0, ctx->stream,
-                       p.tile_cnt, p.tile_sx, p.tile_sy, p.tile_rmax, p.tiles_per_bundle, tile_off, agg);
-    HIP_TRY(hipGetLastError());
-    hipLaunchKernelGGL((k_ft_scatter<T>), dim3((unsigned)tiles), dim3(kBlock), 0, ctx->stream,
-                       p.w_ex, p.w_ey, p.w_r, p.w_th, rpb, p.tiles_per_bundle, tile_off, agg,
-                       dex, dey, drho, dth, tile_sq);
-    HIP_TRY(hipGetLastError());
-    hipLaunchKernelGGL(k_ft_finalize, dim3((unsigned)nb), dim3(kBlock), 0, ctx->stream,
-                       tile_sq, p.tiles_per_bundle, agg, dcount, drms);
-    HIP_TRY(hipGetLastError());
-    if (!devp) {
-        rc = from_device<int64_t>(ctx, count, dcount, (size_t)nb); if (rc) return rc;
-        rc = from_device<double>(ctx, rms, drms, (size_t)nb); if (rc) return rc;
-        HIP_TRY(hipStreamSynchronize(ctx->stream));
-        for (int b = 0; b < nb && !stats_only; ++b) {
-            const size_t off = (size_t)b * 2 * rpb, cnt = (size_t)count[b];
-            if (!cnt) continue;
-            rc = from_device<T>(ctx, ex + off, dex + off, cnt); if (rc) return rc;
-            rc = from_device<T>(ctx, ey + off, dey + off, cnt); if (rc) return rc;
-            rc = from_device<T>(ctx, rho + off, drho + off, cnt); if (rc) return rc;
-            rc = from_device<T>(ctx, theta + off, dth + off, cnt); if (rc) return rc;
-        }
-        HIP_TRY(hipStreamSynchronize(ctx->stream));
-    }
-    return ORT_OK;
+int ort_full_trace_f32(ort_ctx* ctx, const ort_system* sys, int nb, const ort_bundle* bundles,
+                       const float* axes, int64_t axes_len, int ny, int nx,
+                       float* ex, float* ey, float* rho, float* theta,
+                       int64_t* count, double* rms, unsigned flags)
+{
+    return full_trace_impl<float>(ctx, sys, nb, bundles, axes, axes_len, ny, nx, ex, ey, rho, theta, count, rms, flags);
 }
 
 // --------------------------------------------------------------------------------------
@@ -729,95 +839,14 @@ int ort_spot_batch_f64(ort_ctx* ctx, int nsys, int rows, const double* R, const 
                        const double* a, const double* hprime, int nfields, const double* fields, int k_rays,
                        ort_first_order* fo_out, int64_t* count, double* rms, unsigned flags)
 {
-    typedef double T;
-    int rc = check_ctx(ctx); if (rc) return rc;
-    if (nsys <= 0 || rows < 2 || rows + 1 > ORT_MAX_ROWS || !R || !t || !n || !a || !hprime || nfields <= 0 || !fields ||
-        k_rays < 2 || !count || !rms)
-        return fail(ORT_EINVAL, "bad spot_batch arguments");
-    const bool devp = flags & ORT_DEVICE_PTRS;
-    if (!devp) for (int f = 0; f < nfields; ++f)
-        if (!(std::fabs(fields[f]) <= 1.0)) return fail(ORT_EDOMAIN, "DomainError with %g: Domain: |H| <= 1.0", fields[f]);
-    const int64_t na64 = (int64_t)nsys * nfields;
-    if (na64 > 0x7fffffffLL / 4) return fail(ORT_EINVAL, "too many (system, field) pairs");
-    const int na = (int)na64, k2 = k_rays / 2, S = rows;          // extended system: rows + 1 rows -> S = rows iterations
-    const int64_t rpb = (int64_t)k_rays * k2;
-    if (rpb > 0x7fffffffLL - kTile) return fail(ORT_EINVAL, "bundle of %lld rays is too large (max 2^31)", (long long)rpb);
-    const size_t nr = (size_t)nsys * rows;
-    if (!devp) for (int s = 0; s < nsys; ++s)
-        if (t[(size_t)s * rows + rows - 1] != 0.0)
-            return fail(ORT_EINVAL, "system %d: spot_batch expects a last thickness of 0 (image space)", s);
-    const double *dR = R, *dt = t, *dn = n, *da = a, *dh = hprime, *dfields = fields;
-    if (!devp) {
-        rc = to_device<double>(ctx, SL_IN0, R, nr, &dR); if (rc) return rc;
-        rc = to_device<double>(ctx, SL_IN1, t, nr, &dt); if (rc) return rc;
-        rc = to_device<double>(ctx, SL_IN2, n, nr, &dn); if (rc) return rc;
-        rc = to_device<double>(ctx, SL_SB_A, a, (size_t)nsys * (rows - 1), &da); if (rc) return rc;
-        rc = to_device<double>(ctx, SL_SB_HP, hprime, (size_t)nsys, &dh); if (rc) return rc;
-        rc = to_device<double>(ctx, SL_SB_FIELDS, fields, (size_t)nfields, &dfields); if (rc) return rc;
-    }
-    FirstOrderOut* d_fo; SurfRec<T>* d_rec; MerSurf *d_mf, *d_mr; double *d_tlf, *d_tlr, *d_ends, *d_axes;
-    AimIn* d_ain; AimOut* d_aout; DevBundle<T>* d_bd; int* d_flag;
-    rc = dev_out<FirstOrderOut>(ctx, SL_SB_FO, (size_t)nsys, &d_fo); if (rc) return rc;
-    rc = dev_out<SurfRec<T>>(ctx, SL_SB_REC, nr, &d_rec); if (rc) return rc;
-    rc = dev_out<MerSurf>(ctx, SL_SB_MF, (size_t)nsys * (rows - 1), &d_mf); if (rc) return rc;
-    rc = dev_out<MerSurf>(ctx, SL_SB_MR, (size_t)nsys * (rows - 1), &d_mr); if (rc) return rc;
-    rc = dev_out<double>(ctx, SL_SB_TLF, (size_t)nsys, &d_tlf); if (rc) return rc;
-    rc = dev_out<double>(ctx, SL_SB_TLR, (size_t)nsys, &d_tlr); if (rc) return rc;
-    rc = dev_out<AimIn>(ctx, SL_SB_AIN, (size_t)na, &d_ain); if (rc) return rc;
-    rc = dev_out<AimOut>(ctx, SL_SB_AOUT, (size_t)na, &d_aout); if (rc) return rc;
-    rc = dev_out<DevBundle<T>>(ctx, SL_BUNDLES, (size_t)na, &d_bd); if (rc) return rc;
-    ctx->bundle_cache.clear();                                  // SL_BUNDLES no longer mirrors a host array
-    rc = dev_out<double>(ctx, SL_SB_ENDS, (size_t)na * 4, &d_ends); if (rc) return rc;
-    rc = dev_out<double>(ctx, SL_AXES, (size_t)na * (k_rays + k2), &d_axes); if (rc) return rc;
-    rc = dev_out<int>(ctx, SL_SB_FLAG, 1, &d_flag); if (rc) return rc;
-    TraceParams<T> p;
-    memset(&p, 0, sizeof p);
-    p.recs = d_rec; p.coefs = nullptr; p.S = S; p.ncoef = 0; p.bundles = d_bd; p.axes = d_axes;
-    p.ny = k_rays; p.nx = k2; p.rpb = rpb; p.tiles_per_bundle = (int)((rpb + kTile - 1) / kTile);
-    const int64_t tiles = (int64_t)na * p.tiles_per_bundle;
-    if (tiles > 0x7fffffffLL) return fail(ORT_EINVAL, "launch too large");
-    rc = dev_out<int32_t>(ctx, SL_TCNT, (size_t)tiles, &p.tile_cnt); if (rc) return rc;
-    rc = dev_out<double>(ctx, SL_TSX, (size_t)tiles, &p.tile_sx); if (rc) return rc;
-    rc = dev_out<double>(ctx, SL_TSY, (size_t)tiles, &p.tile_sy); if (rc) return rc;
-    rc = dev_out<double>(ctx, SL_TRM, (size_t)tiles, &p.tile_rmax); if (rc) return rc;
-    rc = dev_out<double>(ctx, SL_TOFF, (size_t)tiles, &p.tile_m2x); if (rc) return rc;
-    rc = dev_out<double>(ctx, SL_TSQ, (size_t)tiles, &p.tile_m2y); if (rc) return rc;
-    int64_t* dcount = count; double* drms = rms;
-    if (!devp) {
-        rc = dev_out<int64_t>(ctx, SL_RES0, (size_t)na, &dcount); if (rc) return rc;
-        rc = dev_out<double>(ctx, SL_RES1, (size_t)na, &drms); if (rc) return rc;
-    }
-    hipStream_t st = ctx->stream;
-    auto nblk = [](int64_t n, int b) { return dim3((unsigned)((n + b - 1) / b)); };
-    HIP_TRY(hipMemsetAsync(d_flag, 0, sizeof(int), st));
-    // solve (RayTracing.jl:302-323) -> tables -> aiming requests -> aiming (:223-296) -> bundles + axis end
-    // points (PupilSampling.jl:94-122) -> axes -> trace + stop filter + tile moments -> per-bundle RMS
-    hipLaunchKernelGGL(k_first_order, nblk(nsys, 64), dim3(64), 0, st, nsys, rows, dR, dt, dn, da, (const double*)nullptr, dh,
-                       587.5618e-6, d_fo);
-    hipLaunchKernelGGL(k_build_tables, nblk((int64_t)nr, kBlock), dim3(kBlock), 0, st, nsys, rows, dR, dt, dn, d_fo, d_rec, d_mf, d_mr,
-                       d_tlf, d_tlr);
-    hipLaunchKernelGGL(k_build_aim, nblk(na, kBlock), dim3(kBlock), 0, st, nsys, nfields, rows, d_fo, da, dfields, d_ain);
-    hipLaunchKernelGGL(k_aim, nblk(na, 64), dim3(64), 0, st, na, d_ain, d_mf, (const double*)nullptr, d_tlf, d_mr,
-                       (const double*)nullptr, d_tlr, rows - 1, 0, d_aout);
-    hipLaunchKernelGGL(k_build_bundles, nblk(na, kBlock), dim3(kBlock), 0, st, na, k_rays, k2, d_ain, d_aout, d_bd, d_ends, d_flag);
-    hipLaunchKernelGGL(k_make_axes, nblk((int64_t)na * (k_rays + k2), kBlock), dim3(kBlock), 0, st, na, k_rays, k2, d_ends, d_axes);
-    HIP_TRY(hipGetLastError());
-    rc = launch_trace<T, true, false, false, FT_STATS>(ctx, p, tiles, flags); if (rc) return rc;
-    hipLaunchKernelGGL(k_ft_stats_reduce, dim3((unsigned)na), dim3(kBlock), 0, st,
-                       p.tile_cnt, p.tile_sx, p.tile_sy, p.tile_m2x, p.tile_m2y, p.tile_rmax, p.tiles_per_bundle, dcount, drms);
-    HIP_TRY(hipGetLastError());
-    if (devp) {
-        if (fo_out) HIP_TRY(hipMemcpyAsync(fo_out, d_fo, (size_t)nsys * sizeof(FirstOrderOut), hipMemcpyDeviceToDevice, st));
-        return ORT_OK;       // asynchronous; a failed aiming shows as NaN RMS of that bundle (and ok = 0 upstream)
-    }
-    int flag = 0;
-    HIP_TRY(hipMemcpyAsync(&flag, d_flag, sizeof(int), hipMemcpyDeviceToHost, st));
-    if (fo_out) { rc = from_device<FirstOrderOut>(ctx, reinterpret_cast<FirstOrderOut*>(fo_out), d_fo, (size_t)nsys); if (rc) return rc; }
-    rc = from_device<int64_t>(ctx, count, dcount, (size_t)na); if (rc) return rc;
-    rc = from_device<double>(ctx, rms, drms, (size_t)na); if (rc) return rc;
-    HIP_TRY(hipStreamSynchronize(st));
-    if (flag) return fail(ORT_EHIP, "ray aiming did not converge for at least one (system, field) pair");
-    return ORT_OK;
+    return spot_batch_impl<double>(ctx, nsys, rows, R, t, n, a, hprime, nfields, fields, k_rays, fo_out, count, rms, flags);
+}
+
+int ort_spot_batch_f32(ort_ctx* ctx, int nsys, int rows, const double* R, const double* t, const double* n,
+                       const double* a, const double* hprime, int nfields, const double* fields, int k_rays,
+                       ort_first_order* fo_out, int64_t* count, double* rms, unsigned flags)
+{
+    return spot_batch_impl<float>(ctx, nsys, rows, R, t, n, a, hprime, nfields, fields, k_rays, fo_out, count, rms, flags);
 }
 
 // --------------------------------------------------------------------------------------

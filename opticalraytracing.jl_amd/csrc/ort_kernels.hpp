@@ -837,15 +837,16 @@ __device__ __forceinline__ double dd_range_elem(double a, double b, int n, int i
     return q1 + q2;
 }
 
+template <typename T>
 __global__ __launch_bounds__(kBlock) void k_make_axes(int nb, int ny, int nx, const double* __restrict__ ends,
-                                                      double* __restrict__ axes)
+                                                      T* __restrict__ axes)
 {
     const int64_t g = (int64_t)blockIdx.x * kBlock + threadIdx.x;
     const int per = ny + nx;
     if (g >= (int64_t)nb * per) return;
     const int b = (int)(g / per), j = (int)(g - (int64_t)b * per);
     const double* e = ends + (int64_t)b * 4;
-    axes[g] = (j < ny) ? dd_range_elem(e[0], e[1], ny, j) : dd_range_elem(e[2], e[3], nx, j - ny);
+    axes[g] = (T)((j < ny) ? dd_range_elem(e[0], e[1], ny, j) : dd_range_elem(e[2], e[3], nx, j - ny));
 }
 
 // ------------------------------------------------------------------------------------
@@ -981,9 +982,10 @@ __device__ __forceinline__ void make_rec(SurfRec<T>& r, T t, T Rv, T n1, T n2)
 
 // one thread per (system, loop index i): extended skew table [nsys][rows], forward and reversed
 // meridional tables [nsys][rows-1], last thicknesses
+template <typename T>
 __global__ __launch_bounds__(kBlock) void k_build_tables(int nsys, int rows, const double* __restrict__ R, const double* __restrict__ t,
                                                          const double* __restrict__ n, const FirstOrderOut* __restrict__ fo,
-                                                         SurfRec<double>* __restrict__ rec_ext, MerSurf* __restrict__ mer_fwd,
+                                                         SurfRec<T>* __restrict__ rec_ext, MerSurf* __restrict__ mer_fwd,
                                                          MerSurf* __restrict__ mer_rev, double* __restrict__ tl_fwd,
                                                          double* __restrict__ tl_rev)
 {
@@ -998,8 +1000,8 @@ __global__ __launch_bounds__(kBlock) void k_build_tables(int nsys, int rows, con
         const double te = (i == rows - 1) ? BFD : tt(i);                 // t[end-1] = focus
         const double Re = (i + 1 < rows) ? Rs[i + 1] : __builtin_inf();
         const double n1 = ns[i], n2 = (i + 1 < rows) ? ns[i + 1] : 1.0;
-        SurfRec<double> r;
-        make_rec<double>(r, te, Re, n1, n2);
+        SurfRec<T> r;
+        make_rec<T>(r, te, Re, n1, n2);
         rec_ext[(int64_t)s * rows + i] = r;
     }
     if (i < rows - 1) {
@@ -1033,20 +1035,21 @@ __global__ __launch_bounds__(kBlock) void k_build_aim(int nsys, int nf, int rows
     ain[g] = q;
 }
 
+template <typename T>
 __global__ __launch_bounds__(kBlock) void k_build_bundles(int na, int k_rays, int k2, const AimIn* __restrict__ ain,
-                                                          const AimOut* __restrict__ aout, DevBundle<double>* __restrict__ bd,
+                                                          const AimOut* __restrict__ aout, DevBundle<T>* __restrict__ bd,
                                                           double* __restrict__ ends, int* __restrict__ fail_flag)
 {
     const int g = blockIdx.x * kBlock + threadIdx.x;
     if (g >= na) return;
     const AimIn q = ain[g]; const AimOut o = aout[g];
     if (!o.ok) atomicOr(fail_flag, 1);
-    DevBundle<double> d;
+    DevBundle<T> d;
     d.system = q.system; d.stop = q.stop - 1;
-    d.u = ::tan(o.U); d.v = 0.0;                                         // PupilSampling.jl:38-39 (V = 0, :115)
-    const double nrm = __builtin_sqrt((d.v * d.v + d.u * d.u) + 1.0), inv = 1.0 / nrm;
+    d.u = (T)::tan(o.U); d.v = T(0);                                     // PupilSampling.jl:38-39 (V = 0, :115)
+    const T nrm = (T)__builtin_sqrt((double)((d.v * d.v + d.u * d.u) + T(1))), inv = T(1) / nrm;
     d.k0 = d.v * inv; d.k1 = d.u * inv; d.k2 = inv;
-    d.a_stop = fabs(q.a_stop); d.hprime = o.hprime; d.ybar = 0.0; d.z0 = 1.0;
+    d.a_stop = (T)fabs(q.a_stop); d.hprime = (T)o.hprime; d.ybar = T(0); d.z0 = T(1);
     d.yoff = (int64_t)g * (k_rays + k2); d.xoff = d.yoff + k_rays;
     bd[g] = d;
     ends[4 * (int64_t)g + 0] = o.y1; ends[4 * (int64_t)g + 1] = o.y2; ends[4 * (int64_t)g + 2] = 0.0; ends[4 * (int64_t)g + 3] = o.y_EP;

@@ -126,8 +126,13 @@ class HipEngine:
 
     # ---- full_trace grid stage: PupilSampling.jl:121-146,169-173 -------------------------
     def full_trace_grid(self, pres: Prescription, bundles: Sequence[dict], axes, ny: int, nx: int,
-                        raybasis: bool = False, stats_only: bool = False) -> List[dict]:
-        axes = f64(axes).ravel()
+                        raybasis: bool = False, stats_only: bool = False, dtype=np.float64) -> List[dict]:
+        """dtype = np.float32 traces the grid in binary32 (`ort_full_trace_f32`; statistics stay binary64)."""
+        dtype = np.dtype(dtype)
+        if dtype not in (np.dtype(np.float64), np.dtype(np.float32)):
+            raise TypeError("full_trace_grid: dtype must be float64 or float32")
+        fn = self.ctx.lib.ort_full_trace_f64 if dtype == np.float64 else self.ctx.lib.ort_full_trace_f32
+        axes = np.ascontiguousarray(f64(axes).ravel(), dtype=dtype)
         nb = len(bundles)
         cap = 2 * ny * nx
         count = np.zeros(nb, dtype=np.int64); rms = np.zeros(nb)
@@ -135,12 +140,12 @@ class HipEngine:
         flags = self.base_flags | (_capi.ORT_RAYBASIS if raybasis else 0)
         sysd = self.system(pres)
         if stats_only:      # one pass, nothing ray-sized leaves (or is even written on) the device
-            check(self.ctx.lib.ort_full_trace_f64(self.ctx.h, sysd.h, nb, barr, ptr(axes), axes.size, ny, nx,
-                                                  None, None, None, None, ptr(count), ptr(rms), flags))
+            check(fn(self.ctx.h, sysd.h, nb, barr, ptr(axes), axes.size, ny, nx,
+                     None, None, None, None, ptr(count), ptr(rms), flags))
             return [{"rms": float(rms[b]), "count": int(count[b])} for b in range(nb)]
-        ex = np.empty((nb, cap)); ey = np.empty((nb, cap)); rho = np.empty((nb, cap)); th = np.empty((nb, cap))
-        check(self.ctx.lib.ort_full_trace_f64(self.ctx.h, sysd.h, nb, barr, ptr(axes), axes.size, ny, nx,
-                                              ptr(ex), ptr(ey), ptr(rho), ptr(th), ptr(count), ptr(rms), flags))
+        ex, ey, rho, th = (np.empty((nb, cap), dtype=dtype) for _ in range(4))
+        check(fn(self.ctx.h, sysd.h, nb, barr, ptr(axes), axes.size, ny, nx,
+                 ptr(ex), ptr(ey), ptr(rho), ptr(th), ptr(count), ptr(rms), flags))
         out = []
         for b in range(nb):
             c = int(count[b])

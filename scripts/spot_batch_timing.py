@@ -10,7 +10,8 @@ from tests import common as cm
 eng = ort.HipEngine(fast_math=True)
 mats = workloads.config5(None, ninst=10000)
 for k in (32, 64, 256):
-    for name, fn in (("tolerance_run", batch.tolerance_run), ("spot_batch", batch.spot_batch)):
+    f32 = lambda *a, **kw: batch.spot_batch(*a, dtype=np.float32, **kw)
+    for name, fn in (("tolerance_run", batch.tolerance_run), ("spot_batch", batch.spot_batch), ("spot_batch_f32", f32)):
         for rep in range(4):
             t0 = time.perf_counter()
             r = fn(mats, cm.DG_A, cm.DG_H, fields=(0.0, 1.0), k_rays=k, engine=eng)

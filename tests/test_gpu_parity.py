@@ -742,6 +742,57 @@ def test_spot_batch_single_call_matches_staged_pipeline(hip_engine):
         batch.spot_batch(bad, cm.DG_A, cm.DG_H, engine=hip_engine)
 
 
+@pytest.mark.parametrize("policy", ["ieee", "fast"])
+def test_full_trace_f32_matches_its_own_summary_trace(oracle_engine, policy):
+    """ort_full_trace_f32 (BASELINE config 5 names Float32): the error vectors are exactly the
+    survivors of the Float32 summary trace (which test_f32_build_extension pins to the CPU float
+    loop) in ray order, mirrored; RMS (accumulated in binary64) equals numpy's two-pass value on
+    them; the statistics-only route agrees; and both sit within Float32 accuracy of the Float64 run."""
+    import ctypes as C
+    from opticalraytracing_jl_amd import _capi
+    eng = ort.HipEngine(fast_math=(policy == "fast"))
+    k = 96
+    pres, bundles, axes = _dg_bundles(oracle_engine, k)
+    bundles = bundles[:3]
+    nb, rpb = len(bundles), k * k
+    res = eng.full_trace_grid(pres, bundles, axes, k, k, dtype=np.float32)
+    st_only = eng.full_trace_grid(pres, bundles, axes, k, k, dtype=np.float32, stats_only=True)
+    ref64 = eng.full_trace_grid(pres, bundles, axes, k, k, stats_only=True)
+    N = nb * rpb
+    xf, yf = (np.empty(N, dtype=np.float32) for _ in range(2))
+    st = np.empty(N, dtype=np.int32)
+    out = _capi.ort_grid_out_f32()
+    out.xf, out.yf, out.status = xf.ctypes.data, yf.ctypes.data, st.ctypes.data
+    a32 = np.ascontiguousarray(axes, dtype=np.float32)
+    _capi.check(eng.ctx.lib.ort_trace_grid_f32(eng.ctx.h, eng.system(pres).h, nb, _capi.make_bundles(bundles), a32.ctypes.data,
+                                               a32.size, k, k, C.byref(out), eng.base_flags))
+    for b, bd in enumerate(bundles):
+        sl = slice(b * rpb, (b + 1) * rpb)
+        keep = ((st[sl] & (1 << 16)) == 0) & ~np.isnan(xf[sl]) & ~np.isnan(yf[sl])
+        ex = xf[sl][keep]; ey = yf[sl][keep] - np.float32(bd["hprime"])
+        r = res[b]
+        assert r["count"] == 2 * keep.sum() and r["ex"].dtype == np.float32
+        assert np.array_equal(r["ex"], np.concatenate([ex, -ex])) and np.array_equal(r["ey"], np.concatenate([ey, ey]))
+        e64x, e64y = r["ex"].astype(np.float64), r["ey"].astype(np.float64)
+        rms = math.sqrt(np.mean((e64x - e64x.mean()) ** 2 + (e64y - e64y.mean()) ** 2))
+        assert abs(r["rms"] - rms) <= 1e-12 * rms
+        assert st_only[b]["count"] == r["count"] and abs(st_only[b]["rms"] - rms) <= 1e-9 * rms
+        assert abs(r["count"] - ref64[b]["count"]) <= 0.002 * ref64[b]["count"]
+        assert abs(r["rms"] - ref64[b]["rms"]) <= 2e-3 * ref64[b]["rms"]
+
+
+def test_spot_batch_f32_tracks_f64(hip_engine):
+    """ort_spot_batch_f32: solve + aiming in binary64, pupil trace in binary32 — counts and RMS within
+    Float32 accuracy of the Float64 pipeline, first-order structs identical."""
+    from opticalraytracing_jl_amd import batch, workloads
+    mats = workloads.config5(None, ninst=200)
+    a = batch.spot_batch(mats, cm.DG_A, cm.DG_H, fields=(0.0, 1.0), k_rays=64, engine=hip_engine)
+    b = batch.spot_batch(mats, cm.DG_A, cm.DG_H, fields=(0.0, 1.0), k_rays=64, engine=hip_engine, dtype=np.float32)
+    assert np.array_equal(a["f"], b["f"]) and np.array_equal(a["W040"], b["W040"])
+    assert np.all(np.abs(a["count"] - b["count"]) <= 0.01 * a["count"])
+    assert np.all(np.abs(a["rms"] - b["rms"]) <= 5e-3 * a["rms"])
+
+
 def test_device_axes_match_host_range(hip_engine):
     """ort_make_axes_f64 == api.linrange_batch bit for bit (same double-double algorithm), incl. the
     dyadic tie (81/108) that separates an approximate lerp from the exactly rounded one."""
