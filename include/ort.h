@@ -58,6 +58,8 @@ extern "C" {
 #define ORT_NO_LDS        (1u << 6) /* read the surface table through scalar loads, not LDS */
 
 #define ORT_STATUS_STOPPED (1 << 16)
+#define ORT_STATUS_VIGNETTED (1 << 17)                /* ort_system_set_apertures: outside a clear aperture */
+#define ORT_STATUS_VIGNETTE_SURFACE(s) ((((s) >> 20) & 0xff) + 1) /* first such surface row, 1-based */
 #define ORT_STATUS_INDEX(s) ((s) & 0xffff)
 
 typedef struct ort_ctx ort_ctx;       /* one per (host thread, GPU) */
@@ -91,6 +93,13 @@ int ort_system_create(ort_ctx *ctx, int nsys, int rows,
                       const double *K, const double *coef, int ncoef,
                       ort_system **out);
 int ort_system_destroy(ort_system *sys);
+/* EXTENSION (no reference counterpart: the reference filters real rays at the stop only, Q12, and
+ * treats the other semi-diameters paraxially, src/Vignetting.jl): clear semi-diameters a : [nsys][rows-1]
+ * for the real-ray trace, one per loop iteration (for a full_trace table: system.a, then Inf for the
+ * appended image plane).  A ray with x*x + y*y > a*a on any surface gets ORT_STATUS_VIGNETTED and the
+ * index of the first such surface in its status, and is dropped by the full_trace filter and compaction
+ * like a ray outside the stop; coordinates and history are unaffected.  NULL clears.  Off by default. */
+int ort_system_set_apertures(ort_system *sys, const double *a);
 int ort_system_rows(const ort_system *sys);
 int ort_system_count(const ort_system *sys);
 

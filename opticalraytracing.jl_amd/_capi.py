@@ -25,6 +25,7 @@ ORT_CLIP = 1 << 4
 ORT_FAST_MATH = 1 << 5
 ORT_NO_LDS = 1 << 6
 ORT_STATUS_STOPPED = 1 << 16
+ORT_STATUS_VIGNETTED = 1 << 17
 ORT_MAX_ROWS = 64
 ORT_MAX_NCOEF = 12
 ORT_EDOMAIN = -2
@@ -101,6 +102,7 @@ SIGNATURES = {
     "ort_ctx_device_info": (_i, [_p, C.c_char_p, _i, C.POINTER(_i), C.POINTER(_i), C.POINTER(_l)]),
     "ort_system_create": (_i, [_p, _i, _i, _p, _p, _p, _p, _p, _i, C.POINTER(_p)]),
     "ort_system_destroy": (_i, [_p]),
+    "ort_system_set_apertures": (_i, [_p, _p]),
     "ort_system_rows": (_i, [_p]),
     "ort_system_count": (_i, [_p]),
     "ort_trace_skew_f64": (_i, [_p, _p, _i, _l, _p, _p, _p, _p, _p, _p, _l, _p, _u]),
@@ -261,6 +263,14 @@ class DeviceSystem:
         h = C.c_void_p()
         check(ctx.lib.ort_system_create(ctx.h, nsys, rows, ptr(R), ptr(t), ptr(n), ptr(Kp), ptr(cp), ncoef, C.byref(h)))
         self.h = h
+
+    def set_apertures(self, a) -> None:
+        """Clear semi-diameters [nsys][rows-1] for the real-ray trace (extension; None clears)."""
+        if a is None:
+            check(self.ctx.lib.ort_system_set_apertures(self.h, None))
+            return
+        a = np.ascontiguousarray(np.broadcast_to(f64(a), (self.nsys, self.rows - 1)))
+        check(self.ctx.lib.ort_system_set_apertures(self.h, ptr(a)))
 
     def close(self):
         if getattr(self, "h", None) and getattr(self.ctx, "h", None):

@@ -92,6 +92,8 @@ struct ort_system {
     std::vector<double> t_last;    // t[rows-1] per system (meridional ts tail)
     double* d_tlast = nullptr;     // the same on the device (aiming kernel)
     void* slab = nullptr;          // the one device allocation all of the above point into
+    double* ap64 = nullptr;        // [nsys][S] squared clear semi-diameters (ort_system_set_apertures), or null
+    float* ap32 = nullptr;
 };
 
 namespace {
@@ -154,10 +156,12 @@ template <typename T> struct Sel;
 template <> struct Sel<double> {
     static const SurfRec<double>* rec(const ort_system* s) { return s->rec64; }
     static const double* coef(const ort_system* s) { return s->coef64; }
+    static const double* ap2(const ort_system* s) { return s->ap64; }
 };
 template <> struct Sel<float> {
     static const SurfRec<float>* rec(const ort_system* s) { return s->rec32; }
     static const float* coef(const ort_system* s) { return s->coef32; }
+    static const float* ap2(const ort_system* s) { return s->ap32; }
 };
 
 // pick the kernel instantiation
@@ -295,7 +299,7 @@ int trace_grid_impl(ort_ctx* ctx, const ort_system* sys, int nb, const ort_bundl
 
     TraceParams<T> p;
     memset(&p, 0, sizeof p);
-    p.recs = Sel<T>::rec(sys); p.coefs = Sel<T>::coef(sys); p.S = S; p.ncoef = sys->ncoef;
+    p.recs = Sel<T>::rec(sys); p.coefs = Sel<T>::coef(sys); p.S = S; p.ncoef = sys->ncoef; p.apert2 = Sel<T>::ap2(sys);
     rc = upload_bundles<T>(ctx, sys, nb, bundles, ny, nx, axes_len, flags, &p.bundles); if (rc) return rc;
     p.ny = ny; p.nx = nx; p.rpb = rpb; p.tiles_per_bundle = (int)((rpb + kTile - 1) / kTile);
     p.raybasis = (flags & ORT_RAYBASIS) ? 1 : 0;
@@ -363,7 +367,7 @@ int trace_list_impl(ort_ctx* ctx, const ort_system* sys, int isys, int64_t nrays
     if (hist && ld < nrays) return fail(ORT_EINVAL, "ld %lld < rays %lld", (long long)ld, (long long)nrays);
     TraceParams<T> p;
     memset(&p, 0, sizeof p);
-    p.recs = Sel<T>::rec(sys); p.coefs = Sel<T>::coef(sys); p.S = S; p.ncoef = sys->ncoef;
+    p.recs = Sel<T>::rec(sys); p.coefs = Sel<T>::coef(sys); p.S = S; p.ncoef = sys->ncoef; p.apert2 = Sel<T>::ap2(sys);
     p.nrays = nrays; p.isys = isys; p.slopes_given = (flags & ORT_INPUT_SLOPES) ? 1 : 0;
     const int64_t blocks = (nrays + kTile - 1) / kTile;
     if (flags & ORT_DEVICE_PTRS) {
@@ -413,7 +417,7 @@ int full_trace_impl(ort_ctx* ctx, const ort_system* sys, int nb, const ort_bundl
 
     TraceParams<T> p;
     memset(&p, 0, sizeof p);
-    p.recs = Sel<T>::rec(sys); p.coefs = Sel<T>::coef(sys); p.S = S; p.ncoef = sys->ncoef;
+    p.recs = Sel<T>::rec(sys); p.coefs = Sel<T>::coef(sys); p.S = S; p.ncoef = sys->ncoef; p.apert2 = Sel<T>::ap2(sys);
     rc = upload_bundles<T>(ctx, sys, nb, bundles, ny, nx, axes_len, flags, &p.bundles); if (rc) return rc;
     p.ny = ny; p.nx = nx; p.rpb = rpb; p.tiles_per_bundle = (int)((rpb + kTile - 1) / kTile);
     p.raybasis = (flags & ORT_RAYBASIS) ? 1 : 0;
@@ -758,7 +762,33 @@ int ort_system_destroy(ort_system* sys)
     hipError_t e;
     if (sys->ctx) { e = hipSetDevice(sys->ctx->device); (void)e; e = hipStreamSynchronize(sys->ctx->stream); (void)e; }
     if (sys->slab) { e = hipFree(sys->slab); (void)e; }
+    if (sys->ap64) { e = hipFree(sys->ap64); (void)e; }
     delete sys;
+    return ORT_OK;
+}
+
+int ort_system_set_apertures(ort_system* sys, const double* a)
+{
+    if (!sys || !sys->ctx) return fail(ORT_EINVAL, "null system");
+    int rc = check_ctx(sys->ctx); if (rc) return rc;
+    HIP_TRY(hipStreamSynchronize(sys->ctx->stream));            // no launch may still be reading the old table
+    if (sys->ap64) { HIP_TRY(hipFree(sys->ap64)); sys->ap64 = nullptr; sys->ap32 = nullptr; }
+    if (!a) return ORT_OK;
+    const int S = sys->rows - 1;
+    const size_t cnt = (size_t)sys->nsys * S;
+    std::vector<double> h64(cnt); std::vector<float> h32(cnt);
+    for (size_t i = 0; i < cnt; ++i) {
+        if (!(a[i] >= 0.0)) return fail(ORT_EINVAL, "aperture %zu is negative or NaN", i);
+        h64[i] = a[i] * a[i];
+        const float af = (float)a[i];
+        h32[i] = af * af;
+    }
+    void* d = nullptr;
+    HIP_TRY(hipMalloc(&d, cnt * (sizeof(double) + sizeof(float))));
+    sys->ap64 = static_cast<double*>(d);
+    sys->ap32 = reinterpret_cast<float*>(sys->ap64 + cnt);
+    HIP_TRY(hipMemcpy(sys->ap64, h64.data(), cnt * sizeof(double), hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(sys->ap32, h32.data(), cnt * sizeof(float), hipMemcpyHostToDevice));
     return ORT_OK;
 }
 

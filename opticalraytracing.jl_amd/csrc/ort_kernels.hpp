@@ -70,6 +70,7 @@ struct TraceParams {
     const T* ly; const T* lx; const T* lU; const T* lV;
     int64_t nrays; int isys; int slopes_given;
     int raybasis;
+    const T* apert2;            // [nsys][S] squared clear semi-diameters (extension, off when null)
     // outputs
     T* xv; T* yv; int64_t ld;
     T* xf; T* yf; T* xs; T* ys;
@@ -138,6 +139,7 @@ __device__ __forceinline__ void load_rec(SurfRec<T>& d, const __attribute__((add
 // compacted by k_ft_scatter); FT_STATS = stop filter + per-tile (count, mean, M2, max r) only —
 // nothing ray-sized is written: the statistics-only route of ort_full_trace_f64.
 enum { FT_NONE = 0, FT_FULL = 1, FT_STATS = 2 };
+constexpr int kStatusVignetted = 1 << 17, kStatusVigShift = 20;
 // ------------------------------------------------------------------------------------
 template <typename T, int MATH, bool USE_LDS, bool GRID, bool HIST, bool SUMM, int FT>
 __global__ __launch_bounds__(kBlock, ORT_MIN_WAVES) void k_trace(TraceParams<T> p)
@@ -171,6 +173,9 @@ __global__ __launch_bounds__(kBlock, ORT_MIN_WAVES) void k_trace(TraceParams<T> 
     const SurfRec<T>* __restrict__ grec = p.recs + (int64_t)sysid * S;
     const T* __restrict__ gcoef = p.coefs ? p.coefs + (int64_t)sysid * (S + 1) * p.ncoef : nullptr;
     const int ncoef = p.ncoef;
+    // clear-aperture extension (no reference counterpart): wave-uniform row pointer, null = off
+    typedef const __attribute__((address_space(4))) T* CApPtr;  // wave-uniform address: scalar loads
+    const CApPtr gap2 = ((SUMM || FT) && p.apert2) ? (CApPtr)(uintptr_t)(p.apert2 + (int64_t)sysid * S) : (CApPtr)0;
 
     if (USE_LDS) {
         // stage this system's table: S records of sizeof(SurfRec<T>) bytes, as 16-B words
@@ -267,6 +272,17 @@ __global__ __launch_bounds__(kBlock, ORT_MIN_WAVES) void k_trace(TraceParams<T> 
                 st[r] += __builtin_isunordered(ray[r].x, ray[r].y) ? 0 : 1;
                 if (i == stopi) { xs_[r] = ray[r].x; ys_[r] = ray[r].y; }
             }
+            if (gap2) {                                          // scalar branch: one s_cbranch when off
+                const T a2 = gap2[i];
+#pragma unroll
+                for (int r = 0; r < kRPT; ++r) {
+                    // bit 17: outside the clear aperture of some surface; bits 20..27 count the surfaces
+                    // passed before that -> 1-based index of the first vignetting surface = count + 1
+                    const T r2 = ray[r].x * ray[r].x + ray[r].y * ray[r].y;
+                    st[r] |= (r2 > a2) ? kStatusVignetted : 0;
+                    st[r] += (st[r] & kStatusVignetted) ? 0 : (1 << kStatusVigShift);
+                }
+            }
         }
         if (HIST) {
             if (vec_all) {
@@ -311,7 +327,8 @@ __global__ __launch_bounds__(kBlock, ORT_MIN_WAVES) void k_trace(TraceParams<T> 
         for (int r = 0; r < kRPT; ++r) {
             const T xf = ray[r].x, yf = ray[r].y;
             const T ri = dev_hypot(xs_[r], ys_[r]);                  // :131
-            const bool drop = (ri > a_stop) || t_isnan(xf) || t_isnan(yf) || !live[r];  // :132
+            const bool drop = (ri > a_stop) || t_isnan(xf) || t_isnan(yf) || !live[r] ||   // :132
+                              (st[r] & kStatusVignetted);
             thv[r] = dev_atan2(ys_[r], xs_[r]);                      // :133
             eyv[r] = yf - hprime;                                    // :134
             exv[r] = xf;                                             // :135

@@ -29,6 +29,7 @@ class Prescription:
     n: np.ndarray
     K: Optional[np.ndarray] = None      # [nsys, rows]
     coef: Optional[np.ndarray] = None   # [nsys, rows, ncoef]
+    apertures: Optional[np.ndarray] = None   # [nsys, rows-1] clear semi-diameters (extension, see ort.h)
 
     def __post_init__(self):
         self.R = np.atleast_2d(f64(self.R))
@@ -39,6 +40,8 @@ class Prescription:
         if self.coef is not None:
             c = f64(self.coef)
             self.coef = c[None] if c.ndim == 2 else c
+        if self.apertures is not None:
+            self.apertures = np.ascontiguousarray(np.broadcast_to(f64(self.apertures), (self.R.shape[0], self.R.shape[1] - 1)))
 
     @property
     def rows(self) -> int:
@@ -52,6 +55,7 @@ class Prescription:
         parts = [self.R.tobytes(), self.t.tobytes(), self.n.tobytes(),
                  b"" if self.K is None else self.K.tobytes(),
                  b"" if self.coef is None else self.coef.tobytes(),
+                 b"" if self.apertures is None else self.apertures.tobytes(),
                  str(self.R.shape).encode()]
         return b"|".join(parts)
 
@@ -78,6 +82,8 @@ class HipEngine:
             if len(self._systems) > 32:
                 self._systems.pop(next(iter(self._systems))).close()
             s = DeviceSystem(self.ctx, pres.R, pres.t, pres.n, pres.K, pres.coef)
+            if pres.apertures is not None:
+                s.set_apertures(pres.apertures)
             self._systems[k] = s
         return s
 

@@ -793,6 +793,50 @@ def test_spot_batch_f32_tracks_f64(hip_engine):
     assert np.all(np.abs(a["rms"] - b["rms"]) <= 5e-3 * a["rms"])
 
 
+def test_clear_aperture_extension(hip_engine, oracle_engine):
+    """ort_system_set_apertures (extension, off by default): a ray leaving a surface's clear
+    semi-diameter is flagged (bit 17 + index of the first such surface) and compacted away by the
+    full_trace filter.  Checked against the oracle's per-surface history with the same predicate
+    x*x + y*y > a*a; coordinates and the NaN status index must not change."""
+    import dataclasses
+    from opticalraytracing_jl_amd import _capi
+    k = 64
+    pres, bundles, axes = _dg_bundles(oracle_engine, k)
+    S = pres.rows - 1
+    ap = np.concatenate([0.93 * cm.DG_A, [math.inf]])           # rows-1 = S entries, image plane open
+    assert ap.size == S
+    pres_ap = dataclasses.replace(pres, apertures=ap)
+    base = hip_engine.grid(pres, bundles, axes, k, k)
+    g = hip_engine.grid(pres_ap, bundles, axes, k, k)
+    o = oracle_engine.grid(pres, bundles, axes, k, k)
+    for key in ("xv", "yv", "xf", "yf", "xs", "ys"):
+        assert np.array_equal(g[key], base[key], equal_nan=True), key
+    assert np.array_equal(g["status"] & 0x1ffff, base["status"])
+    out = (o["xv"] * o["xv"] + o["yv"] * o["yv"]) > (ap * ap)[:, None]          # [S][N]
+    vig = out.any(axis=0)
+    first = np.where(vig, out.argmax(axis=0) + 1, 0)
+    assert vig.any() and not vig.all()
+    assert np.array_equal((g["status"] & _capi.ORT_STATUS_VIGNETTED) != 0, vig)
+    assert np.array_equal(np.where(vig, ((g["status"] >> 20) & 0xff) + 1, 0), first)
+    # full_trace drops them, in order, and the statistics-only route agrees
+    ft = hip_engine.full_trace_grid(pres_ap, bundles, axes, k, k)
+    so = hip_engine.full_trace_grid(pres_ap, bundles, axes, k, k, stats_only=True)
+    rpb = k * k
+    for b, bd in enumerate(bundles):
+        sl = slice(b * rpb, (b + 1) * rpb)
+        keep = ((g["status"][sl] & ((1 << 16) | (1 << 17))) == 0) & ~np.isnan(g["xf"][sl]) & ~np.isnan(g["yf"][sl])
+        ex = g["xf"][sl][keep]; ey = g["yf"][sl][keep] - bd["hprime"]
+        assert ft[b]["count"] == 2 * keep.sum() == so[b]["count"]
+        assert np.array_equal(ft[b]["ex"], np.concatenate([ex, -ex])) and np.array_equal(ft[b]["ey"], np.concatenate([ey, ey]))
+        assert abs(so[b]["rms"] - ft[b]["rms"]) <= 1e-10 * ft[b]["rms"]
+    # clearing restores the reference behaviour
+    sysd = hip_engine.system(pres_ap)
+    sysd.set_apertures(None)
+    g2 = hip_engine.grid(pres_ap, bundles, axes, k, k)
+    assert np.array_equal(g2["status"], base["status"])
+    sysd.set_apertures(ap)
+
+
 def test_device_axes_match_host_range(hip_engine):
     """ort_make_axes_f64 == api.linrange_batch bit for bit (same double-double algorithm), incl. the
     dyadic tie (81/108) that separates an approximate lerp from the exactly rounded one."""
