@@ -129,4 +129,28 @@ function full_trace(surfaces::Layout, system::System, H::Float64, k_rays::Int, f
     return RealRayError(εx[1:m], εy[1:m], system.marginal.nu[end], ρ[1:m], θ[1:m], H, rms[])
 end
 
+# [full_trace(solve(M, a, h′), H, k_rays).RMS for M in instances, H in fields] as ONE call: solve, aiming,
+# pupil axes, trace and spot statistics chained on the device (include/ort.h: ort_spot_batch_f64 / _f32).
+# `instances` :: Vector of rows×3 surface matrices of equal size; returns (count, rms) :: nfields × ninst.
+function spot_batch(instances::Vector{<:AbstractMatrix}, a::AbstractVector, h′::Float64,
+                    fields::Vector{Float64} = [0.0], k_rays::Int = 64; single::Bool = false,
+                    flags::UInt32 = UInt32(0))
+    ninst = length(instances); rows = size(instances[1], 1)
+    col(j) = reduce(vcat, (Float64.(M[:, j]) for M in instances))       # [ninst][rows], instance-major
+    R, t, n = col(1), col(2), col(3)
+    av = repeat(Float64.(a), ninst); hp = fill(h′, ninst)
+    cnt = Matrix{Int64}(undef, length(fields), ninst); rms = Matrix{Float64}(undef, length(fields), ninst)
+    GC.@preserve R t n av hp fields cnt rms begin
+        rc = single ?
+            ccall((:ort_spot_batch_f32, LIB), Cint, (Ptr{Cvoid}, Cint, Cint, Ptr{Float64}, Ptr{Float64}, Ptr{Float64},
+                  Ptr{Float64}, Ptr{Float64}, Cint, Ptr{Float64}, Cint, Ptr{Cvoid}, Ptr{Int64}, Ptr{Float64}, UInt32),
+                  ctx().h, ninst, rows, R, t, n, av, hp, length(fields), fields, k_rays, C_NULL, cnt, rms, flags) :
+            ccall((:ort_spot_batch_f64, LIB), Cint, (Ptr{Cvoid}, Cint, Cint, Ptr{Float64}, Ptr{Float64}, Ptr{Float64},
+                  Ptr{Float64}, Ptr{Float64}, Cint, Ptr{Float64}, Cint, Ptr{Cvoid}, Ptr{Int64}, Ptr{Float64}, UInt32),
+                  ctx().h, ninst, rows, R, t, n, av, hp, length(fields), fields, k_rays, C_NULL, cnt, rms, flags)
+        check(rc)
+    end
+    return cnt, rms
+end
+
 end # module

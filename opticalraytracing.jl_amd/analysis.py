@@ -203,6 +203,31 @@ def TSA(surfaces, system=None, k_rays: int = K_RAYS, engine=None):
     return y_XP, eps
 
 
+def caustic_rays(surfaces, system=None, k_rays: int = K_RAYS, engine=None):
+    """The ray set behind the reference's caustic plot (ext/MakieExtension.jl:353-398, the numbers only):
+    k_rays meridional rays y = range(y_marginal, y_marginal / k_rays, k_rays) at U = 0, traced in ONE
+    launch, each extended to the paraxial image plane (negative LSA, :373-377) or to the marginal focus
+    (:378-381).  Returns dict: y0 [k], z_surf / y_surf [k][rows-1] (polyline through the surfaces,
+    :386-387), zf (scalar), yf [k] (image-space end point, :391-392)."""
+    if isinstance(surfaces, System) and system is None:
+        system = surfaces
+        surfaces = system.layout
+    z = system.marginal.z
+    real_marginal = trace_marginal_ray(surfaces, system, engine=engine)
+    y = api.linrange(real_marginal.y[0], real_marginal.y[0] / k_rays, k_rays)       # :364
+    paraxial_BFD = z[-1] - z[-2]                                                    # :365
+    marginal_focus = real_marginal.z[-1]                                            # :366
+    marginal_BFD = marginal_focus - z[-2]                                           # :368
+    to_paraxial = abs(marginal_focus) < abs(z[-1])                                  # :373
+    zf = z[-1] if to_paraxial else marginal_focus
+    BFD = paraxial_BFD if to_paraxial else marginal_BFD
+    rays = api.raytrace(surfaces, y, 0.0, RealRay, engine=engine)
+    yf = np.array([transfer_real(r, surface_to_focus(BFD, r)) for r in rays])       # :377,381
+    return {"y0": np.array([r.y[0] for r in rays]), "z_surf": np.array([r.z[:-1] for r in rays]),
+            "y_surf": np.array([r.y[1:] for r in rays]), "zf": float(zf), "yf": yf,
+            "to_paraxial_plane": bool(to_paraxial)}
+
+
 def SA(y, eps, degree: int):                                           # SeidelAberrations.jl:139-146
     if degree % 2 == 0 or degree < 3:
         raise DomainError(f"DomainError with {degree}: Required: isodd(degree) && degree ≥ 3")
