@@ -151,6 +151,28 @@ __device__ __forceinline__ T poly_deriv(const T* __restrict__ c, int nc, T y)
     return acc;
 }
 
+// MATH_FAST forms with fused multiply-adds.  p is needed at the vertex-plane y (sag, :13) and the two
+// derivatives at the surface point (tilt, :18-19, Q2), so p' (y) and p'(x) share one Horner pass in
+// which every coefficient is read (LDS broadcast) and scaled by its power once.
+template <typename T>
+__device__ __forceinline__ T poly_eval_fast(const T* __restrict__ c, int nc, T y)
+{
+    T acc = c[nc - 1];
+    for (int j = nc - 2; j >= 0; --j) acc = t_fma<T>(acc, y, c[j]);
+    return acc;
+}
+template <typename T>
+__device__ __forceinline__ void poly_deriv2_fast(const T* __restrict__ c, int nc, T y, T x, T& dpy, T& dpx)
+{
+    if (nc < 2) { dpy = T(0); dpx = T(0); return; }
+    dpy = dpx = T(nc - 1) * c[nc - 1];
+    for (int j = nc - 2; j >= 1; --j) {
+        const T dj = T(j) * c[j];
+        dpy = t_fma<T>(dpy, y, dj);
+        dpx = t_fma<T>(dpx, x, dj);
+    }
+}
+
 // Launch direction cosines from slopes: k = normalize([v, u, 1])  (:40-41, Q6).
 template <typename T, int MATH>
 __device__ __forceinline__ void ray_init(Ray<T>& r, T y, T x, T u, T v)
@@ -286,7 +308,7 @@ __device__ __forceinline__ void surface_step_fast_poly(Ray<T>& r, const SurfRec<
         const T r2 = t_fma<T>(r.x, r.x, r.y * r.y);
         const T A = t_fma<T>(v, v, t_fma<T>(u, u, s.opk));
         const T D = t_fma<T>(beta, beta, -(r2 * A));
-        sg = r2 * fast_rcp(beta + s.sgn * fast_sqrt<T>(D)) + poly_eval<T>(coef, s.ncoef, r.y);
+        sg = t_fma<T>(r2, fast_rcp(t_fma<T>(s.sgn, fast_sqrt<T>(D), beta)), poly_eval_fast<T>(coef, s.ncoef, r.y));
         sg = (D >= T(0)) ? sg : t_nan<T>();
         r.y = t_fma<T>(sg, u, r.y);
         r.x = t_fma<T>(sg, v, r.x);
@@ -294,8 +316,10 @@ __device__ __forceinline__ void surface_step_fast_poly(Ray<T>& r, const SurfRec<
         is = s.sgn * fast_rsqrt(t_fma<T>(-rr, s.opk, s.R2));
     }                                                // flat row: sag = 0 without p(y) (:12), tilt = p' only (:18)
     r.sprev = sg;
-    const T tx = t_fma<T>(r.x, is, poly_deriv<T>(coef, s.ncoef, r.x));   // Q2
-    const T ty = t_fma<T>(r.y, is, poly_deriv<T>(coef, s.ncoef, r.y));
+    T dpy, dpx;
+    poly_deriv2_fast<T>(coef, s.ncoef, r.y, r.x, dpy, dpx);
+    const T tx = t_fma<T>(r.x, is, dpx);                         // Q2: p'(x) on the x slope
+    const T ty = t_fma<T>(r.y, is, dpy);
     const T inv = fast_rsqrt(t_fma<T>(tx, tx, t_fma<T>(ty, ty, T(1))));
     const T m0 = tx * inv, m1 = ty * inv, m2 = -inv;
     const T g = -t_fma<T>(r.k2, m2, t_fma<T>(r.k1, m1, r.k0 * m0));

@@ -1,0 +1,51 @@
+"""BASELINE config 3 at full size: Double-Gauss with 4 aspheric (conic + even polynomial) surfaces,
+3 fields x 3 index columns x 2048 x 2048 pupil = 37.7 M rays, 4.53e8 intersections; history trace,
+full_trace with stop-filter compaction (error vectors out), and the statistics-only route.
+Run on the GPU box: python scripts/config3_demo.py [pupil]"""
+import ctypes as C
+import sys
+sys.path.insert(0, ".")
+import numpy as np
+import torch
+import opticalraytracing_jl_amd as ort
+from opticalraytracing_jl_amd import _capi, api, workloads
+
+k = int(sys.argv[1]) if len(sys.argv) > 1 else 2048
+dev = torch.device("cuda", 0)
+for policy in ("fast", "ieee"):
+    eng = ort.HipEngine(fast_math=(policy == "fast"))
+    ort.set_default_engine(eng)
+    pres, bundles, axes = workloads.config3(api, k, engine=eng)
+    nb = len(bundles); rpb = k * k; N = nb * rpb; S = pres.rows - 1
+    sysd = eng.system(pres); barr = _capi.make_bundles(bundles)
+    d_axes = torch.from_numpy(axes).to(dev)
+    lib, h = eng.ctx.lib, eng.ctx.h
+    fl = eng.base_flags | _capi.ORT_DEVICE_PTRS
+
+    def timed(fn, reps=5):
+        fn(); eng.ctx.synchronize()
+        eng.ctx.timer_start()
+        for _ in range(reps):
+            fn()
+        return eng.ctx.timer_stop() / reps
+
+    xv = torch.empty((S, N), dtype=torch.float64, device=dev); yv = torch.empty_like(xv)
+    out = _capi.ort_grid_out_f64(); out.xv, out.yv, out.ld = xv.data_ptr(), yv.data_ptr(), N
+    ms = timed(lambda: _capi.check(lib.ort_trace_grid_f64(h, sysd.h, nb, barr, d_axes.data_ptr(), axes.size, k, k, C.byref(out), fl)))
+    print(f"[{policy}] history: {ms:.3f} ms  {N * S / ms * 1e3:.3e} intersections/s  {16.0 * N * S / ms / 1e6:.0f} GB/s", flush=True)
+    del xv, yv
+    cap = 2 * rpb
+    ex = torch.empty((nb, cap), dtype=torch.float64, device=dev); ey = torch.empty_like(ex)
+    rho = torch.empty_like(ex); th = torch.empty_like(ex)
+    cnt = torch.empty(nb, dtype=torch.int64, device=dev); rms = torch.empty(nb, dtype=torch.float64, device=dev)
+    ms = timed(lambda: _capi.check(lib.ort_full_trace_f64(h, sysd.h, nb, barr, d_axes.data_ptr(), axes.size, k, k,
+                                                          ex.data_ptr(), ey.data_ptr(), rho.data_ptr(), th.data_ptr(),
+                                                          cnt.data_ptr(), rms.data_ptr(), fl)))
+    kept = int(cnt.sum().item()) // 2
+    print(f"[{policy}] full_trace + compaction: {ms:.3f} ms  {N * S / ms * 1e3:.3e} intersections/s  kept {kept}/{N} "
+          f"({kept / N:.3f})  out {32.0 * 2 * kept / 1e9:.2f} GB  mean rms {float(rms.mean()):.6e}", flush=True)
+    ms = timed(lambda: _capi.check(lib.ort_full_trace_f64(h, sysd.h, nb, barr, d_axes.data_ptr(), axes.size, k, k,
+                                                          None, None, None, None, cnt.data_ptr(), rms.data_ptr(), fl)))
+    print(f"[{policy}] statistics only: {ms:.3f} ms  {N * S / ms * 1e3:.3e} intersections/s  mean rms {float(rms.mean()):.6e}", flush=True)
+    del ex, ey, rho, th
+    torch.cuda.empty_cache()
