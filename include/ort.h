@@ -243,6 +243,14 @@ int ort_first_order_f64(ort_ctx *ctx, int nsys, int rows, const double *R, const
 int ort_spot_batch_f64(ort_ctx *ctx, int nsys, int rows, const double *R, const double *t, const double *n,
                        const double *a, const double *hprime, int nfields, const double *fields, int k_rays,
                        ort_first_order *fo_out, int64_t *count, double *rms, unsigned flags);
+/* The same pipeline returning the error vectors too — `full_trace(solve(surfaces, a, h′), H, k_rays)` of
+ * src/PupilSampling.jl:159-163 for every (system, field) in one call: ex, ey, rho, theta :
+ * [nsys*nfields][2*k_rays*(k_rays/2)], count[b] entries valid in slab b (= RealRayError.x/.y/.r/.t,
+ * src/Types.jl:184-192), rms[b] = RealRayError.RMS. */
+int ort_full_trace_batch_f64(ort_ctx *ctx, int nsys, int rows, const double *R, const double *t, const double *n,
+                             const double *a, const double *hprime, int nfields, const double *fields, int k_rays,
+                             ort_first_order *fo_out, double *ex, double *ey, double *rho, double *theta,
+                             int64_t *count, double *rms, unsigned flags);
 /* same call with the pupil-grid trace in Float32 (solve and aiming stay Float64: they are O(rows)
  * per system and decide the grid end points).                                                     */
 int ort_spot_batch_f32(ort_ctx *ctx, int nsys, int rows, const double *R, const double *t, const double *n,

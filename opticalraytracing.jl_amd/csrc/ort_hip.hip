@@ -396,48 +396,32 @@ int trace_list_impl(ort_ctx* ctx, const ort_system* sys, int isys, int64_t nrays
     return ORT_OK;
 }
 
+// The full_trace stages on a prepared TraceParams (recs / coefs / bundles / axes / grid shape set by the
+// caller): tile buffers, trace with the FT epilogue, scan + scatter + finalize (or the statistics-only
+// merge), results to the caller.  ex == NULL selects statistics only.
 template <typename T>
-int full_trace_impl(ort_ctx* ctx, const ort_system* sys, int nb, const ort_bundle* bundles,
-                    const T* axes, int64_t axes_len, int ny, int nx, T* ex, T* ey, T* rho, T* theta,
-                    int64_t* count, double* rms, unsigned flags)
+int run_full_trace(ort_ctx* ctx, TraceParams<T>& p, int nb, T* ex, T* ey, T* rho, T* theta,
+                   int64_t* count, double* rms, unsigned flags)
 {
-    int rc = check_ctx(ctx); if (rc) return rc;
-    rc = check_sys(ctx, sys); if (rc) return rc;
-    if (nb <= 0 || !bundles || !axes || ny <= 0 || nx <= 0 || !count || !rms)
-        return fail(ORT_EINVAL, "bad full_trace arguments");
-    const bool stats_only = !ex && !ey && !rho && !theta;        // spot statistics without the error vectors
-    if (!stats_only && (!ex || !ey || !rho || !theta)) return fail(ORT_EINVAL, "ex, ey, rho, theta: all or none");
-    const int S = sys->rows - 1;
-    for (int b = 0; b < nb; ++b)
-        if (bundles[b].stop <= 0 || bundles[b].stop > S) return fail(ORT_EINVAL, "bundle %d: full_trace needs a stop index in 1..%d", b, S);
-    const int64_t rpb = (int64_t)ny * nx;
-    if (rpb > 0x7fffffffLL - kTile) return fail(ORT_EINVAL, "bundle of %lld rays is too large (max 2^31)", (long long)rpb);
-    const int64_t N = rpb * nb;
     const bool devp = flags & ORT_DEVICE_PTRS;
-
-    TraceParams<T> p;
-    memset(&p, 0, sizeof p);
-    p.recs = Sel<T>::rec(sys); p.coefs = Sel<T>::coef(sys); p.S = S; p.ncoef = sys->ncoef; p.apert2 = Sel<T>::ap2(sys);
-    rc = upload_bundles<T>(ctx, sys, nb, bundles, ny, nx, axes_len, flags, &p.bundles); if (rc) return rc;
-    p.ny = ny; p.nx = nx; p.rpb = rpb; p.tiles_per_bundle = (int)((rpb + kTile - 1) / kTile);
-    p.raybasis = (flags & ORT_RAYBASIS) ? 1 : 0;
+    const bool stats_only = !ex;
+    const int64_t rpb = p.rpb, N = rpb * nb;
     const int64_t tiles = (int64_t)nb * p.tiles_per_bundle;
-    if (devp) p.axes = axes;
-    else { rc = to_device<T>(ctx, SL_AXES, axes, (size_t)axes_len, &p.axes); if (rc) return rc; }
-
+    if (tiles > 0x7fffffffLL) return fail(ORT_EINVAL, "launch too large");
+    int rc;
     rc = dev_out<int32_t>(ctx, SL_TCNT, (size_t)tiles, &p.tile_cnt); if (rc) return rc;
     rc = dev_out<double>(ctx, SL_TSX, (size_t)tiles, &p.tile_sx); if (rc) return rc;
     rc = dev_out<double>(ctx, SL_TSY, (size_t)tiles, &p.tile_sy); if (rc) return rc;
     rc = dev_out<double>(ctx, SL_TRM, (size_t)tiles, &p.tile_rmax); if (rc) return rc;
+    int64_t* dcount = count; double* drms = rms;
+    if (!devp) {
+        rc = dev_out<int64_t>(ctx, SL_RES0, (size_t)nb, &dcount); if (rc) return rc;
+        rc = dev_out<double>(ctx, SL_RES1, (size_t)nb, &drms); if (rc) return rc;
+    }
     if (stats_only) {
         // one pass: trace + stop filter + per-tile (n, mean, M2), merged per bundle — no ray-sized buffer at all
         rc = dev_out<double>(ctx, SL_TOFF, (size_t)tiles, &p.tile_m2x); if (rc) return rc;
         rc = dev_out<double>(ctx, SL_TSQ, (size_t)tiles, &p.tile_m2y); if (rc) return rc;
-        int64_t* dcount = count; double* drms = rms;
-        if (!devp) {
-            rc = dev_out<int64_t>(ctx, SL_RES0, (size_t)nb, &dcount); if (rc) return rc;
-            rc = dev_out<double>(ctx, SL_RES1, (size_t)nb, &drms); if (rc) return rc;
-        }
         rc = launch_trace<T, true, false, false, FT_STATS>(ctx, p, tiles, flags); if (rc) return rc;
         hipLaunchKernelGGL(k_ft_stats_reduce, dim3((unsigned)nb), dim3(kBlock), 0, ctx->stream,
                            p.tile_cnt, p.tile_sx, p.tile_sy, p.tile_m2x, p.tile_m2y, p.tile_rmax, p.tiles_per_bundle, dcount, drms);
@@ -457,17 +441,12 @@ int full_trace_impl(ort_ctx* ctx, const ort_system* sys, int nb, const ort_bundl
     rc = dev_out<int64_t>(ctx, SL_TOFF, (size_t)tiles, &tile_off); if (rc) return rc;
     rc = dev_out<double>(ctx, SL_TSQ, (size_t)tiles, &tile_sq); if (rc) return rc;
     rc = dev_out<FtBundleAgg>(ctx, SL_AGG, (size_t)nb, &agg); if (rc) return rc;
-
-    T *dex = ex, *dey = ey, *drho = rho, *dth = theta; int64_t* dcount = count; double* drms = rms;
+    T *dex = ex, *dey = ey, *drho = rho, *dth = theta;
     if (!devp) {
-        if (!stats_only) {
-            rc = dev_out<T>(ctx, SL_OUT0, (size_t)2 * N, &dex); if (rc) return rc;
-            rc = dev_out<T>(ctx, SL_OUT1, (size_t)2 * N, &dey); if (rc) return rc;
-            rc = dev_out<T>(ctx, SL_OUT2, (size_t)2 * N, &drho); if (rc) return rc;
-            rc = dev_out<T>(ctx, SL_OUT4, (size_t)2 * N, &dth); if (rc) return rc;
-        }
-        rc = dev_out<int64_t>(ctx, SL_RES0, (size_t)nb, &dcount); if (rc) return rc;
-        rc = dev_out<double>(ctx, SL_RES1, (size_t)nb, &drms); if (rc) return rc;
+        rc = dev_out<T>(ctx, SL_OUT0, (size_t)2 * N, &dex); if (rc) return rc;
+        rc = dev_out<T>(ctx, SL_OUT1, (size_t)2 * N, &dey); if (rc) return rc;
+        rc = dev_out<T>(ctx, SL_OUT2, (size_t)2 * N, &drho); if (rc) return rc;
+        rc = dev_out<T>(ctx, SL_OUT4, (size_t)2 * N, &dth); if (rc) return rc;
     }
     rc = launch_trace<T, true, false, false, FT_FULL>(ctx, p, tiles, flags); if (rc) return rc;
     hipLaunchKernelGGL(k_ft_scan, dim3((unsigned)nb), dim3(kBlock), 0, ctx->stream,
@@ -484,7 +463,7 @@ int full_trace_impl(ort_ctx* ctx, const ort_system* sys, int nb, const ort_bundl
         rc = from_device<int64_t>(ctx, count, dcount, (size_t)nb); if (rc) return rc;
         rc = from_device<double>(ctx, rms, drms, (size_t)nb); if (rc) return rc;
         HIP_TRY(hipStreamSynchronize(ctx->stream));
-        for (int b = 0; b < nb && !stats_only; ++b) {
+        for (int b = 0; b < nb; ++b) {
             const size_t off = (size_t)b * 2 * rpb, cnt = (size_t)count[b];
             if (!cnt) continue;
             rc = from_device<T>(ctx, ex + off, dex + off, cnt); if (rc) return rc;
@@ -498,14 +477,44 @@ int full_trace_impl(ort_ctx* ctx, const ort_system* sys, int nb, const ort_bundl
 }
 
 template <typename T>
+int full_trace_impl(ort_ctx* ctx, const ort_system* sys, int nb, const ort_bundle* bundles,
+                    const T* axes, int64_t axes_len, int ny, int nx, T* ex, T* ey, T* rho, T* theta,
+                    int64_t* count, double* rms, unsigned flags)
+{
+    int rc = check_ctx(ctx); if (rc) return rc;
+    rc = check_sys(ctx, sys); if (rc) return rc;
+    if (nb <= 0 || !bundles || !axes || ny <= 0 || nx <= 0 || !count || !rms)
+        return fail(ORT_EINVAL, "bad full_trace arguments");
+    const bool stats_only = !ex && !ey && !rho && !theta;        // spot statistics without the error vectors
+    if (!stats_only && (!ex || !ey || !rho || !theta)) return fail(ORT_EINVAL, "ex, ey, rho, theta: all or none");
+    const int S = sys->rows - 1;
+    for (int b = 0; b < nb; ++b)
+        if (bundles[b].stop <= 0 || bundles[b].stop > S) return fail(ORT_EINVAL, "bundle %d: full_trace needs a stop index in 1..%d", b, S);
+    const int64_t rpb = (int64_t)ny * nx;
+    if (rpb > 0x7fffffffLL - kTile) return fail(ORT_EINVAL, "bundle of %lld rays is too large (max 2^31)", (long long)rpb);
+    const bool devp = flags & ORT_DEVICE_PTRS;
+
+    TraceParams<T> p;
+    memset(&p, 0, sizeof p);
+    p.recs = Sel<T>::rec(sys); p.coefs = Sel<T>::coef(sys); p.S = S; p.ncoef = sys->ncoef; p.apert2 = Sel<T>::ap2(sys);
+    rc = upload_bundles<T>(ctx, sys, nb, bundles, ny, nx, axes_len, flags, &p.bundles); if (rc) return rc;
+    p.ny = ny; p.nx = nx; p.rpb = rpb; p.tiles_per_bundle = (int)((rpb + kTile - 1) / kTile);
+    p.raybasis = (flags & ORT_RAYBASIS) ? 1 : 0;
+    if (devp) p.axes = axes;
+    else { rc = to_device<T>(ctx, SL_AXES, axes, (size_t)axes_len, &p.axes); if (rc) return rc; }
+    return run_full_trace<T>(ctx, p, nb, ex, ey, rho, theta, count, rms, flags);
+}
+
+template <typename T>
 int spot_batch_impl(ort_ctx* ctx, int nsys, int rows, const double* R, const double* t, const double* n,
-                       const double* a, const double* hprime, int nfields, const double* fields, int k_rays,
-                       ort_first_order* fo_out, int64_t* count, double* rms, unsigned flags)
+                    const double* a, const double* hprime, int nfields, const double* fields, int k_rays,
+                    ort_first_order* fo_out, T* ex, T* ey, T* rho, T* theta, int64_t* count, double* rms, unsigned flags)
 {
     int rc = check_ctx(ctx); if (rc) return rc;
     if (nsys <= 0 || rows < 2 || rows + 1 > ORT_MAX_ROWS || !R || !t || !n || !a || !hprime || nfields <= 0 || !fields ||
         k_rays < 2 || !count || !rms)
         return fail(ORT_EINVAL, "bad spot_batch arguments");
+    if ((ex || ey || rho || theta) && (!ex || !ey || !rho || !theta)) return fail(ORT_EINVAL, "ex, ey, rho, theta: all or none");
     const bool devp = flags & ORT_DEVICE_PTRS;
     if (!devp) for (int f = 0; f < nfields; ++f)
         if (!(std::fabs(fields[f]) <= 1.0)) return fail(ORT_EDOMAIN, "DomainError with %g: Domain: |H| <= 1.0", fields[f]);
@@ -546,19 +555,6 @@ int spot_batch_impl(ort_ctx* ctx, int nsys, int rows, const double* R, const dou
     memset(&p, 0, sizeof p);
     p.recs = d_rec; p.coefs = nullptr; p.S = S; p.ncoef = 0; p.bundles = d_bd; p.axes = d_axes;
     p.ny = k_rays; p.nx = k2; p.rpb = rpb; p.tiles_per_bundle = (int)((rpb + kTile - 1) / kTile);
-    const int64_t tiles = (int64_t)na * p.tiles_per_bundle;
-    if (tiles > 0x7fffffffLL) return fail(ORT_EINVAL, "launch too large");
-    rc = dev_out<int32_t>(ctx, SL_TCNT, (size_t)tiles, &p.tile_cnt); if (rc) return rc;
-    rc = dev_out<double>(ctx, SL_TSX, (size_t)tiles, &p.tile_sx); if (rc) return rc;
-    rc = dev_out<double>(ctx, SL_TSY, (size_t)tiles, &p.tile_sy); if (rc) return rc;
-    rc = dev_out<double>(ctx, SL_TRM, (size_t)tiles, &p.tile_rmax); if (rc) return rc;
-    rc = dev_out<double>(ctx, SL_TOFF, (size_t)tiles, &p.tile_m2x); if (rc) return rc;
-    rc = dev_out<double>(ctx, SL_TSQ, (size_t)tiles, &p.tile_m2y); if (rc) return rc;
-    int64_t* dcount = count; double* drms = rms;
-    if (!devp) {
-        rc = dev_out<int64_t>(ctx, SL_RES0, (size_t)na, &dcount); if (rc) return rc;
-        rc = dev_out<double>(ctx, SL_RES1, (size_t)na, &drms); if (rc) return rc;
-    }
     hipStream_t st = ctx->stream;
     auto nblk = [](int64_t n, int b) { return dim3((unsigned)((n + b - 1) / b)); };
     HIP_TRY(hipMemsetAsync(d_flag, 0, sizeof(int), st));
@@ -574,19 +570,14 @@ int spot_batch_impl(ort_ctx* ctx, int nsys, int rows, const double* R, const dou
     hipLaunchKernelGGL((k_build_bundles<T>), nblk(na, kBlock), dim3(kBlock), 0, st, na, k_rays, k2, d_ain, d_aout, d_bd, d_ends, d_flag);
     hipLaunchKernelGGL((k_make_axes<T>), nblk((int64_t)na * (k_rays + k2), kBlock), dim3(kBlock), 0, st, na, k_rays, k2, d_ends, d_axes);
     HIP_TRY(hipGetLastError());
-    rc = launch_trace<T, true, false, false, FT_STATS>(ctx, p, tiles, flags); if (rc) return rc;
-    hipLaunchKernelGGL(k_ft_stats_reduce, dim3((unsigned)na), dim3(kBlock), 0, st,
-                       p.tile_cnt, p.tile_sx, p.tile_sy, p.tile_m2x, p.tile_m2y, p.tile_rmax, p.tiles_per_bundle, dcount, drms);
-    HIP_TRY(hipGetLastError());
+    rc = run_full_trace<T>(ctx, p, na, ex, ey, rho, theta, count, rms, flags); if (rc) return rc;
     if (devp) {
         if (fo_out) HIP_TRY(hipMemcpyAsync(fo_out, d_fo, (size_t)nsys * sizeof(FirstOrderOut), hipMemcpyDeviceToDevice, st));
-        return ORT_OK;       // asynchronous; a failed aiming shows as NaN RMS of that bundle (and ok = 0 upstream)
+        return ORT_OK;       // asynchronous; a failed aiming shows as NaN RMS of that bundle
     }
     int flag = 0;
     HIP_TRY(hipMemcpyAsync(&flag, d_flag, sizeof(int), hipMemcpyDeviceToHost, st));
     if (fo_out) { rc = from_device<FirstOrderOut>(ctx, reinterpret_cast<FirstOrderOut*>(fo_out), d_fo, (size_t)nsys); if (rc) return rc; }
-    rc = from_device<int64_t>(ctx, count, dcount, (size_t)na); if (rc) return rc;
-    rc = from_device<double>(ctx, rms, drms, (size_t)na); if (rc) return rc;
     HIP_TRY(hipStreamSynchronize(st));
     if (flag) return fail(ORT_EHIP, "ray aiming did not converge for at least one (system, field) pair");
     return ORT_OK;
@@ -869,14 +860,26 @@ int ort_spot_batch_f64(ort_ctx* ctx, int nsys, int rows, const double* R, const 
                        const double* a, const double* hprime, int nfields, const double* fields, int k_rays,
                        ort_first_order* fo_out, int64_t* count, double* rms, unsigned flags)
 {
-    return spot_batch_impl<double>(ctx, nsys, rows, R, t, n, a, hprime, nfields, fields, k_rays, fo_out, count, rms, flags);
+    return spot_batch_impl<double>(ctx, nsys, rows, R, t, n, a, hprime, nfields, fields, k_rays, fo_out,
+                                   nullptr, nullptr, nullptr, nullptr, count, rms, flags);
+}
+
+int ort_full_trace_batch_f64(ort_ctx* ctx, int nsys, int rows, const double* R, const double* t, const double* n,
+                             const double* a, const double* hprime, int nfields, const double* fields, int k_rays,
+                             ort_first_order* fo_out, double* ex, double* ey, double* rho, double* theta,
+                             int64_t* count, double* rms, unsigned flags)
+{
+    if (!ex || !ey || !rho || !theta) return fail(ORT_EINVAL, "full_trace_batch needs ex, ey, rho, theta (ort_spot_batch_f64 is the statistics-only call)");
+    return spot_batch_impl<double>(ctx, nsys, rows, R, t, n, a, hprime, nfields, fields, k_rays, fo_out,
+                                   ex, ey, rho, theta, count, rms, flags);
 }
 
 int ort_spot_batch_f32(ort_ctx* ctx, int nsys, int rows, const double* R, const double* t, const double* n,
                        const double* a, const double* hprime, int nfields, const double* fields, int k_rays,
                        ort_first_order* fo_out, int64_t* count, double* rms, unsigned flags)
 {
-    return spot_batch_impl<float>(ctx, nsys, rows, R, t, n, a, hprime, nfields, fields, k_rays, fo_out, count, rms, flags);
+    return spot_batch_impl<float>(ctx, nsys, rows, R, t, n, a, hprime, nfields, fields, k_rays, fo_out,
+                                  nullptr, nullptr, nullptr, nullptr, count, rms, flags);
 }
 
 // --------------------------------------------------------------------------------------

@@ -4,7 +4,7 @@ full_trace with stop-filter compaction (error vectors out), and the statistics-o
 Run on the GPU box: python scripts/config3_demo.py [pupil]"""
 import ctypes as C
 import sys
-sys.path.insert(0, ".")
+sys.path.insert(0, __import__("os").path.dirname(__import__("os").path.dirname(__import__("os").path.abspath(__file__))))
 import numpy as np
 import torch
 import opticalraytracing_jl_amd as ort

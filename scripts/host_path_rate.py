@@ -3,7 +3,7 @@ pageable numpy outputs vs page-locked outputs (torch pin_memory, or hipHostRegis
 Run on the GPU box: python scripts/host_path_rate.py [pupil]"""
 import ctypes as C
 import sys, time
-sys.path.insert(0, ".")
+sys.path.insert(0, __import__("os").path.dirname(__import__("os").path.dirname(__import__("os").path.abspath(__file__))))
 import numpy as np
 import torch
 import opticalraytracing_jl_amd as ort

@@ -1,7 +1,7 @@
 """Config 5 (10^4 instances x 2 fields, k_rays=32): staged `tolerance_run` vs the single-call
 device-resident `spot_batch`.  Run on the GPU box: python scripts/spot_batch_timing.py"""
 import sys, time
-sys.path.insert(0, ".")
+sys.path.insert(0, __import__("os").path.dirname(__import__("os").path.dirname(__import__("os").path.abspath(__file__))))
 import numpy as np
 import opticalraytracing_jl_amd as ort
 from opticalraytracing_jl_amd import batch, workloads

@@ -781,6 +781,41 @@ def test_full_trace_f32_matches_its_own_summary_trace(oracle_engine, policy):
         assert abs(r["rms"] - ref64[b]["rms"]) <= 2e-3 * ref64[b]["rms"]
 
 
+def test_full_trace_batch_one_call(hip_engine, oracle_engine):
+    """ort_full_trace_batch_f64 — full_trace(solve(surfaces, a, h′), H, k_rays) from the raw prescription
+    in one C call — on the reference's own config-1 case (Cooke triplet, test/runtests.jl:19-35) and
+    on perturbed Double-Gauss instances: counts identical to and RMS within 1e-10 of the statistics-only
+    pipeline (same aiming kernels), vectors consistent with their own statistics, and the whole thing
+    within the aiming tolerance (sqrt(eps), RayTracing.jl:1) of the host-driven oracle route."""
+    from opticalraytracing_jl_amd import batch, workloads
+    cases = [(cm.cooke()[None], cm.COOKE_A, cm.COOKE_H, (0.0, 1.0), 64),
+             (workloads.config5(None, ninst=6), cm.DG_A, cm.DG_H, (0.0, 0.7, 1.0), 48)]
+    for mats, a, hp, fields, k in cases:
+        fo, res = batch.full_trace_systems(mats, a, hp, fields=fields, k_rays=k, engine=hip_engine)
+        sb = batch.spot_batch(mats, a, hp, fields=fields, k_rays=k, engine=hip_engine)
+        nf = len(fields)
+        for b, r in enumerate(res):
+            i, fi = divmod(b, nf)
+            assert r["count"] == sb["count"][i, fi] and r["count"] > 0
+            assert abs(r["rms"] - sb["rms"][i, fi]) <= 1e-10 * r["rms"]
+            half = r["count"] // 2
+            assert np.array_equal(r["ex"][half:], -r["ex"][:half]) and np.array_equal(r["ey"][half:], r["ey"][:half])
+            rms = math.sqrt(np.mean((r["ex"] - r["ex"].mean()) ** 2 + (r["ey"] - r["ey"].mean()) ** 2))
+            assert abs(r["rms"] - rms) <= 1e-12 * rms
+            assert abs(r["rho"].max() - 1.0) <= 1e-15                 # r ./= maximum(r)  (PupilSampling.jl:142)
+        for i in (0, mats.shape[0] - 1):
+            s = ort.solve(mats[i].copy(), a, hp, engine=oracle_engine)
+            assert fo["stop"][i] == s.stop and abs(fo["f"][i] - s.f) <= 1e-11 * abs(s.f)
+            for fi, H in enumerate(fields):
+                e = ort.full_trace(s, H, k, engine=oracle_engine)
+                r = res[i * nf + fi]
+                # the edge rays are aimed AT the stop rim to within sqrt(eps): the outermost grid rows sit on
+                # it and may fall either side (reference behaviour too; edge-ray heights are parity-unpinned)
+                assert abs(r["count"] - len(e.x)) <= 8
+                tol = 1e-6 if r["count"] == len(e.x) else 5e-3
+                assert abs(r["rms"] - e.RMS) <= tol * max(e.RMS, 1e-3)
+
+
 def test_spot_batch_f32_tracks_f64(hip_engine):
     """ort_spot_batch_f32: solve + aiming in binary64, pupil trace in binary32 — counts and RMS within
     Float32 accuracy of the Float64 pipeline, first-order structs identical."""
