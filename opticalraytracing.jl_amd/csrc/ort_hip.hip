@@ -565,7 +565,7 @@ int spot_batch_impl(ort_ctx* ctx, int nsys, int rows, const double* R, const dou
     hipLaunchKernelGGL((k_build_tables<T>), nblk((int64_t)nr, kBlock), dim3(kBlock), 0, st, nsys, rows, dR, dt, dn, d_fo, d_rec, d_mf, d_mr,
                        d_tlf, d_tlr);
     hipLaunchKernelGGL(k_build_aim, nblk(na, kBlock), dim3(kBlock), 0, st, nsys, nfields, rows, d_fo, da, dfields, d_ain);
-    hipLaunchKernelGGL(k_aim, nblk(na, 64), dim3(64), 0, st, na, d_ain, d_mf, (const double*)nullptr, d_tlf, d_mr,
+    hipLaunchKernelGGL(k_aim, nblk((int64_t)na * 4, 64), dim3(64), 0, st, na, d_ain, d_mf, (const double*)nullptr, d_tlf, d_mr,
                        (const double*)nullptr, d_tlr, rows - 1, 0, d_aout);
     hipLaunchKernelGGL((k_build_bundles<T>), nblk(na, kBlock), dim3(kBlock), 0, st, na, k_rays, k2, d_ain, d_aout, d_bd, d_ends, d_flag);
     hipLaunchKernelGGL((k_make_axes<T>), nblk((int64_t)na * (k_rays + k2), kBlock), dim3(kBlock), 0, st, na, k_rays, k2, d_ends, d_axes);
@@ -932,6 +932,7 @@ int ort_aim_f64(ort_ctx* ctx, const ort_system* fwd, const ort_system* rev, int 
     rc = check_sys(ctx, rev); if (rc) return rc;
     if (n < 0 || !in || !out) return fail(ORT_EINVAL, "bad aim arguments");
     if (n == 0) return ORT_OK;
+    if (n > (1 << 29)) return fail(ORT_EINVAL, "too many aiming requests (4 lanes each)");
     if (fwd->rows != rev->rows || fwd->nsys != rev->nsys || fwd->ncoef != rev->ncoef)
         return fail(ORT_EINVAL, "forward and reversed system batches differ in shape");
     const bool devp = flags & ORT_DEVICE_PTRS;
@@ -949,7 +950,7 @@ int ort_aim_f64(ort_ctx* ctx, const ort_system* fwd, const ort_system* rev, int 
         rc = to_device<AimIn>(ctx, SL_IN0, reinterpret_cast<const AimIn*>(in), (size_t)n, &din); if (rc) return rc;
         rc = dev_out<AimOut>(ctx, SL_OUT0, (size_t)n, &dout); if (rc) return rc;
     }
-    hipLaunchKernelGGL(k_aim, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, ctx->stream, n, din,
+    hipLaunchKernelGGL(k_aim, dim3((unsigned)(((int64_t)n * 4 + 63) / 64)), dim3(64), 0, ctx->stream, n, din,
                        fwd->mer, fwd->coef64, fwd->d_tlast, rev->mer, rev->coef64, rev->d_tlast, S, fwd->ncoef, dout);
     HIP_TRY(hipGetLastError());
     if (!devp) {

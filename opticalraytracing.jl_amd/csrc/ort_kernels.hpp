@@ -28,6 +28,9 @@ namespace ort {
 #ifndef ORT_NT_STORES
 #define ORT_NT_STORES 1      // non-temporal history stores
 #endif
+#ifndef ORT_APERTURES
+#define ORT_APERTURES 1   // 0 compiles the clear-aperture extension out (A/B builds)
+#endif
 #ifndef ORT_MIN_WAVES
 #define ORT_MIN_WAVES 5      // __launch_bounds__ 2nd argument (waves per SIMD): 96 VGPRs, no spill in the fast history kernel
 #endif
@@ -175,7 +178,7 @@ __global__ __launch_bounds__(kBlock, ORT_MIN_WAVES) void k_trace(TraceParams<T> 
     const int ncoef = p.ncoef;
     // clear-aperture extension (no reference counterpart): wave-uniform row pointer, null = off
     typedef const __attribute__((address_space(4))) T* CApPtr;  // wave-uniform address: scalar loads
-    const CApPtr gap2 = ((SUMM || FT) && p.apert2) ? (CApPtr)(uintptr_t)(p.apert2 + (int64_t)sysid * S) : (CApPtr)0;
+    const CApPtr gap2 = (ORT_APERTURES && (SUMM || FT) && p.apert2) ? (CApPtr)(uintptr_t)(p.apert2 + (int64_t)sysid * S) : (CApPtr)0;
 
     if (USE_LDS) {
         // stage this system's table: S records of sizeof(SurfRec<T>) bytes, as 16-B words
@@ -716,15 +719,47 @@ __device__ inline MerEnd mer_trace_to(const MerSurf* __restrict__ surf, const do
     return e;
 }
 
+// FD-Newton on one scalar `v` shared by a PAIR of lanes: the even lane traces at v, the odd lane at v + eps
+// (the reference's forward difference, RayTracing.jl:230,283), both apply the same update — the serial
+// loop's arithmetic, two traces per round side by side.  `trace(v)` returns the MerEnd of a ray launched
+// with the pair's free variable set to v; loss = y_stop - target.  The two pairs of a 4-lane group run
+// different problems concurrently; the loop is group-uniform so the shuffles always see live lanes.
+template <typename F>
+__device__ __forceinline__ void pair_newton(F&& trace, double& v, double target, double atol, int cap, bool cap_fails,
+                                            int pairbase, int role, MerEnd& e, double& loss, int& iters, int& ok)
+{
+    const double eps = 1.4901161193847656e-08;                   // const ϵ = sqrt(eps()), RayTracing.jl:1
+    const bool pert = role & 1;
+    bool conv = false;
+    int it = 0;
+    e.y_stop = e.y_last = e.U_last = e.z_last = e.z_prev = 0.0;
+    while (true) {
+        if (!conv) e = trace(pert ? v + eps : v);
+        const double L = e.y_stop - target;
+        const double L0 = __shfl(L, pairbase, 4), L1 = __shfl(L, pairbase + 1, 4);
+        if (!conv) {
+            loss = L0;
+            if (!(fabs(L0) > atol)) conv = true;                 // NaN ends the loop like the reference (:229,282)
+            else if (it >= cap) { conv = true; if (cap_fails) ok = 0; }
+            else { v -= L0 * eps / (L1 - L0); ++it; }            // :231,284
+        }
+        const int other = __shfl((int)conv, role ^ 2, 4);
+        if (conv && other) break;
+    }
+    iters += it;
+}
+
+// Four lanes per (system, field): lanes 0-1 = chief pair, lanes 2-3 = marginal pair, then lanes 0-1 / 2-3 =
+// the two edge rays.  Same operations on the same values as the serial drivers, a quarter of the latency.
 __global__ __launch_bounds__(64) void k_aim(int n, const AimIn* __restrict__ in,
                                             const MerSurf* __restrict__ fwd, const double* __restrict__ cfwd, const double* __restrict__ tl_fwd,
                                             const MerSurf* __restrict__ rev, const double* __restrict__ crev, const double* __restrict__ tl_rev,
                                             int S, int ncoef, AimOut* __restrict__ out)
 {
     const int g = blockIdx.x * 64 + threadIdx.x;
-    if (g >= n) return;
-    const AimIn a = in[g];
-    const double eps = 1.4901161193847656e-08;                   // const ϵ = sqrt(eps()), RayTracing.jl:1
+    const int aim = g >> 2, role = g & 3, pair = role >> 1, pairbase = pair * 2;
+    const bool valid = aim < n;
+    const AimIn a = in[valid ? aim : n - 1];                     // tail lanes shadow the last request: uniform shuffles
     const int rows = S + 1;
     const MerSurf* F = fwd + (int64_t)a.system * S;
     const MerSurf* Rv = rev + (int64_t)a.system * S;
@@ -732,58 +767,41 @@ __global__ __launch_bounds__(64) void k_aim(int n, const AimIn* __restrict__ in,
     const double* cR = crev ? crev + (int64_t)a.system * rows * ncoef : nullptr;
     const double tlF = tl_fwd[a.system], tlR = tl_rev[a.system];
     int iters = 0, ok = 1;
-    // ---- real chief ray on the reversed system (RayTracing.jl:278-286)
+    // ---- phase 1: real chief ray on the reversed system (RayTracing.jl:278-286) | real marginal ray (:225-233)
     const int stop_rev = rows - a.stop;                          // :278
     const double ybp = a.chief_y_end;                            // :279
-    double ubp = -a.chief_u_end;                                 // :280
-    MerEnd ray = mer_trace_to(Rv, cR, S, ncoef, a.layout_rev, tlR, ybp, ubp, stop_rev);
-    for (int it = 0; fabs(ray.y_stop) > a.atol; ++it) {          // :282 (NaN ends the loop like the reference)
-        if (it >= 200) { ok = 0; break; }
-        const double dy = mer_trace_to(Rv, cR, S, ncoef, a.layout_rev, tlR, ybp, ubp + eps, stop_rev).y_stop;   // :283
-        ubp -= ray.y_stop * eps / (dy - ray.y_stop);             // :284
-        ray = mer_trace_to(Rv, cR, S, ncoef, a.layout_rev, tlR, ybp, ubp, stop_rev);                            // :285
-        ++iters;
-    }
-    const double yb2 = ray.y_last;                               // ȳ[2] = reverse(ray.y)[1]           :287
-    const double ub1 = -ray.U_last;                              // ū[1] = -reverse(ray.u)[1]          :289
-    const double z2 = ray.z_last - ray.z_prev;                   // z[2] = ray.z[end] - ray.z[end-1]   :292
+    double v = pair == 0 ? -a.chief_u_end : a.y_marg;            // :280 | :225
+    MerEnd e; double loss = 0.0;
+    pair_newton([&](double w) {
+                    return pair == 0 ? mer_trace_to(Rv, cR, S, ncoef, a.layout_rev, tlR, ybp, w, stop_rev)
+                                     : mer_trace_to(F, cF, S, ncoef, a.layout_fwd, tlF, w, 0.0, a.stop);
+                }, v, pair == 0 ? 0.0 : a.a_stop, a.atol, 200, true, pairbase, role, e, loss, iters, ok);
+    // results live on the base lanes: chief on lane 0, marginal on lane 2
+    const double yb2 = __shfl(e.y_last, 0, 4);                   // ȳ[2] = reverse(ray.y)[1]           :287
+    const double ub1 = -__shfl(e.U_last, 0, 4);                  // ū[1] = -reverse(ray.u)[1]          :289
+    const double z2 = __shfl(e.z_last, 0, 4) - __shfl(e.z_prev, 0, 4);   // z[2] = ray.z[end] - ray.z[end-1]   :292
     const double EP_t = -yb2 / ::tan(ub1) + z2;                  // :293
-    // ---- real marginal ray (RayTracing.jl:225-233)
-    double y = a.y_marg;
-    MerEnd mr = mer_trace_to(F, cF, S, ncoef, a.layout_fwd, tlF, y, 0.0, a.stop);
-    double dstop = mr.y_stop - a.a_stop;                         // stop_loss :117-120
-    for (int it = 0; fabs(dstop) > a.atol; ++it) {               // :229
-        if (it >= 200) { ok = 0; break; }
-        const double d2 = mer_trace_to(F, cF, S, ncoef, a.layout_fwd, tlF, y + eps, 0.0, a.stop).y_stop - a.a_stop;   // :230
-        y -= dstop * eps / (d2 - dstop);                         // :231
-        mr = mer_trace_to(F, cF, S, ncoef, a.layout_fwd, tlF, y, 0.0, a.stop);
-        dstop = mr.y_stop - a.a_stop;                            // :232
-        ++iters;
-    }
-    const double y_EP = fabs(y);                                 // PupilSampling.jl:98 (real_marginal.y[1])
-    // ---- field, edge rays (PupilSampling.jl:94-100)
+    const double y_EP = fabs(__shfl(v, 2, 4));                   // PupilSampling.jl:98 (real_marginal.y[1])
+    // ---- phase 2: field, edge rays (PupilSampling.jl:94-100)
     const double U = a.H * ub1;                                  // :96
     const double u = ::tan(U);                                   // :97
     const double astop = fabs(a.a_stop);                         // :91
-    double ye[2] = { y_EP - u * EP_t, -y_EP - u * EP_t };        // :99
-    for (int e = 0; e < 2; ++e) {
-        const double target = e == 0 ? astop : -astop;
-        const double y0 = ye[e];
-        double yy = y0;
-        double d = mer_trace_to(F, cF, S, ncoef, a.layout_fwd, tlF, yy, U, a.stop).y_stop - target;
-        for (int it = 0; fabs(d) > a.atol && it < 100; ++it) {
-            const double dd = mer_trace_to(F, cF, S, ncoef, a.layout_fwd, tlF, yy + eps, U, a.stop).y_stop - target;
-            yy -= d * eps / (dd - d);
-            d = mer_trace_to(F, cF, S, ncoef, a.layout_fwd, tlF, yy, U, a.stop).y_stop - target;
-            ++iters;
-        }
-        if (!(fabs(d) <= 1e300)) yy = y0;                        // isnan(Δ) ? Inf : Δ keeps the start point (:72,78)
-        ye[e] = yy;
+    const double target = pair == 0 ? astop : -astop;
+    const double y0 = (pair == 0 ? y_EP : -y_EP) - u * EP_t;     // :99
+    double yy = y0;
+    int ok2 = 1;
+    pair_newton([&](double w) { return mer_trace_to(F, cF, S, ncoef, a.layout_fwd, tlF, w, U, a.stop); },
+                yy, target, a.atol, 100, false, pairbase, role, e, loss, iters, ok2);
+    if (!(fabs(loss) <= 1e300)) yy = y0;                         // isnan(Δ) ? Inf : Δ keeps the start point (:72,78)
+    const double y2e = __shfl(yy, 2, 4);
+    const int it_all = iters + __shfl(iters, 2, 4);              // lanes 0 and 2 carry their pairs' counts
+    const int ok_all = ok & __shfl(ok, 2, 4);
+    if (valid && role == 0) {
+        AimOut o;
+        o.U = U; o.y1 = yy; o.y2 = y2e; o.y_EP = y_EP; o.hprime = u * a.f; o.EP_t = EP_t; o.Ubar = ub1;
+        o.iters = it_all; o.ok = ok_all;
+        out[aim] = o;
     }
-    AimOut o;
-    o.U = U; o.y1 = ye[0]; o.y2 = ye[1]; o.y_EP = y_EP; o.hprime = u * a.f; o.EP_t = EP_t; o.Ubar = ub1;
-    o.iters = iters; o.ok = ok;
-    out[g] = o;
 }
 
 // ------------------------------------------------------------------------------------

@@ -9,7 +9,7 @@ from tests import common as cm
 
 eng = ort.HipEngine(fast_math=True)
 mats = workloads.config5(None, ninst=10000)
-for k in (32, 64, 256):
+for k in ([int(a) for a in sys.argv[1:]] or [32, 64, 256]):
     f32 = lambda *a, **kw: batch.spot_batch(*a, dtype=np.float32, **kw)
     for name, fn in (("tolerance_run", batch.tolerance_run), ("spot_batch", batch.spot_batch), ("spot_batch_f32", f32)):
         for rep in range(4):
