@@ -68,7 +68,7 @@ enum { SL_IN0 = 0, SL_IN1, SL_IN2, SL_IN3, SL_OUT0, SL_OUT1, SL_OUT2, SL_OUT3, S
        SL_BUNDLES, SL_AXES, SL_WEX, SL_WEY, SL_WR, SL_WTH, SL_TCNT, SL_TSX, SL_TSY, SL_TRM,
        SL_TOFF, SL_TSQ, SL_AGG, SL_RES0, SL_RES1, SL_TAB0, SL_TAB1, SL_TAB2, SL_TAB3,
        SL_SB_FO, SL_SB_REC, SL_SB_MF, SL_SB_MR, SL_SB_TLF, SL_SB_TLR, SL_SB_AIN, SL_SB_AOUT, SL_SB_ENDS, SL_SB_FLAG,
-       SL_SB_FIELDS, SL_SB_A, SL_SB_HP, SL_COUNT };
+       SL_SB_FIELDS, SL_SB_A, SL_SB_HP, SL_SB_PACK, SL_COUNT };
 
 }  // namespace
 
@@ -79,6 +79,20 @@ struct ort_ctx {
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     Scratch slot[SL_COUNT];
     std::vector<unsigned char> bundle_cache;   // last uploaded DevBundle bytes
+    void* pin = nullptr;                       // page-locked staging for the packed small transfers
+    size_t pin_cap = 0;
+    int pinned(size_t bytes, unsigned char** out)
+    {
+        if (bytes > pin_cap) {
+            if (pin) { hipError_t e = hipHostFree(pin); (void)e; pin = nullptr; pin_cap = 0; }
+            const size_t want = std::max<size_t>(bytes * 2, 1 << 16);
+            hipError_t e = hipHostMalloc(&pin, want, hipHostMallocDefault);
+            if (e != hipSuccess) { pin = nullptr; return fail(ORT_ENOMEM, "hipHostMalloc(%zu) failed: %s", want, hipGetErrorString(e)); }
+            pin_cap = want;
+        }
+        *out = static_cast<unsigned char*>(pin);
+        return ORT_OK;
+    }
 };
 
 struct ort_system {
@@ -528,17 +542,27 @@ int spot_batch_impl(ort_ctx* ctx, int nsys, int rows, const double* R, const dou
         if (t[(size_t)s * rows + rows - 1] != 0.0)
             return fail(ORT_EINVAL, "system %d: spot_batch expects a last thickness of 0 (image space)", s);
     const double *dR = R, *dt = t, *dn = n, *da = a, *dh = hprime, *dfields = fields;
+    const size_t n_a = (size_t)nsys * (rows - 1);
+    const size_t in_cnt = 3 * nr + n_a + (size_t)nsys + (size_t)nfields;            // doubles, packed: one H2D copy
+    // packed results of the statistics-only host call: [count | rms | first-order | flag], one D2H copy
+    const size_t o_cnt = 0, o_rms = o_cnt + (size_t)na * sizeof(int64_t), o_fo = o_rms + (size_t)na * sizeof(double),
+                 o_flag = o_fo + (size_t)nsys * sizeof(FirstOrderOut), out_bytes = o_flag + 8;
+    unsigned char* hpin = nullptr; unsigned char* dpack = nullptr;
     if (!devp) {
-        rc = to_device<double>(ctx, SL_IN0, R, nr, &dR); if (rc) return rc;
-        rc = to_device<double>(ctx, SL_IN1, t, nr, &dt); if (rc) return rc;
-        rc = to_device<double>(ctx, SL_IN2, n, nr, &dn); if (rc) return rc;
-        rc = to_device<double>(ctx, SL_SB_A, a, (size_t)nsys * (rows - 1), &da); if (rc) return rc;
-        rc = to_device<double>(ctx, SL_SB_HP, hprime, (size_t)nsys, &dh); if (rc) return rc;
-        rc = to_device<double>(ctx, SL_SB_FIELDS, fields, (size_t)nfields, &dfields); if (rc) return rc;
+        rc = ctx->pinned(std::max(in_cnt * sizeof(double), out_bytes), &hpin); if (rc) return rc;
+        rc = dev_out<unsigned char>(ctx, SL_SB_PACK, in_cnt * sizeof(double) + out_bytes, &dpack); if (rc) return rc;
+        double* hp = reinterpret_cast<double*>(hpin); double* dp = reinterpret_cast<double*>(dpack);
+        size_t o = 0;
+        auto put = [&](const double* src, size_t cnt, const double** dev) { memcpy(hp + o, src, cnt * sizeof(double)); *dev = dp + o; o += cnt; };
+        put(R, nr, &dR); put(t, nr, &dt); put(n, nr, &dn); put(a, n_a, &da); put(hprime, (size_t)nsys, &dh); put(fields, (size_t)nfields, &dfields);
+        HIP_TRY(hipMemcpyAsync(dpack, hpin, in_cnt * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+        HIP_TRY(hipStreamSynchronize(ctx->stream));              // the staging buffer is reused for the results below
     }
+    unsigned char* dres = dpack ? dpack + in_cnt * sizeof(double) : nullptr;
     FirstOrderOut* d_fo; SurfRec<T>* d_rec; MerSurf *d_mf, *d_mr; double *d_tlf, *d_tlr, *d_ends; T* d_axes;
     AimIn* d_ain; AimOut* d_aout; DevBundle<T>* d_bd; int* d_flag;
-    rc = dev_out<FirstOrderOut>(ctx, SL_SB_FO, (size_t)nsys, &d_fo); if (rc) return rc;
+    if (dres) d_fo = reinterpret_cast<FirstOrderOut*>(dres + o_fo);
+    else { rc = dev_out<FirstOrderOut>(ctx, SL_SB_FO, (size_t)nsys, &d_fo); if (rc) return rc; }
     rc = dev_out<SurfRec<T>>(ctx, SL_SB_REC, nr, &d_rec); if (rc) return rc;
     rc = dev_out<MerSurf>(ctx, SL_SB_MF, (size_t)nsys * (rows - 1), &d_mf); if (rc) return rc;
     rc = dev_out<MerSurf>(ctx, SL_SB_MR, (size_t)nsys * (rows - 1), &d_mr); if (rc) return rc;
@@ -550,7 +574,8 @@ int spot_batch_impl(ort_ctx* ctx, int nsys, int rows, const double* R, const dou
     ctx->bundle_cache.clear();                                  // SL_BUNDLES no longer mirrors a host array
     rc = dev_out<double>(ctx, SL_SB_ENDS, (size_t)na * 4, &d_ends); if (rc) return rc;
     rc = dev_out<T>(ctx, SL_AXES, (size_t)na * (k_rays + k2), &d_axes); if (rc) return rc;
-    rc = dev_out<int>(ctx, SL_SB_FLAG, 1, &d_flag); if (rc) return rc;
+    if (dres) d_flag = reinterpret_cast<int*>(dres + o_flag);
+    else { rc = dev_out<int>(ctx, SL_SB_FLAG, 1, &d_flag); if (rc) return rc; }
     TraceParams<T> p;
     memset(&p, 0, sizeof p);
     p.recs = d_rec; p.coefs = nullptr; p.S = S; p.ncoef = 0; p.bundles = d_bd; p.axes = d_axes;
@@ -570,15 +595,30 @@ int spot_batch_impl(ort_ctx* ctx, int nsys, int rows, const double* R, const dou
     hipLaunchKernelGGL((k_build_bundles<T>), nblk(na, kBlock), dim3(kBlock), 0, st, na, k_rays, k2, d_ain, d_aout, d_bd, d_ends, d_flag);
     hipLaunchKernelGGL((k_make_axes<T>), nblk((int64_t)na * (k_rays + k2), kBlock), dim3(kBlock), 0, st, na, k_rays, k2, d_ends, d_axes);
     HIP_TRY(hipGetLastError());
-    rc = run_full_trace<T>(ctx, p, na, ex, ey, rho, theta, count, rms, flags); if (rc) return rc;
     if (devp) {
+        rc = run_full_trace<T>(ctx, p, na, ex, ey, rho, theta, count, rms, flags); if (rc) return rc;
         if (fo_out) HIP_TRY(hipMemcpyAsync(fo_out, d_fo, (size_t)nsys * sizeof(FirstOrderOut), hipMemcpyDeviceToDevice, st));
         return ORT_OK;       // asynchronous; a failed aiming shows as NaN RMS of that bundle
     }
+    if (!ex) {
+        // statistics only: (count, rms) land in the packed result block on the device; ONE copy brings
+        // them, the first-order structs and the convergence flag back through the pinned buffer
+        rc = run_full_trace<T>(ctx, p, na, (T*)nullptr, (T*)nullptr, (T*)nullptr, (T*)nullptr,
+                               reinterpret_cast<int64_t*>(dres + o_cnt), reinterpret_cast<double*>(dres + o_rms),
+                               flags | ORT_DEVICE_PTRS);
+        if (rc) return rc;
+        HIP_TRY(hipMemcpyAsync(hpin, dres, out_bytes, hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipStreamSynchronize(st));
+        memcpy(count, hpin + o_cnt, (size_t)na * sizeof(int64_t));
+        memcpy(rms, hpin + o_rms, (size_t)na * sizeof(double));
+    } else {
+        rc = run_full_trace<T>(ctx, p, na, ex, ey, rho, theta, count, rms, flags); if (rc) return rc;
+        HIP_TRY(hipMemcpyAsync(hpin + o_fo, dres + o_fo, out_bytes - o_fo, hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipStreamSynchronize(st));
+    }
+    if (fo_out) memcpy(fo_out, hpin + o_fo, (size_t)nsys * sizeof(FirstOrderOut));
     int flag = 0;
-    HIP_TRY(hipMemcpyAsync(&flag, d_flag, sizeof(int), hipMemcpyDeviceToHost, st));
-    if (fo_out) { rc = from_device<FirstOrderOut>(ctx, reinterpret_cast<FirstOrderOut*>(fo_out), d_fo, (size_t)nsys); if (rc) return rc; }
-    HIP_TRY(hipStreamSynchronize(st));
+    memcpy(&flag, hpin + o_flag, sizeof(int));
     if (flag) return fail(ORT_EHIP, "ray aiming did not converge for at least one (system, field) pair");
     return ORT_OK;
 }
@@ -627,6 +667,7 @@ int ort_ctx_destroy(ort_ctx* ctx)
     hipError_t e = hipSetDevice(ctx->device); (void)e;
     e = hipStreamSynchronize(ctx->stream); (void)e;
     for (auto& s : ctx->slot) s.release();
+    if (ctx->pin) { e = hipHostFree(ctx->pin); (void)e; }
     if (ctx->ev0) { e = hipEventDestroy(ctx->ev0); (void)e; }
     if (ctx->ev1) { e = hipEventDestroy(ctx->ev1); (void)e; }
     if (ctx->own_stream && ctx->stream) { e = hipStreamDestroy(ctx->stream); (void)e; }
