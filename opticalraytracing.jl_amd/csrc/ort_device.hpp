@@ -133,12 +133,18 @@ __device__ __forceinline__ double sqrt_core(double a)
     return __builtin_fma(g, e, g);
 }
 __device__ __forceinline__ float sqrt_core(float a) { return a * fast_rsqrt(a); }
-template <typename T>
-__device__ __forceinline__ T fast_sqrt(T a)
+// sqrt with the reference's edge cases: 0 -> 0, negative (miss / TIR) -> NaN.  The seed of rsq(0) is +inf
+// and 0 * inf = NaN; seeding from a + tiny instead costs one add where a compare and two selects would:
+// a + tiny == a for every a > 1e-284, a = 0 gives 0 * rsq(tiny) = 0 exactly, and a negative radicand
+// (|a| >> tiny) still gives NaN.
+__device__ __forceinline__ double fast_sqrt(double a)
 {
-    const T g = sqrt_core(a);
-    return a == T(0) ? T(0) : g;
+    const double r0 = __builtin_amdgcn_rsq(a + 1e-300);
+    const double g = a * r0, h = 0.5 * r0;
+    const double e = __builtin_fma(-h, g, 0.5);
+    return __builtin_fma(g, e, g);
 }
+__device__ __forceinline__ float fast_sqrt(float a) { return a * fast_rsqrt(a + 1e-36f); }
 
 // sqrt of a strictly positive argument (caller clamps): no guard.
 template <typename T>
@@ -320,7 +326,7 @@ __device__ __forceinline__ void surface_step_fast_poly(Ray<T>& r, const SurfRec<
         const T r2 = t_fma<T>(r.x, r.x, r.y * r.y);
         const T A = t_fma<T>(v, v, t_fma<T>(u, u, s.opk));
         const T D = t_fma<T>(beta, beta, -(r2 * A));
-        sg = t_fma<T>(r2, fast_rcp(t_fma<T>(s.sgn, fast_sqrt<T>(D), beta)), poly_eval_fast<T>(coef, s.ncoef, r.y));
+        sg = t_fma<T>(r2, fast_rcp(t_fma<T>(s.sgn, fast_sqrt(D), beta)), poly_eval_fast<T>(coef, s.ncoef, r.y));
         sg = (D >= T(0)) ? sg : t_nan<T>();
         r.y = t_fma<T>(sg, u, r.y);
         r.x = t_fma<T>(sg, v, r.x);
@@ -377,7 +383,7 @@ __device__ __forceinline__ void surface_step_fast_conic(Ray<T>& r, const SurfRec
         const T F = t_fma<T>(c, P2, T(-2) * z0);
         const T G = t_fma<T>(-c, Pk, r.k2);
         const T E2 = t_fma<T>(G, G, -(c * F));
-        const T E = fast_sqrt<T>(E2);                            // NaN when the ray misses (:9)
+        const T E = fast_sqrt(E2);                            // NaN when the ray misses (:9)
         const T d = F * fast_rcp(G + E);
         r.x = t_fma<T>(d, r.k0, r.x);
         r.y = t_fma<T>(d, r.k1, r.y);
@@ -393,7 +399,7 @@ __device__ __forceinline__ void surface_step_fast_conic(Ray<T>& r, const SurfRec
         const T G = t_fma<T>(-c, Pk, r.k2);
         const T a = c * t_fma<T>(s.K * r.k2, r.k2, T(1));
         const T E2 = t_fma<T>(G, G, -(a * F));
-        const T E = fast_sqrt<T>(E2);
+        const T E = fast_sqrt(E2);
         const T d = F * fast_rcp(G + E);
         r.x = t_fma<T>(d, r.k0, r.x);
         r.y = t_fma<T>(d, r.k1, r.y);
@@ -439,7 +445,7 @@ __device__ __forceinline__ void surface_step_fast_sphere_c(Ray<T>& r, const Surf
     const T b = t_fma<T>(Qz0, r.k2, t_fma<T>(r.y, r.k1, r.x * r.k0));
     const T q = t_fma<T>(Qz0, Qz0, t_fma<T>(r.y, r.y, r.x * r.x));
     const T disc = t_fma<T>(b, b, s.R2 - q);
-    const T sq = fast_sqrt<T>(disc);                             // NaN when the ray misses (:9)
+    const T sq = fast_sqrt(disc);                             // NaN when the ray misses (:9)
     const T d = -t_fma<T>(s.sgn, sq, b);
     r.x = t_fma<T>(d, r.k0, r.x);
     r.y = t_fma<T>(d, r.k1, r.y);
