@@ -227,7 +227,8 @@ def full_trace_systems(mats: np.ndarray, a, hprime, fields: Sequence[float] = (0
     return first, out
 
 
-def image_hits(mats: np.ndarray, a, hprime, fields: Sequence[float], k: int, engine=None, shard=None):
+def image_hits(mats: np.ndarray, a, hprime, fields: Sequence[float], k: int, engine=None, shard=None,
+               dtype=np.float64):
     """Image-plane hit points of every (instance, field) bundle over the FULL square pupil k x k
     (BASELINE config 4: zoom / wavelength sweeps): first-order solve and aiming on the device, pupil
     boxes from the aimed marginal and chief rays, one summary-mode trace writing only (x_f, y_f,
@@ -236,7 +237,8 @@ def image_hits(mats: np.ndarray, a, hprime, fields: Sequence[float], k: int, eng
 
     shard = (rank, world): trace only this rank's contiguous slab of bundles (dist.shard_bounds) —
     concatenating the ranks' outputs in rank order (dist.allgather_hits / ort_allgather_hits_f64)
-    reproduces the single-GPU result."""
+    reproduces the single-GPU result.  dtype = np.float32: Float32 trace and hits (BASELINE config 5:
+    8 B per ray out); solve, aiming and the pupil axes are still computed in Float64."""
     import torch
     from . import dist as odist
     eng = _eng(engine)
@@ -247,7 +249,16 @@ def image_hits(mats: np.ndarray, a, hprime, fields: Sequence[float], k: int, eng
         raise DomainError("Domain: |H| ≤ 1.0")
     nf = len(fields)
     a_arr = np.ascontiguousarray(np.broadcast_to(np.asarray(a, dtype=np.float64), (ninst, rows - 1)))
-    fo = first_order_arrays(eng, mats, a_arr, hprime)
+    hp_arr = np.ascontiguousarray(np.broadcast_to(np.asarray(hprime, dtype=np.float64), (ninst,)))
+    na = ninst * nf
+    lo, hi = (0, na) if shard is None else odist.shard_bounds(na, shard[1])[shard[0]]
+    if hi <= lo:
+        raise ValueError("image_hits: this shard holds no bundle")
+    # a rank solves, aims and uploads only the instances its slab of bundles touches
+    i0, i1 = lo // nf, (hi - 1) // nf + 1
+    mats, a_arr, hp_arr = mats[i0:i1], a_arr[i0:i1], hp_arr[i0:i1]
+    lo, hi, ninst = lo - i0 * nf, hi - i0 * nf, i1 - i0
+    fo = first_order_arrays(eng, mats, a_arr, hp_arr)
     R, t, n = mats[:, :, 0], mats[:, :, 1].copy(), mats[:, :, 2]
     t[:, 0] = np.where(np.isfinite(t[:, 0]), t[:, 0], 0.0)
     BFD = fo["BFD"]
@@ -255,8 +266,6 @@ def image_hits(mats: np.ndarray, a, hprime, fields: Sequence[float], k: int, eng
     rev_R = -np.concatenate([np.full((ninst, 1), math.inf), R[:, :0:-1]], axis=1)
     rev_t = t[:, ::-1].copy(); rev_t[:, 0] = BFD
     rev = Prescription(rev_R, rev_t, n[:, ::-1].copy(), np.zeros_like(rev_R))
-    na = ninst * nf
-    lo, hi = (0, na) if shard is None else odist.shard_bounds(na, shard[1])[shard[0]]
     nb = hi - lo
     inst = np.repeat(np.arange(ninst, dtype=np.int32), nf)[lo:hi]
     Hs = np.tile(fields, ninst)[lo:hi]
@@ -293,16 +302,25 @@ def image_hits(mats: np.ndarray, a, hprime, fields: Sequence[float], k: int, eng
     dev = torch.device("cuda", eng.ctx.device)
     d_ends = torch.from_numpy(ends).to(dev)
     d_axes = torch.empty(nb * 2 * k, dtype=torch.float64, device=dev)
-    xf = torch.empty((nb, k, k), dtype=torch.float64, device=dev); yf = torch.empty_like(xf)
+    f32 = np.dtype(dtype) == np.float32
+    tdt = torch.float32 if f32 else torch.float64
+    xf = torch.empty((nb, k, k), dtype=tdt, device=dev); yf = torch.empty_like(xf)
     st = torch.empty((nb, k, k), dtype=torch.int32, device=dev)
     torch.cuda.synchronize(dev)
     fl = eng.base_flags | _capi.ORT_DEVICE_PTRS
     lib, h = eng.ctx.lib, eng.ctx.h
     _capi.check(lib.ort_make_axes_f64(h, nb, k, k, d_ends.data_ptr(), d_axes.data_ptr(), fl))
-    out = _capi.ort_grid_out_f64()
-    out.xf, out.yf, out.status = xf.data_ptr(), yf.data_ptr(), st.data_ptr()
     import ctypes as C
-    _capi.check(lib.ort_trace_grid_f64(h, eng.system(ext).h, nb, barr, d_axes.data_ptr(), d_axes.numel(), k, k,
-                                       C.byref(out), fl))
+    if f32:
+        eng.ctx.synchronize()
+        d_axes = d_axes.to(torch.float32)
+        torch.cuda.synchronize(dev)
+        out = _capi.ort_grid_out_f32()
+        trace = lib.ort_trace_grid_f32
+    else:
+        out = _capi.ort_grid_out_f64()
+        trace = lib.ort_trace_grid_f64
+    out.xf, out.yf, out.status = xf.data_ptr(), yf.data_ptr(), st.data_ptr()
+    _capi.check(trace(h, eng.system(ext).h, nb, barr, d_axes.data_ptr(), d_axes.numel(), k, k, C.byref(out), fl))
     eng.ctx.synchronize()
     return xf, yf, st

@@ -932,3 +932,10 @@ def test_image_hits_config4_sharded(hip_engine, oracle_engine):
     ox, oy = oracle_engine.skew(pres, yy, xx, np.full(576, math.tan(aim.U)), np.zeros(576), slopes=True)
     assert np.abs(whole[0][4].cpu().numpy().ravel() - ox[-1]).max() <= 1e-6      # aiming tolerance sqrt(eps)
     assert np.abs(whole[1][4].cpu().numpy().ravel() - oy[-1]).max() <= 1e-6
+    # Float32 hits (config 5's payload type): same aiming, Float32 trace — within Float32 accuracy of the above
+    w32 = batch.image_hits(mats, cm.DG_A, cm.DG_H, fields, 24, engine=hip_engine, dtype=np.float32)
+    assert w32[0].dtype == torch.float32 and w32[0].shape == whole[0].shape
+    ok = ~torch.isnan(whole[0]) & ~torch.isnan(w32[0])
+    assert float(ok.float().mean()) > 0.5
+    assert float((w32[0][ok].double() - whole[0][ok]).abs().max()) <= 2e-4
+    assert float((w32[1][ok].double() - whole[1][ok]).abs().max()) <= 2e-4
