@@ -179,7 +179,7 @@ def main():
         step()
     torch.cuda.synchronize(dev)
     if dist is not None:
-        dist.barrier()
+        odist.barrier(local_dev)
     torch.cuda.synchronize(dev)
     eng.ctx.timer_start()                                   # hipEventRecord on the launch stream
     t0 = time.perf_counter()
@@ -188,7 +188,7 @@ def main():
     ev_ms = eng.ctx.timer_stop()                            # hipEventSynchronize + elapsed
     torch.cuda.synchronize(dev)
     if dist is not None:
-        dist.barrier()
+        odist.barrier(local_dev)
     torch.cuda.synchronize(dev)
     wall = time.perf_counter() - t0
     if dist is not None:
@@ -217,10 +217,10 @@ def main():
     # ---- the single reassembly all-gather of image-plane hits (untimed region, timed alone) ----
     gather = None
     if dist is not None and hits is not None:
-        torch.cuda.synchronize(dev); dist.barrier()
+        torch.cuda.synchronize(dev); odist.barrier(local_dev)
         g0 = time.perf_counter()
         gx, gy = odist.allgather_hits(hits[0].to(cdev), hits[1].to(cdev))
-        torch.cuda.synchronize(dev); dist.barrier()
+        torch.cuda.synchronize(dev); odist.barrier(local_dev)
         gdt = time.perf_counter() - g0
         gbytes = 16.0 * N * world
         gather = {"ms": gdt * 1e3, "bytes_assembled_per_rank": gbytes, "GBps_per_rank": gbytes / gdt / 1e9,

@@ -44,6 +44,16 @@ def init_process_group(backend: str = "nccl"):
     return dist
 
 
+def barrier(device=None):
+    """dist.barrier() that names this rank's GPU for the nccl (RCCL) backend — the plain call guesses the
+    device from the rank and warns; gloo takes no device."""
+    import torch.distributed as dist
+    if dist.get_backend() == "nccl" and device is not None:
+        dist.barrier(device_ids=[int(device)])
+    else:
+        dist.barrier()
+
+
 def allgather_hits(xf, yf, group=None):
     """All-gather equal-size per-rank hit slabs (image-plane x, y) into rank-ordered tensors of
     world*len entries: ONE collective over a packed [2, n] buffer."""

@@ -36,7 +36,7 @@ if nb_total % world:
 batch.image_hits(mats[:2], workloads.DG_A, workloads.DG_H, fields, 32, engine=eng)       # warm-up: allocations, first launches
 for rep in range(3):
     torch.cuda.synchronize(dev)
-    if dist: dist.barrier()
+    if dist: odist.barrier(devi)
     t0 = time.perf_counter()
     xf, yf, st = batch.image_hits(mats, workloads.DG_A, workloads.DG_H, fields, k, engine=eng, shard=(rank, world))
     torch.cuda.synchronize(dev)
@@ -44,7 +44,7 @@ for rep in range(3):
     if dist:
         cdev = dev if backend == "nccl" else torch.device("cpu")
         gx, gy = odist.allgather_hits(xf.reshape(-1).to(cdev), yf.reshape(-1).to(cdev))
-        torch.cuda.synchronize(dev); dist.barrier()
+        torch.cuda.synchronize(dev); odist.barrier(devi)
     else:
         gx, gy = xf.reshape(-1), yf.reshape(-1)
     t2 = time.perf_counter()
@@ -64,4 +64,4 @@ if args.check and rank == 0:
     if not same:
         raise SystemExit(1)
 if dist:
-    dist.barrier(); dist.destroy_process_group()
+    odist.barrier(devi); dist.destroy_process_group()

@@ -37,6 +37,7 @@ def _worker(rank, world, port, k, out_q):
         mine = odist.shard(bundles, rank, world)                 # contiguous slab, rank order
         res = eng.grid(pres, mine, axes, k, k, history=False)
         xf, yf = torch.from_numpy(res["xf"]), torch.from_numpy(res["yf"])
+        odist.barrier(None)                                      # gloo: plain barrier (nccl names its GPU)
         gx, gy = odist.allgather_hits(xf, yf)                    # ONE collective
         kept = torch.from_numpy(res["xf"][(res["status"] >> 16) == 0])
         rag = odist.allgather_ragged(kept)
