@@ -106,3 +106,20 @@ def rel_err(got, ref, scale):
     d = np.abs(got - ref) / np.maximum(np.abs(ref), scale)
     d = np.where(both_nan, 0.0, d)
     return np.where(np.isnan(d), np.inf, d)
+
+
+def build_c_example(name: str = "cooke_full_trace") -> str:
+    """gcc-compile examples/<name>.c against include/ort.h and the in-tree libort_hip.so; returns the binary."""
+    import os
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    from opticalraytracing_jl_amd import _capi
+    _capi.load()                                              # builds the library if it is missing
+    libdir = os.path.dirname(_capi.LIB_PATH)
+    out = os.path.join(root, "build", name)
+    os.makedirs(os.path.dirname(out), exist_ok=True)
+    cmd = ["gcc", "-O2", "-Wall", "-Werror", "-I" + os.path.join(root, "include"), os.path.join(root, "examples", name + ".c"),
+           "-o", out, "-L" + libdir, "-lort_hip", "-Wl,-rpath," + libdir, "-Wl,-rpath,/opt/rocm/lib",
+           "-Wl,-rpath-link,/opt/rocm/lib", "-lm"]
+    subprocess.run(cmd, check=True, capture_output=True)
+    return out

@@ -65,3 +65,16 @@ def test_product_never_imports_oracle():
             if f.endswith((".py", ".hip", ".hpp", ".h", ".cpp")):
                 txt = open(os.path.join(dirpath, f), errors="ignore").read()
                 assert not pat.search(txt), f"{f} reaches into oracle/"
+
+
+def test_plain_c_caller_builds_and_fails_loudly_without_gpu():
+    """examples/cooke_full_trace.c — a C program with nothing but include/ort.h — compiles and links against
+    the library; without a GPU it must stop at ort_ctx_create with the no-fallback error, not compute."""
+    import subprocess
+    import torch
+    from tests import common as cm
+    exe = cm.build_c_example()
+    if torch.cuda.is_available():
+        pytest.skip("GPU present: the run itself is covered by the gpu suite")
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=60)
+    assert r.returncode == 2 and "no CPU fallback" in r.stderr

@@ -816,6 +816,25 @@ def test_full_trace_batch_one_call(hip_engine, oracle_engine):
                 assert abs(r["rms"] - e.RMS) <= tol * max(e.RMS, 1e-3)
 
 
+def test_plain_c_caller_matches_host_mirror(hip_engine):
+    """The drop-in boundary used from plain C (examples/cooke_full_trace.c, no Python in the process): same
+    first-order numbers and spot sizes as the Python host mirror over the same library."""
+    import re
+    import subprocess
+    from opticalraytracing_jl_amd import batch
+    exe = cm.build_c_example()
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stderr
+    f = float(re.search(r"f = ([0-9.]+)", r.stdout).group(1))
+    rows = re.findall(r"H = ([0-9.]+)  rays = (\d+)  RMS = ([0-9.]+)  \(recomputed from the vectors: ([0-9.]+)\)", r.stdout)
+    assert len(rows) == 2
+    fo, res = batch.full_trace_systems(cm.cooke()[None], cm.COOKE_A, cm.COOKE_H, (0.0, 1.0), 64,
+                                       engine=ort.HipEngine())           # IEEE policy, as the C program's flags = 0
+    assert abs(f - fo["f"][0]) < 1e-6
+    for (H, cnt, rms, rms2), ref in zip(rows, res):
+        assert int(cnt) == ref["count"] and abs(float(rms) - ref["rms"]) < 1e-9 and abs(float(rms) - float(rms2)) < 1e-9
+
+
 def test_spot_batch_f32_tracks_f64(hip_engine):
     """ort_spot_batch_f32: solve + aiming in binary64, pupil trace in binary32 — counts and RMS within
     Float32 accuracy of the Float64 pipeline, first-order structs identical."""
