@@ -257,6 +257,7 @@ __global__ __launch_bounds__(kBlock, ORT_MIN_WAVES) void k_trace(TraceParams<T> 
     const CRecPtr crec = (CRecPtr)(uintptr_t)grec;
     SurfRec<T> nxt;
     if (!USE_LDS) load_rec<T>(nxt, crec, 0);
+    const int stop_u = __builtin_amdgcn_readfirstlane(stopi);    // bundle-uniform: the stop capture is a scalar branch
     for (int i = 0; i < S; ++i) {
         SurfRec<T> cur;
         if (!USE_LDS) {
@@ -273,7 +274,10 @@ __global__ __launch_bounds__(kBlock, ORT_MIN_WAVES) void k_trace(TraceParams<T> 
                 // NaN is sticky (every later transfer propagates it), so the 1-based index of the first
                 // NaN surface is 1 + the number of surfaces with ordered (x, y): one v_cmp_o + one add.
                 st[r] += __builtin_isunordered(ray[r].x, ray[r].y) ? 0 : 1;
-                if (i == stopi) { xs_[r] = ray[r].x; ys_[r] = ray[r].y; }
+            }
+            if (i == stop_u) {
+#pragma unroll
+                for (int r = 0; r < kRPT; ++r) { xs_[r] = ray[r].x; ys_[r] = ray[r].y; }
             }
             if (gap2) {                                          // scalar branch: one s_cbranch when off
                 const T a2 = gap2[i];
