@@ -347,9 +347,11 @@ __device__ __forceinline__ void surface_step_fast_poly(Ray<T>& r, const SurfRec<
     pin(cf);
     cf = ok ? cf : T(0);
     const T ee = ok ? s.eta : T(1);
-    r.k0 = t_fma<T>(ee, r.k0, cf * m0);
-    r.k1 = t_fma<T>(ee, r.k1, cf * m1);
-    r.k2 = t_fma<T>(ee, r.k2, cf * m2);
+    // product on the OLD component first, then accumulate into it: the two-address v_fmac then updates k in
+    // place (the other association lands in a temporary and costs a v_mov per component)
+    r.k0 = t_fma<T>(cf, m0, ee * r.k0);
+    r.k1 = t_fma<T>(cf, m1, ee * r.k1);
+    r.k2 = t_fma<T>(cf, m2, ee * r.k2);
 }
 
 // MATH_FAST, conic row (sphere, flat, conic) in direction-cosine form.  With the ray point
@@ -424,9 +426,9 @@ __device__ __forceinline__ void surface_step_fast_conic(Ray<T>& r, const SurfRec
         ee = ok ? ee : T(1);
     }
     const T gc = gam * cn;
-    r.k0 = t_fma<T>(ee, r.k0, -(gc * r.x));
-    r.k1 = t_fma<T>(ee, r.k1, -(gc * r.y));
-    r.k2 = t_fma<T>(ee, r.k2, gam * n2);
+    r.k0 = t_fma<T>(-gc, r.x, ee * r.k0);                        // in-place form, see surface_step_fast_poly
+    r.k1 = t_fma<T>(-gc, r.y, ee * r.k1);
+    r.k2 = t_fma<T>(gam, n2, ee * r.k2);
 }
 
 // MATH_FAST, strongly curved sphere (|R| <= kCentreFormMaxR) in CENTRE form: with Q = P - C
@@ -463,9 +465,9 @@ __device__ __forceinline__ void surface_step_fast_sphere_c(Ray<T>& r, const Surf
         ee = ok ? ee : T(1);
     }
     const T gc = gam * c;
-    r.k0 = t_fma<T>(ee, r.k0, -(gc * r.x));
-    r.k1 = t_fma<T>(ee, r.k1, -(gc * r.y));
-    r.k2 = t_fma<T>(ee, r.k2, -(gc * Qz));
+    r.k0 = t_fma<T>(-gc, r.x, ee * r.k0);                        // in-place form, see surface_step_fast_poly
+    r.k1 = t_fma<T>(-gc, r.y, ee * r.k1);
+    r.k2 = t_fma<T>(-gc, Qz, ee * r.k2);
 }
 
 // All N rays of a lane through one surface.  `cls` packs the row's wave-uniform class bits
@@ -478,6 +480,7 @@ __device__ __forceinline__ void surface_step_n(Ray<T> (&r)[N], const SurfRec<T>&
 {
 #define ORT_ALL_RAYS(call) _Pragma("unroll") for (int q = 0; q < N; ++q) { call; }
     if (MATH == MATH_IEEE) {
+        // (the independent-if form of the MATH_FAST arm below was tried here too: +2 % kernel time, kept as a chain)
         if (cls & CLS_FINITE) {
             if (cls & CLS_HASP) { ORT_ALL_RAYS((surface_step_ieee<T, true, true>(r[q], s, coef))) }
             else                { ORT_ALL_RAYS((surface_step_ieee<T, true, false>(r[q], s, coef))) }
@@ -486,21 +489,26 @@ __device__ __forceinline__ void surface_step_n(Ray<T> (&r)[N], const SurfRec<T>&
             else                { ORT_ALL_RAYS((surface_step_ieee<T, false, false>(r[q], s, coef))) }
         }
     } else {
+        // INDEPENDENT ifs on scalar conditions, not an else-if chain: each arm merges only with its own skip
+        // path, which the register coalescer joins with the loop-carried state (updates in place); a multi-arm
+        // merge costs a v_mov_b64 per state component per surface.
         const int kind = cls >> CLS_KIND_SHIFT;
         const bool tir = cls & CLS_TIR;
-        if (kind == KIND_SPHERE) {
-            if (tir) { ORT_ALL_RAYS((surface_step_fast_conic<T, KIND_SPHERE, true, true>(r[q], s))) }
-            else     { ORT_ALL_RAYS((surface_step_fast_conic<T, KIND_SPHERE, true, false>(r[q], s))) }
-        } else if (kind == KIND_FLAT) {
-            if (!(cls & CLS_REFR)) { ORT_ALL_RAYS((surface_step_fast_conic<T, KIND_FLAT, false, false>(r[q], s))) }
-            else                   { ORT_ALL_RAYS((surface_step_fast_conic<T, KIND_FLAT, true, true>(r[q], s))) }
-        } else if (kind == KIND_SPHERE_C) {
-            if (tir) { ORT_ALL_RAYS((surface_step_fast_sphere_c<T, true>(r[q], s))) }
-            else     { ORT_ALL_RAYS((surface_step_fast_sphere_c<T, false>(r[q], s))) }
-        } else if (kind == KIND_CONIC) {
-            ORT_ALL_RAYS((surface_step_fast_conic<T, KIND_CONIC, true, true>(r[q], s)))
-        } else {
-            ORT_ALL_RAYS((surface_step_fast_poly<T>(r[q], s, coef)))
+        const bool refr = cls & CLS_REFR;
+        if (kind == KIND_SPHERE_C && !tir) { ORT_ALL_RAYS((surface_step_fast_sphere_c<T, false>(r[q], s))) }
+        if (kind == KIND_SPHERE_C && tir)  { ORT_ALL_RAYS((surface_step_fast_sphere_c<T, true>(r[q], s))) }
+        if (kind == KIND_FLAT && !refr)    { ORT_ALL_RAYS((surface_step_fast_conic<T, KIND_FLAT, false, false>(r[q], s))) }
+        if (kind == KIND_FLAT && refr)     { ORT_ALL_RAYS((surface_step_fast_conic<T, KIND_FLAT, true, true>(r[q], s))) }
+        if (kind == KIND_SPHERE || kind == KIND_CONIC || kind == KIND_POLY) {   // the general forms share ONE arm:
+            // as independent arms they drag their merge copies back onto the path of the sphere / flat rows (measured)
+            if (kind == KIND_SPHERE) {
+                if (tir) { ORT_ALL_RAYS((surface_step_fast_conic<T, KIND_SPHERE, true, true>(r[q], s))) }
+                else     { ORT_ALL_RAYS((surface_step_fast_conic<T, KIND_SPHERE, true, false>(r[q], s))) }
+            } else if (kind == KIND_CONIC) {
+                ORT_ALL_RAYS((surface_step_fast_conic<T, KIND_CONIC, true, true>(r[q], s)))
+            } else {
+                ORT_ALL_RAYS((surface_step_fast_poly<T>(r[q], s, coef)))
+            }
         }
     }
 #undef ORT_ALL_RAYS
