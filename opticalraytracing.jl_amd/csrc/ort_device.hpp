@@ -499,9 +499,13 @@ __device__ __forceinline__ void surface_step_n(Ray<T> (&r)[N], const SurfRec<T>&
         if (kind == KIND_SPHERE_C && tir)  { ORT_ALL_RAYS((surface_step_fast_sphere_c<T, true>(r[q], s))) }
         if (kind == KIND_FLAT && !refr)    { ORT_ALL_RAYS((surface_step_fast_conic<T, KIND_FLAT, false, false>(r[q], s))) }
         if (kind == KIND_FLAT && refr)     { ORT_ALL_RAYS((surface_step_fast_conic<T, KIND_FLAT, true, true>(r[q], s))) }
-        if (kind == KIND_SPHERE || kind == KIND_CONIC || kind == KIND_POLY) {   // the general forms share ONE arm:
+        // Float32 never uses the centre form (cancellation), so ITS hot sphere arms are the general ones
+        constexpr bool kF32 = sizeof(T) == 4;
+        if (kF32 && kind == KIND_SPHERE && !tir) { ORT_ALL_RAYS((surface_step_fast_conic<T, KIND_SPHERE, true, false>(r[q], s))) }
+        if (kF32 && kind == KIND_SPHERE && tir)  { ORT_ALL_RAYS((surface_step_fast_conic<T, KIND_SPHERE, true, true>(r[q], s))) }
+        if ((!kF32 && kind == KIND_SPHERE) || kind == KIND_CONIC || kind == KIND_POLY) {   // the general forms share ONE arm:
             // as independent arms they drag their merge copies back onto the path of the sphere / flat rows (measured)
-            if (kind == KIND_SPHERE) {
+            if (!kF32 && kind == KIND_SPHERE) {
                 if (tir) { ORT_ALL_RAYS((surface_step_fast_conic<T, KIND_SPHERE, true, true>(r[q], s))) }
                 else     { ORT_ALL_RAYS((surface_step_fast_conic<T, KIND_SPHERE, true, false>(r[q], s))) }
             } else if (kind == KIND_CONIC) {
