@@ -43,11 +43,11 @@ poly(c::Vector{Float64}) = OpticalRayTracing.Polynomial(y -> evalpoly(y, c))
 function upload(R, t, n, K = nothing, coef = nothing)
     rows = length(R)
     ncoef = coef === nothing ? 0 : size(coef, 2)
-    cT = coef === nothing ? C_NULL : pointer(permutedims(coef))     # [rows][ncoef] row-major
+    coefT = coef === nothing ? nothing : permutedims(coef)          # [rows][ncoef] row-major, kept alive below
     r = Ref{Ptr{Cvoid}}(C_NULL)
-    GC.@preserve R t n K coef check(ccall((:ort_system_create, LIB), Cint,
+    GC.@preserve R t n K coefT check(ccall((:ort_system_create, LIB), Cint,
         (Ptr{Cvoid}, Cint, Cint, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Cint, Ref{Ptr{Cvoid}}),
-        ctx().h, 1, rows, R, t, n, K === nothing ? C_NULL : pointer(K), cT, ncoef, r))
+        ctx().h, 1, rows, R, t, n, K === nothing ? C_NULL : pointer(K), coefT === nothing ? C_NULL : pointer(coefT), ncoef, r))
     return r[]
 end
 release(sys) = ccall((:ort_system_destroy, LIB), Cint, (Ptr{Cvoid},), sys)
