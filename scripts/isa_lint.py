@@ -1,0 +1,45 @@
+#!/usr/bin/env python3
+"""Build-side guard for the hot loop of the FAST trace kernels (runs here, no GPU): compiles the library to
+gfx950 assembly and checks, for the history and the summary kernel,
+  * the centre-form sphere arms (the blocks with exactly 4 v_rsq_f64 and no v_rcp_f64) carry no v_mov_b64,
+  * no other block of the surface loop is a pure copy block (>= 10 v_mov_b64 in <= 20 instructions),
+  * no scratch (spill) instruction anywhere in the kernel.
+The register coalescer's outcome is sensitive to the shape of the class dispatch in surface_step_n:
+run this after touching it.   python scripts/isa_lint.py"""
+import os, re, subprocess, sys, tempfile
+from collections import Counter
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+KERNELS = {"history": "_ZN3ort7k_traceIdLi1ELb1ELb1ELb1ELb0ELi0EEEvNS_11TraceParamsIT_EE",
+           "summary": "_ZN3ort7k_traceIdLi1ELb1ELb1ELb0ELb1ELi0EEEvNS_11TraceParamsIT_EE"}
+with tempfile.TemporaryDirectory(dir=os.path.join(ROOT, "build") if os.path.isdir(os.path.join(ROOT, "build")) else None) as td:
+    asm = os.path.join(td, "ort.s")
+    subprocess.run(["hipcc", "--offload-arch=gfx950", "-O3", "-ffp-contract=off", "-std=c++17", "-fno-slp-vectorize",
+                    "-I" + os.path.join(ROOT, "include"), "-S", "--cuda-device-only",
+                    os.path.join(ROOT, "opticalraytracing.jl_amd", "csrc", "ort_hip.hip"), "-o", asm], check=True,
+                   stderr=subprocess.DEVNULL)
+    txt = open(asm).read()
+bad = 0
+for tag, name in KERNELS.items():
+    i = txt.index(name + ":"); j = txt.index(".Lfunc_end", i)
+    blocks, cur, lab = [], [], "entry"
+    for l in txt[i:j].split("\n"):
+        t = l.strip()
+        m = re.match(r"^(\.LBB\d+_\d+):", t)
+        if m:
+            blocks.append((lab, cur)); cur = []; lab = m.group(1)
+        elif t and not t.startswith((".", ";")):
+            cur.append(t.split(";")[0].strip())
+    blocks.append((lab, cur))
+    n_inst = sum(len(b) for _, b in blocks)
+    scratch = sum(1 for _, b in blocks for x in b if "scratch_" in x)
+    arms = [(lab, b) for lab, b in blocks if sum(x.startswith("v_rsq_f64") for x in b) == 4 and not any(x.startswith("v_rcp_f64") for x in b)]
+    arm_movs = [sum(x.startswith("v_mov_b64") for x in b) for _, b in arms]
+    arm_valu = [sum(x.startswith("v_") for x in b) for _, b in arms]
+    copy_blocks = [lab for lab, b in blocks if len(b) <= 20 and sum(x.startswith("v_mov_b64") for x in b) >= 10]
+    # the general (grouped) arm keeps its own merge copies; they must not sit on the sphere / flat path:
+    # heuristically, at most one pure copy block may remain in the kernel
+    ok = scratch == 0 and len(arms) >= 2 and all(m == 0 for m in arm_movs[:2]) and len(copy_blocks) <= 1
+    print(f"{tag}: {n_inst} instructions, scratch {scratch}, sphere arms VALU {arm_valu[:2]} with v_mov_b64 {arm_movs[:2]}, "
+          f"pure copy blocks {copy_blocks} -> {'ok' if ok else 'REGRESSION'}")
+    bad += not ok
+sys.exit(1 if bad else 0)
