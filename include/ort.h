@@ -251,6 +251,16 @@ int ort_full_trace_batch_f64(ort_ctx *ctx, int nsys, int rows, const double *R, 
                              const double *a, const double *hprime, int nfields, const double *fields, int k_rays,
                              ort_first_order *fo_out, double *ex, double *ey, double *rho, double *theta,
                              int64_t *count, double *rms, unsigned flags);
+/* The same for aspheric prescriptions — `full_trace(solve(layout, a, h′), H, k_rays)` with
+ * layout = Layout(R, t, n, K, p) (src/Types.jl:82-112): K : [nsys][rows] conic constants or NULL,
+ * coef : [nsys][rows][ncoef] power-series coefficients of p (or NULL / ncoef = 0).  The real chief ray is
+ * aimed through the reference's reversed Layout, K and p plainly reversed (src/RayTracing.jl:272-274).
+ * ex = ey = rho = theta = NULL: statistics only. */
+int ort_full_trace_layout_batch_f64(ort_ctx *ctx, int nsys, int rows, const double *R, const double *t, const double *n,
+                                    const double *K, const double *coef, int ncoef,
+                                    const double *a, const double *hprime, int nfields, const double *fields, int k_rays,
+                                    ort_first_order *fo_out, double *ex, double *ey, double *rho, double *theta,
+                                    int64_t *count, double *rms, unsigned flags);
 /* same call with the pupil-grid trace in Float32 (solve and aiming stay Float64: they are O(rows)
  * per system and decide the grid end points).                                                     */
 int ort_spot_batch_f32(ort_ctx *ctx, int nsys, int rows, const double *R, const double *t, const double *n,

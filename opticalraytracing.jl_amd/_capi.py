@@ -117,6 +117,8 @@ SIGNATURES = {
     "ort_spot_batch_f64": (_i, [_p, _i, _i, _p, _p, _p, _p, _p, _i, _p, _i, C.POINTER(ort_first_order), _p, _p, _u]),
     "ort_full_trace_batch_f64": (_i, [_p, _i, _i, _p, _p, _p, _p, _p, _i, _p, _i, C.POINTER(ort_first_order),
                                       _p, _p, _p, _p, _p, _p, _u]),
+    "ort_full_trace_layout_batch_f64": (_i, [_p, _i, _i, _p, _p, _p, _p, _p, _i, _p, _p, _i, _p, _i,
+                                             C.POINTER(ort_first_order), _p, _p, _p, _p, _p, _p, _u]),
     "ort_spot_batch_f32": (_i, [_p, _i, _i, _p, _p, _p, _p, _p, _i, _p, _i, C.POINTER(ort_first_order), _p, _p, _u]),
     "ort_trace_meridional_f64": (_i, [_p, _p, _i, _l, _p, _p, _p, _p, _p, _l, _u]),
     "ort_trace_paraxial_f64": (_i, [_p, _i, _i, _p, _p, _p, _l, _p, _p, _p, _p, _l, _u]),

@@ -189,19 +189,24 @@ def spot_batch(mats: np.ndarray, a, hprime, fields: Sequence[float] = (0.0,), k_
 
 
 def full_trace_systems(mats: np.ndarray, a, hprime, fields: Sequence[float] = (0.0,), k_rays: int = SPOT_RAYS,
-                       engine=None):
-    """`[full_trace(solve(M, a, h′), H, k_rays) for M in mats, H in fields]` as ONE C call
-    (`ort_full_trace_batch_f64`): the spot pipeline of `spot_batch` with the error vectors returned.
+                       engine=None, coef=None):
+    """`[full_trace(solve(M, a, h′), H, k_rays) for M in mats, H in fields]` as ONE C call: the spot pipeline of
+    `spot_batch` with the error vectors returned.  mats : [ninst][rows][3] = [R t n] (`ort_full_trace_batch_f64`)
+    or [ninst][rows][4] = [R t n K] and / or coef : [ninst][rows][ncoef] power-series coefficients of p — the
+    reference's Layout(R, t, n, K, p) (`ort_full_trace_layout_batch_f64`).
     Returns (first-order dict of [ninst] arrays, list over (instance, field) of dicts with ex, ey, rho,
     theta, rms, count, H — the fields of RealRayError, src/Types.jl:184-192)."""
     eng = _eng(engine)
     mats = np.ascontiguousarray(mats, dtype=np.float64)
     if mats.ndim == 2:
         mats = mats[None]
-    ninst, rows, _ = mats.shape
+    ninst, rows, ncol = mats.shape
     fields = np.ascontiguousarray(np.abs(np.asarray(fields, dtype=np.float64)))
     nf = len(fields)
     R = np.ascontiguousarray(mats[:, :, 0]); t = np.ascontiguousarray(mats[:, :, 1]); n = np.ascontiguousarray(mats[:, :, 2])
+    K = np.ascontiguousarray(mats[:, :, 3]) if ncol >= 4 else None
+    if coef is not None:
+        coef = np.ascontiguousarray(np.broadcast_to(np.asarray(coef, dtype=np.float64), (ninst, rows, np.shape(coef)[-1])))
     a_arr = np.ascontiguousarray(np.broadcast_to(np.asarray(a, dtype=np.float64), (ninst, rows - 1)))
     hp = np.ascontiguousarray(np.broadcast_to(np.asarray(hprime, dtype=np.float64), (ninst,)))
     na = ninst * nf
@@ -209,12 +214,20 @@ def full_trace_systems(mats: np.ndarray, a, hprime, fields: Sequence[float] = (0
     fo = (_capi.ort_first_order * ninst)()
     ex, ey, rho, th = (np.empty((na, cap)) for _ in range(4))
     count = np.zeros(na, dtype=np.int64); rms = np.zeros(na)
-    rc = eng.ctx.lib.ort_full_trace_batch_f64(eng.ctx.h, ninst, rows, _capi.ptr(R), _capi.ptr(t), _capi.ptr(n),
-                                              _capi.ptr(a_arr), _capi.ptr(hp), nf, _capi.ptr(fields), int(k_rays), fo,
-                                              _capi.ptr(ex), _capi.ptr(ey), _capi.ptr(rho), _capi.ptr(th),
-                                              _capi.ptr(count), _capi.ptr(rms), eng.base_flags)
+    lib, h = eng.ctx.lib, eng.ctx.h
+    if K is None and coef is None:
+        rc = lib.ort_full_trace_batch_f64(h, ninst, rows, _capi.ptr(R), _capi.ptr(t), _capi.ptr(n),
+                                          _capi.ptr(a_arr), _capi.ptr(hp), nf, _capi.ptr(fields), int(k_rays), fo,
+                                          _capi.ptr(ex), _capi.ptr(ey), _capi.ptr(rho), _capi.ptr(th),
+                                          _capi.ptr(count), _capi.ptr(rms), eng.base_flags)
+    else:
+        rc = lib.ort_full_trace_layout_batch_f64(h, ninst, rows, _capi.ptr(R), _capi.ptr(t), _capi.ptr(n), _capi.ptr(K),
+                                                 _capi.ptr(coef), 0 if coef is None else coef.shape[2],
+                                                 _capi.ptr(a_arr), _capi.ptr(hp), nf, _capi.ptr(fields), int(k_rays), fo,
+                                                 _capi.ptr(ex), _capi.ptr(ey), _capi.ptr(rho), _capi.ptr(th),
+                                                 _capi.ptr(count), _capi.ptr(rms), eng.base_flags)
     if rc == _capi.ORT_EDOMAIN:
-        raise DomainError(eng.ctx.lib.ort_last_error().decode('utf-8', 'replace'))
+        raise DomainError(lib.ort_last_error().decode('utf-8', 'replace'))
     _capi.check(rc)
     dt = np.dtype([(k, np.float64) for k in _FO_FIELDS[:-2]] + [("stop", np.int32), ("k", np.int32)])
     arr = np.frombuffer(fo, dtype=dt, count=ninst)

@@ -68,7 +68,7 @@ enum { SL_IN0 = 0, SL_IN1, SL_IN2, SL_IN3, SL_OUT0, SL_OUT1, SL_OUT2, SL_OUT3, S
        SL_BUNDLES, SL_AXES, SL_WEX, SL_WEY, SL_WR, SL_WTH, SL_TCNT, SL_TSX, SL_TSY, SL_TRM,
        SL_TOFF, SL_TSQ, SL_AGG, SL_RES0, SL_RES1, SL_TAB0, SL_TAB1, SL_TAB2, SL_TAB3,
        SL_SB_FO, SL_SB_REC, SL_SB_MF, SL_SB_MR, SL_SB_TLF, SL_SB_TLR, SL_SB_AIN, SL_SB_AOUT, SL_SB_ENDS, SL_SB_FLAG,
-       SL_SB_FIELDS, SL_SB_A, SL_SB_HP, SL_SB_PACK, SL_COUNT };
+       SL_SB_FIELDS, SL_SB_A, SL_SB_HP, SL_SB_PACK, SL_SB_CEXT, SL_SB_CREV, SL_COUNT };
 
 }  // namespace
 
@@ -521,6 +521,7 @@ int full_trace_impl(ort_ctx* ctx, const ort_system* sys, int nb, const ort_bundl
 
 template <typename T>
 int spot_batch_impl(ort_ctx* ctx, int nsys, int rows, const double* R, const double* t, const double* n,
+                    const double* K, const double* coef, int ncoef,
                     const double* a, const double* hprime, int nfields, const double* fields, int k_rays,
                     ort_first_order* fo_out, T* ex, T* ey, T* rho, T* theta, int64_t* count, double* rms, unsigned flags)
 {
@@ -529,6 +530,9 @@ int spot_batch_impl(ort_ctx* ctx, int nsys, int rows, const double* R, const dou
         k_rays < 2 || !count || !rms)
         return fail(ORT_EINVAL, "bad spot_batch arguments");
     if ((ex || ey || rho || theta) && (!ex || !ey || !rho || !theta)) return fail(ORT_EINVAL, "ex, ey, rho, theta: all or none");
+    if (ncoef < 0 || ncoef > ORT_MAX_NCOEF || (ncoef > 0 && !coef)) return fail(ORT_EINVAL, "bad coefficient table (ncoef 0..%d)", ORT_MAX_NCOEF);
+    if (!coef) ncoef = 0;
+    const bool layout = K || ncoef > 0;                              // the input is a Layout{Aspheric}: Q16 dispatch
     const bool devp = flags & ORT_DEVICE_PTRS;
     if (!devp) for (int f = 0; f < nfields; ++f)
         if (!(std::fabs(fields[f]) <= 1.0)) return fail(ORT_EDOMAIN, "DomainError with %g: Domain: |H| <= 1.0", fields[f]);
@@ -541,9 +545,9 @@ int spot_batch_impl(ort_ctx* ctx, int nsys, int rows, const double* R, const dou
     if (!devp) for (int s = 0; s < nsys; ++s)
         if (t[(size_t)s * rows + rows - 1] != 0.0)
             return fail(ORT_EINVAL, "system %d: spot_batch expects a last thickness of 0 (image space)", s);
-    const double *dR = R, *dt = t, *dn = n, *da = a, *dh = hprime, *dfields = fields;
-    const size_t n_a = (size_t)nsys * (rows - 1);
-    const size_t in_cnt = 3 * nr + n_a + (size_t)nsys + (size_t)nfields;            // doubles, packed: one H2D copy
+    const double *dR = R, *dt = t, *dn = n, *dK = K, *dcoef = coef, *da = a, *dh = hprime, *dfields = fields;
+    const size_t n_a = (size_t)nsys * (rows - 1), n_c = (size_t)nsys * rows * (size_t)ncoef;
+    const size_t in_cnt = 3 * nr + (K ? nr : 0) + n_c + n_a + (size_t)nsys + (size_t)nfields;   // doubles, packed: one H2D copy
     // packed results of the statistics-only host call: [count | rms | first-order | flag], one D2H copy
     const size_t o_cnt = 0, o_rms = o_cnt + (size_t)na * sizeof(int64_t), o_fo = o_rms + (size_t)na * sizeof(double),
                  o_flag = o_fo + (size_t)nsys * sizeof(FirstOrderOut), out_bytes = o_flag + 8;
@@ -554,16 +558,23 @@ int spot_batch_impl(ort_ctx* ctx, int nsys, int rows, const double* R, const dou
         double* hp = reinterpret_cast<double*>(hpin); double* dp = reinterpret_cast<double*>(dpack);
         size_t o = 0;
         auto put = [&](const double* src, size_t cnt, const double** dev) { memcpy(hp + o, src, cnt * sizeof(double)); *dev = dp + o; o += cnt; };
-        put(R, nr, &dR); put(t, nr, &dt); put(n, nr, &dn); put(a, n_a, &da); put(hprime, (size_t)nsys, &dh); put(fields, (size_t)nfields, &dfields);
+        put(R, nr, &dR); put(t, nr, &dt); put(n, nr, &dn);
+        if (K) put(K, nr, &dK);
+        if (ncoef > 0) put(coef, n_c, &dcoef);
+        put(a, n_a, &da); put(hprime, (size_t)nsys, &dh); put(fields, (size_t)nfields, &dfields);
         HIP_TRY(hipMemcpyAsync(dpack, hpin, in_cnt * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
         HIP_TRY(hipStreamSynchronize(ctx->stream));              // the staging buffer is reused for the results below
     }
     unsigned char* dres = dpack ? dpack + in_cnt * sizeof(double) : nullptr;
     FirstOrderOut* d_fo; SurfRec<T>* d_rec; MerSurf *d_mf, *d_mr; double *d_tlf, *d_tlr, *d_ends; T* d_axes;
-    AimIn* d_ain; AimOut* d_aout; DevBundle<T>* d_bd; int* d_flag;
+    AimIn* d_ain; AimOut* d_aout; DevBundle<T>* d_bd; int* d_flag; T* d_cext = nullptr; double* d_crev = nullptr;
     if (dres) d_fo = reinterpret_cast<FirstOrderOut*>(dres + o_fo);
     else { rc = dev_out<FirstOrderOut>(ctx, SL_SB_FO, (size_t)nsys, &d_fo); if (rc) return rc; }
     rc = dev_out<SurfRec<T>>(ctx, SL_SB_REC, nr, &d_rec); if (rc) return rc;
+    if (ncoef > 0) {
+        rc = dev_out<T>(ctx, SL_SB_CEXT, (size_t)nsys * (rows + 1) * ncoef, &d_cext); if (rc) return rc;
+        rc = dev_out<double>(ctx, SL_SB_CREV, n_c, &d_crev); if (rc) return rc;
+    }
     rc = dev_out<MerSurf>(ctx, SL_SB_MF, (size_t)nsys * (rows - 1), &d_mf); if (rc) return rc;
     rc = dev_out<MerSurf>(ctx, SL_SB_MR, (size_t)nsys * (rows - 1), &d_mr); if (rc) return rc;
     rc = dev_out<double>(ctx, SL_SB_TLF, (size_t)nsys, &d_tlf); if (rc) return rc;
@@ -578,7 +589,7 @@ int spot_batch_impl(ort_ctx* ctx, int nsys, int rows, const double* R, const dou
     else { rc = dev_out<int>(ctx, SL_SB_FLAG, 1, &d_flag); if (rc) return rc; }
     TraceParams<T> p;
     memset(&p, 0, sizeof p);
-    p.recs = d_rec; p.coefs = nullptr; p.S = S; p.ncoef = 0; p.bundles = d_bd; p.axes = d_axes;
+    p.recs = d_rec; p.coefs = d_cext; p.S = S; p.ncoef = ncoef; p.bundles = d_bd; p.axes = d_axes;
     p.ny = k_rays; p.nx = k2; p.rpb = rpb; p.tiles_per_bundle = (int)((rpb + kTile - 1) / kTile);
     hipStream_t st = ctx->stream;
     auto nblk = [](int64_t n, int b) { return dim3((unsigned)((n + b - 1) / b)); };
@@ -587,11 +598,11 @@ int spot_batch_impl(ort_ctx* ctx, int nsys, int rows, const double* R, const dou
     // points (PupilSampling.jl:94-122) -> axes -> trace + stop filter + tile moments -> per-bundle RMS
     hipLaunchKernelGGL(k_first_order, nblk(nsys, 64), dim3(64), 0, st, nsys, rows, dR, dt, dn, da, (const double*)nullptr, dh,
                        587.5618e-6, d_fo);
-    hipLaunchKernelGGL((k_build_tables<T>), nblk((int64_t)nr, kBlock), dim3(kBlock), 0, st, nsys, rows, dR, dt, dn, d_fo, d_rec, d_mf, d_mr,
-                       d_tlf, d_tlr);
-    hipLaunchKernelGGL(k_build_aim, nblk(na, kBlock), dim3(kBlock), 0, st, nsys, nfields, rows, d_fo, da, dfields, d_ain);
-    hipLaunchKernelGGL(k_aim, nblk((int64_t)na * 4, 64), dim3(64), 0, st, na, d_ain, d_mf, (const double*)nullptr, d_tlf, d_mr,
-                       (const double*)nullptr, d_tlr, rows - 1, 0, d_aout);
+    hipLaunchKernelGGL((k_build_tables<T>), nblk((int64_t)nr, kBlock), dim3(kBlock), 0, st, nsys, rows, dR, dt, dn, dK,
+                       ncoef > 0 ? dcoef : (const double*)nullptr, ncoef, d_fo, d_rec, d_cext, d_mf, d_mr, d_crev, d_tlf, d_tlr);
+    hipLaunchKernelGGL(k_build_aim, nblk(na, kBlock), dim3(kBlock), 0, st, nsys, nfields, rows, d_fo, da, dfields, layout ? 1 : 0, d_ain);
+    hipLaunchKernelGGL(k_aim, nblk((int64_t)na * 4, 64), dim3(64), 0, st, na, d_ain, d_mf, ncoef > 0 ? dcoef : (const double*)nullptr, d_tlf,
+                       d_mr, (const double*)d_crev, d_tlr, rows - 1, ncoef, d_aout);
     hipLaunchKernelGGL((k_build_bundles<T>), nblk(na, kBlock), dim3(kBlock), 0, st, na, k_rays, k2, d_ain, d_aout, d_bd, d_ends, d_flag);
     hipLaunchKernelGGL((k_make_axes<T>), nblk((int64_t)na * (k_rays + k2), kBlock), dim3(kBlock), 0, st, na, k_rays, k2, d_ends, d_axes);
     HIP_TRY(hipGetLastError());
@@ -901,7 +912,7 @@ int ort_spot_batch_f64(ort_ctx* ctx, int nsys, int rows, const double* R, const 
                        const double* a, const double* hprime, int nfields, const double* fields, int k_rays,
                        ort_first_order* fo_out, int64_t* count, double* rms, unsigned flags)
 {
-    return spot_batch_impl<double>(ctx, nsys, rows, R, t, n, a, hprime, nfields, fields, k_rays, fo_out,
+    return spot_batch_impl<double>(ctx, nsys, rows, R, t, n, nullptr, nullptr, 0, a, hprime, nfields, fields, k_rays, fo_out,
                                    nullptr, nullptr, nullptr, nullptr, count, rms, flags);
 }
 
@@ -911,7 +922,17 @@ int ort_full_trace_batch_f64(ort_ctx* ctx, int nsys, int rows, const double* R, 
                              int64_t* count, double* rms, unsigned flags)
 {
     if (!ex || !ey || !rho || !theta) return fail(ORT_EINVAL, "full_trace_batch needs ex, ey, rho, theta (ort_spot_batch_f64 is the statistics-only call)");
-    return spot_batch_impl<double>(ctx, nsys, rows, R, t, n, a, hprime, nfields, fields, k_rays, fo_out,
+    return spot_batch_impl<double>(ctx, nsys, rows, R, t, n, nullptr, nullptr, 0, a, hprime, nfields, fields, k_rays, fo_out,
+                                   ex, ey, rho, theta, count, rms, flags);
+}
+
+int ort_full_trace_layout_batch_f64(ort_ctx* ctx, int nsys, int rows, const double* R, const double* t, const double* n,
+                                    const double* K, const double* coef, int ncoef,
+                                    const double* a, const double* hprime, int nfields, const double* fields, int k_rays,
+                                    ort_first_order* fo_out, double* ex, double* ey, double* rho, double* theta,
+                                    int64_t* count, double* rms, unsigned flags)
+{
+    return spot_batch_impl<double>(ctx, nsys, rows, R, t, n, K, coef, ncoef, a, hprime, nfields, fields, k_rays, fo_out,
                                    ex, ey, rho, theta, count, rms, flags);
 }
 
@@ -919,7 +940,7 @@ int ort_spot_batch_f32(ort_ctx* ctx, int nsys, int rows, const double* R, const 
                        const double* a, const double* hprime, int nfields, const double* fields, int k_rays,
                        ort_first_order* fo_out, int64_t* count, double* rms, unsigned flags)
 {
-    return spot_batch_impl<float>(ctx, nsys, rows, R, t, n, a, hprime, nfields, fields, k_rays, fo_out,
+    return spot_batch_impl<float>(ctx, nsys, rows, R, t, n, nullptr, nullptr, 0, a, hprime, nfields, fields, k_rays, fo_out,
                                   nullptr, nullptr, nullptr, nullptr, count, rms, flags);
 }
 

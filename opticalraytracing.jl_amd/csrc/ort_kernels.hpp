@@ -1004,71 +1004,103 @@ __global__ __launch_bounds__(64) void k_first_order(int nsys, int rows, const do
 // into bundle descriptors and axis end points (src/PupilSampling.jl:94-122).
 // ------------------------------------------------------------------------------------
 template <typename T>
-__device__ __forceinline__ void make_rec(SurfRec<T>& r, T t, T Rv, T n1, T n2)
+__device__ __forceinline__ void make_rec(SurfRec<T>& r, T t, T Rv, T n1, T n2, T Kv, int nc)
 {
     r.t = t; r.R = Rv; r.R2 = Rv * Rv;
     r.sgn = Rv > T(0) ? T(1) : (Rv < T(0) ? T(-1) : Rv);
-    r.opk = T(1); r.eta = n1 / n2; r.eta2 = r.eta * r.eta; r.K = T(0);
+    r.opk = T(1) + Kv; r.eta = n1 / n2; r.eta2 = r.eta * r.eta; r.K = Kv;
     r.finite = __builtin_isfinite(Rv) ? 1 : 0;
     r.invR = r.finite ? T(1) / Rv : T(0);
     r.ome2 = T(1) - r.eta2; r.e2c2 = r.eta2 * (r.invR * r.invR); r.ec = r.eta * fabs(r.invR);
-    r.ncoef = 0;
-    r.kind = !r.finite ? KIND_FLAT : KIND_SPHERE;
+    r.ncoef = nc;
+    r.kind = nc > 0 ? KIND_POLY : (!r.finite ? KIND_FLAT : (Kv != T(0) ? KIND_CONIC : KIND_SPHERE));
     if (r.kind == KIND_SPHERE && fabs((double)Rv) <= kCentreFormMaxR && sizeof(T) == 8) { r.kind = KIND_SPHERE_C; r.K = r.t + Rv; }
-    r.cls = (r.finite ? CLS_FINITE : 0) | ((r.eta != T(1)) ? CLS_REFR : 0) | (!(fabs(r.eta) <= T(1)) ? CLS_TIR : 0) |
-            (r.kind << CLS_KIND_SHIFT);
+    r.cls = (r.finite ? CLS_FINITE : 0) | (nc > 0 ? CLS_HASP : 0) | ((r.eta != T(1)) ? CLS_REFR : 0) |
+            (!(fabs(r.eta) <= T(1)) ? CLS_TIR : 0) | (r.kind << CLS_KIND_SHIFT);
 }
 
-// one thread per (system, loop index i): extended skew table [nsys][rows], forward and reversed
-// meridional tables [nsys][rows-1], last thicknesses
+// number of coefficients in use for a row: the whole width if any entry is non-zero AFTER the cast to T
+// (an all-zero row is the reference's `zero` polynomial), as ort_system_create does on the host
+template <typename T>
+__device__ __forceinline__ int row_ncoef(const double* __restrict__ c, int ncoef)
+{
+    int nc = 0;
+    for (int j = 0; j < ncoef; ++j) if ((T)c[j] != T(0)) nc = ncoef;
+    return nc;
+}
+
+// one thread per (system, loop index i): extended skew table [nsys][rows] (+ its coefficient rows
+// [nsys][rows+1][ncoef]), forward and reversed meridional tables [nsys][rows-1] (+ the reversed coefficient
+// rows [nsys][rows][ncoef]; the forward ones are the input), last thicknesses.  K, coef may be null.
 template <typename T>
 __global__ __launch_bounds__(kBlock) void k_build_tables(int nsys, int rows, const double* __restrict__ R, const double* __restrict__ t,
-                                                         const double* __restrict__ n, const FirstOrderOut* __restrict__ fo,
-                                                         SurfRec<T>* __restrict__ rec_ext, MerSurf* __restrict__ mer_fwd,
-                                                         MerSurf* __restrict__ mer_rev, double* __restrict__ tl_fwd,
+                                                         const double* __restrict__ n, const double* __restrict__ K,
+                                                         const double* __restrict__ coef, int ncoef,
+                                                         const FirstOrderOut* __restrict__ fo,
+                                                         SurfRec<T>* __restrict__ rec_ext, T* __restrict__ coef_ext,
+                                                         MerSurf* __restrict__ mer_fwd, MerSurf* __restrict__ mer_rev,
+                                                         double* __restrict__ crev, double* __restrict__ tl_fwd,
                                                          double* __restrict__ tl_rev)
 {
     const int64_t g = (int64_t)blockIdx.x * kBlock + threadIdx.x;
     if (g >= (int64_t)nsys * rows) return;
     const int s = (int)(g / rows), i = (int)(g - (int64_t)s * rows);
     const double* Rs = R + (int64_t)s * rows; const double* ts = t + (int64_t)s * rows; const double* ns = n + (int64_t)s * rows;
+    const double* Ks = K ? K + (int64_t)s * rows : nullptr;
+    const double* cs = (coef && ncoef > 0) ? coef + (int64_t)s * rows * ncoef : nullptr;
     const double BFD = fo[s].BFD;
     auto tt = [&](int j) { return (j == 0 && !__builtin_isfinite(ts[0])) ? 0.0 : ts[j]; };          // Lens() mutation (Q19)
-    // extended system (PupilSampling.jl:111-114): rows+1 rows, loop index i = 0..rows-1
+    // extended system (PupilSampling.jl:111-114): rows+1 rows, loop index i = 0..rows-1 is row i+1
     {
+        const bool real = i + 1 < rows;                                  // the last iteration is the appended image plane
         const double te = (i == rows - 1) ? BFD : tt(i);                 // t[end-1] = focus
-        const double Re = (i + 1 < rows) ? Rs[i + 1] : __builtin_inf();
-        const double n1 = ns[i], n2 = (i + 1 < rows) ? ns[i + 1] : 1.0;
+        const double Re = real ? Rs[i + 1] : __builtin_inf();
+        const double n1 = ns[i], n2 = real ? ns[i + 1] : 1.0;
+        const double Ke = (real && Ks) ? Ks[i + 1] : 0.0;                // K = [surfaces.K; 0.0]  (:112)
+        const int nc = (real && cs) ? row_ncoef<T>(cs + (int64_t)(i + 1) * ncoef, ncoef) : 0;
         SurfRec<T> r;
-        make_rec<T>(r, te, Re, n1, n2);
+        make_rec<T>(r, (T)te, (T)Re, (T)n1, (T)n2, (T)Ke, nc);
         rec_ext[(int64_t)s * rows + i] = r;
+        if (coef_ext) {
+            T* ce = coef_ext + (int64_t)s * (rows + 1) * ncoef;
+            for (int j = 0; j < ncoef; ++j) ce[(int64_t)(i + 1) * ncoef + j] = (real && cs) ? (T)cs[(int64_t)(i + 1) * ncoef + j] : T(0);
+            if (i == 0) for (int j = 0; j < ncoef; ++j) ce[j] = cs ? (T)cs[j] : T(0);
+        }
     }
     if (i < rows - 1) {
         MerSurf m;
-        m.t = tt(i); m.R = Rs[i + 1]; m.sgn = m.R > 0 ? 1.0 : (m.R < 0 ? -1.0 : m.R); m.K = 0.0;
-        m.n1 = ns[i]; m.n2 = ns[i + 1]; m.finite = __builtin_isfinite(m.R) ? 1 : 0; m.ncoef = 0;
+        m.t = tt(i); m.R = Rs[i + 1]; m.sgn = m.R > 0 ? 1.0 : (m.R < 0 ? -1.0 : m.R); m.K = Ks ? Ks[i + 1] : 0.0;
+        m.n1 = ns[i]; m.n2 = ns[i + 1]; m.finite = __builtin_isfinite(m.R) ? 1 : 0;
+        m.ncoef = cs ? row_ncoef<double>(cs + (int64_t)(i + 1) * ncoef, ncoef) : 0;
         mer_fwd[(int64_t)s * (rows - 1) + i] = m;
-        // reversed (RayTracing.jl:267-271): rev_R = -[Inf; R[end:-1:2]], rev_t = reverse(t) with rev_t[1] = BFD
+        // reversed (RayTracing.jl:267-274): rev_R = -[Inf; R[end:-1:2]], rev_t = reverse(t) with rev_t[1] = BFD,
+        // K and p plainly reversed (Q17): row j = i + 1 of the reversed system carries K[rows-1-j], p[rows-1-j]
         MerSurf q;
         q.t = (i == 0) ? BFD : tt(rows - 1 - i);
         q.R = -Rs[rows - 1 - i];                                         // rev_R[i+1] = -R[rows-1-i]
-        q.sgn = q.R > 0 ? 1.0 : (q.R < 0 ? -1.0 : q.R); q.K = 0.0;
-        q.n1 = ns[rows - 1 - i]; q.n2 = ns[rows - 2 - i]; q.finite = __builtin_isfinite(q.R) ? 1 : 0; q.ncoef = 0;
+        q.sgn = q.R > 0 ? 1.0 : (q.R < 0 ? -1.0 : q.R); q.K = Ks ? Ks[rows - 2 - i] : 0.0;
+        q.n1 = ns[rows - 1 - i]; q.n2 = ns[rows - 2 - i]; q.finite = __builtin_isfinite(q.R) ? 1 : 0;
+        q.ncoef = cs ? row_ncoef<double>(cs + (int64_t)(rows - 2 - i) * ncoef, ncoef) : 0;
         mer_rev[(int64_t)s * (rows - 1) + i] = q;
+        if (crev) {
+            double* cr = crev + (int64_t)s * rows * ncoef;
+            for (int j = 0; j < ncoef; ++j) cr[(int64_t)(i + 1) * ncoef + j] = cs[(int64_t)(rows - 2 - i) * ncoef + j];
+            if (i == 0) for (int j = 0; j < ncoef; ++j) cr[j] = cs[(int64_t)(rows - 1) * ncoef + j];
+        }
     }
     if (i == 0) { tl_fwd[s] = tt(rows - 1); tl_rev[s] = tt(0); }
 }
 
 __global__ __launch_bounds__(kBlock) void k_build_aim(int nsys, int nf, int rows, const FirstOrderOut* __restrict__ fo,
                                                       const double* __restrict__ a, const double* __restrict__ fields,
-                                                      AimIn* __restrict__ ain)
+                                                      int layout_fwd, AimIn* __restrict__ ain)
 {
     const int g = blockIdx.x * kBlock + threadIdx.x;
     if (g >= nsys * nf) return;
     const int s = g / nf, f = g - s * nf;
     const FirstOrderOut o = fo[s];
     AimIn q;
-    q.system = s; q.stop = o.stop; q.layout_fwd = 0; q.layout_rev = 1;
+    q.system = s; q.stop = o.stop; q.layout_fwd = layout_fwd; q.layout_rev = 1;   // the reversed system is always a Layout (:272-276)
     q.H = fabs(fields[f]); q.y_marg = o.y_marg; q.a_stop = a[(int64_t)s * (rows - 1) + o.stop - 1];
     q.chief_y_end = o.chief_y_end; q.chief_u_end = o.chief_u_end; q.f = o.f; q.atol = 1.4901161193847656e-08;
     ain[g] = q;

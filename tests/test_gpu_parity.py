@@ -816,6 +816,43 @@ def test_full_trace_batch_one_call(hip_engine, oracle_engine):
                 assert abs(r["rms"] - e.RMS) <= tol * max(e.RMS, 1e-3)
 
 
+def test_full_trace_layout_batch_aspheric(hip_engine, oracle_engine):
+    """ort_full_trace_layout_batch_f64: the one-call pipeline on aspheric Layouts (conic constants +
+    polynomial rows; the reversed system with K, p plainly reversed, RayTracing.jl:272-274) against the
+    host-driven route `full_trace(solve(Layout), H, k)` through the oracle, and against the staged device
+    route through the same library."""
+    from opticalraytracing_jl_amd import batch, workloads
+    fields, k = (0.0, 0.7, 1.0), 48
+    M4s, coefs = zip(*(workloads.double_gauss_aspheric(line) for line in (0, 1, 2)))
+    mats, coef = np.array(M4s), np.array(coefs)
+    fo, res = batch.full_trace_systems(mats, cm.DG_A, cm.DG_H, fields=fields, k_rays=k, engine=hip_engine, coef=coef)
+    for i in range(3):
+        lay = ort.Layout(mats[i, :, 0], mats[i, :, 1], mats[i, :, 2], mats[i, :, 3], [c for c in coef[i]])
+        so = ort.solve(lay, cm.DG_A, cm.DG_H, engine=oracle_engine)
+        sg = ort.solve(lay, cm.DG_A, cm.DG_H, engine=hip_engine)
+        assert fo["stop"][i] == so.stop and abs(fo["f"][i] - so.f) <= 1e-11 * abs(so.f)
+        for fi, H in enumerate(fields):
+            r = res[i * len(fields) + fi]
+            eo = ort.full_trace(so, H, k, engine=oracle_engine)
+            eg = ort.full_trace(sg, H, k, engine=hip_engine)
+            # the outermost grid rows sit ON the stop rim (the edge rays are aimed at it to sqrt(eps)) and fall either
+            # side with the last digits of the aiming; on this strongly aberrated system each such ray moves the RMS by
+            # ~0.1 %.  So: total counts within a few rays, RMS within 1 %, and — the sharp check — the two sets of
+            # transverse errors coincide (to 1e-5 mm) except for those few rim rays.
+            assert r["count"] > 0
+            key = lambda x, y: set(zip(np.round(np.asarray(x) / 1e-5).astype(np.int64), np.round(np.asarray(y) / 1e-5).astype(np.int64)))
+            mine = key(r["ex"], r["ey"])
+            for e in (eo, eg):
+                assert abs(r["count"] - len(e.x)) <= 8 and abs(r["rms"] - e.RMS) <= 1e-2 * e.RMS, (i, H)
+                theirs = key(e.x, e.y)
+                assert len(mine ^ theirs) <= 24 and len(mine & theirs) >= 0.98 * min(len(mine), len(theirs)), (i, H)
+            half = r["count"] // 2
+            assert np.array_equal(r["ex"][half:], -r["ex"][:half])
+    # the aspheric terms matter: the same prescriptions without them give different spots
+    _, plain = batch.full_trace_systems(mats[:, :, :3], cm.DG_A, cm.DG_H, fields=fields, k_rays=k, engine=hip_engine)
+    assert max(abs(p["rms"] - r["rms"]) / r["rms"] for p, r in zip(plain, res)) > 1e-2
+
+
 def test_plain_c_caller_matches_host_mirror(hip_engine):
     """The drop-in boundary used from plain C (examples/cooke_full_trace.c, no Python in the process): same
     first-order numbers and spot sizes as the Python host mirror over the same library."""
