@@ -553,7 +553,7 @@ int spot_batch_impl(ort_ctx* ctx, int nsys, int rows, const double* R, const dou
                  o_flag = o_fo + (size_t)nsys * sizeof(FirstOrderOut), out_bytes = o_flag + 8;
     unsigned char* hpin = nullptr; unsigned char* dpack = nullptr;
     if (!devp) {
-        rc = ctx->pinned(std::max(in_cnt * sizeof(double), out_bytes), &hpin); if (rc) return rc;
+        rc = ctx->pinned(in_cnt * sizeof(double) + out_bytes, &hpin); if (rc) return rc;   // [inputs | results]: no reuse, no mid-call sync
         rc = dev_out<unsigned char>(ctx, SL_SB_PACK, in_cnt * sizeof(double) + out_bytes, &dpack); if (rc) return rc;
         double* hp = reinterpret_cast<double*>(hpin); double* dp = reinterpret_cast<double*>(dpack);
         size_t o = 0;
@@ -563,8 +563,8 @@ int spot_batch_impl(ort_ctx* ctx, int nsys, int rows, const double* R, const dou
         if (ncoef > 0) put(coef, n_c, &dcoef);
         put(a, n_a, &da); put(hprime, (size_t)nsys, &dh); put(fields, (size_t)nfields, &dfields);
         HIP_TRY(hipMemcpyAsync(dpack, hpin, in_cnt * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
-        HIP_TRY(hipStreamSynchronize(ctx->stream));              // the staging buffer is reused for the results below
     }
+    unsigned char* hres = hpin ? hpin + in_cnt * sizeof(double) : nullptr;   // results land behind the inputs
     unsigned char* dres = dpack ? dpack + in_cnt * sizeof(double) : nullptr;
     FirstOrderOut* d_fo; SurfRec<T>* d_rec; MerSurf *d_mf, *d_mr; double *d_tlf, *d_tlr, *d_ends; T* d_axes;
     AimIn* d_ain; AimOut* d_aout; DevBundle<T>* d_bd; int* d_flag; T* d_cext = nullptr; double* d_crev = nullptr;
@@ -618,18 +618,18 @@ int spot_batch_impl(ort_ctx* ctx, int nsys, int rows, const double* R, const dou
                                reinterpret_cast<int64_t*>(dres + o_cnt), reinterpret_cast<double*>(dres + o_rms),
                                flags | ORT_DEVICE_PTRS);
         if (rc) return rc;
-        HIP_TRY(hipMemcpyAsync(hpin, dres, out_bytes, hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipMemcpyAsync(hres, dres, out_bytes, hipMemcpyDeviceToHost, st));
         HIP_TRY(hipStreamSynchronize(st));
-        memcpy(count, hpin + o_cnt, (size_t)na * sizeof(int64_t));
-        memcpy(rms, hpin + o_rms, (size_t)na * sizeof(double));
+        memcpy(count, hres + o_cnt, (size_t)na * sizeof(int64_t));
+        memcpy(rms, hres + o_rms, (size_t)na * sizeof(double));
     } else {
         rc = run_full_trace<T>(ctx, p, na, ex, ey, rho, theta, count, rms, flags); if (rc) return rc;
-        HIP_TRY(hipMemcpyAsync(hpin + o_fo, dres + o_fo, out_bytes - o_fo, hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipMemcpyAsync(hres + o_fo, dres + o_fo, out_bytes - o_fo, hipMemcpyDeviceToHost, st));
         HIP_TRY(hipStreamSynchronize(st));
     }
-    if (fo_out) memcpy(fo_out, hpin + o_fo, (size_t)nsys * sizeof(FirstOrderOut));
+    if (fo_out) memcpy(fo_out, hres + o_fo, (size_t)nsys * sizeof(FirstOrderOut));
     int flag = 0;
-    memcpy(&flag, hpin + o_flag, sizeof(int));
+    memcpy(&flag, hres + o_flag, sizeof(int));
     if (flag) return fail(ORT_EHIP, "ray aiming did not converge for at least one (system, field) pair");
     return ORT_OK;
 }
