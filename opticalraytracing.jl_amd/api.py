@@ -769,7 +769,7 @@ def _stack_prescriptions(press: Sequence[Prescription]) -> Prescription:
 
 def full_trace_aim_batch(systems: Sequence[System], fields: Sequence[float], focus=None, engine=None) -> List[List[Aiming]]:
     """Aiming for every (system, field) pair in ONE device launch (ort_aim_f64): the Newton loops of
-    RayTracing.jl:223-296 and the edge-ray search run one thread per pair.  Returns
+    RayTracing.jl:223-296 and the edge-ray search run four lanes per pair.  Returns
     aims[system][field].  All systems must have the same number of rows."""
     eng = _eng(engine)
     fields = [abs(float(H)) for H in fields]

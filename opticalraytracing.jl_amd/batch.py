@@ -3,7 +3,7 @@ api.py (`solve` -> `full_trace`) restated over arrays so that 10^4 perturbed ins
 handful of launches and no per-instance Python:
 
     first-order solve + Seidel sums   ort_first_order_f64   one thread per instance
-    real-ray aiming                   ort_aim_f64           one thread per (instance, field)
+    real-ray aiming                   ort_aim_f64           four lanes per (instance, field)
     pupil grid trace + spot stats     ort_full_trace_f64    statistics-only mode (16 B per bundle out)
 
 Reference lines: solve src/RayTracing.jl:302-335, aberrations src/SeidelAberrations.jl:6-53,
@@ -79,7 +79,7 @@ def tolerance_run(mats: np.ndarray, a, hprime, fields: Sequence[float] = (0.0,),
     rev_t = t[:, ::-1].copy(); rev_t[:, 0] = BFD
     rev_n = n[:, ::-1].copy()
     rev = Prescription(rev_R, rev_t, rev_n, np.zeros_like(rev_R))
-    # aiming: one thread per (instance, field)
+    # aiming: four lanes per (instance, field)
     na = ninst * nf
     ain = (_capi.ort_aim_in * na)()
     dt_in = np.dtype([("system", np.int32), ("stop", np.int32), ("layout_fwd", np.int32), ("layout_rev", np.int32),

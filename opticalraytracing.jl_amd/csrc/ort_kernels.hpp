@@ -680,7 +680,7 @@ __global__ __launch_bounds__(kBlock) void k_trace_meridional(const MerSurf* __re
 }
 
 // ------------------------------------------------------------------------------------
-// Batched ray aiming (SURVEY §8f "next #1"): one thread per (system, field) runs the Newton
+// Batched ray aiming (SURVEY §8f "next #1"): four lanes per (system, field) run the Newton
 // drivers of src/RayTracing.jl:223-240 (real marginal), :265-296 (real chief, on the reversed
 // system) and the edge-ray search of src/PupilSampling.jl:67-83 (restated as the same
 // FD-Newton, see api._trace_edge_rays), and emits the aiming scalars of
