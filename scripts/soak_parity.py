@@ -42,7 +42,14 @@ for case in range(nsys):
     err = np.maximum(cm.rel_err(fx, ox, 1.0).max(axis=0), cm.rel_err(fy, oy, 1.0).max(axis=0))
     nfr += int(((fs != os_) | (sane & (err > 1e-9))).sum()); ntot += m
     if sane.any():
-        worst_fast = max(worst_fast, float(np.median(err[sane])))
+        med = float(np.median(err[sane]))
+        if med > 1e-9:
+            j = int(np.argmax(np.where(sane, err, 0)))
+            print("FAST OFF case", case, "rows", rows, "aspheric", aspheric, "median", med, "nsane", int(sane.sum()),
+                  "\n R", R.tolist(), "\n t", t.tolist(), "\n n", n.tolist(), "\n K", K.tolist(),
+                  "\n ray", float(y[j]), float(x[j]), float(u[j]), float(v[j]),
+                  "\n ox", ox[:, j].tolist(), "\n fx", fx[:, j].tolist(), flush=True)
+        worst_fast = max(worst_fast, med)
     if case % 250 == 0:
         print(f"case {case}: mismatching systems so far {bad}, fast fringe {nfr}/{ntot}", flush=True)
 print(f"DONE {nsys} systems x 800 rays, seed {seed}: IEEE mismatching systems {bad}; FAST fringe (status flip or > 1e-9) {nfr}/{ntot} = {nfr / ntot:.2e}; "
