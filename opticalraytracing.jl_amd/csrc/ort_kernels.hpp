@@ -559,25 +559,36 @@ __global__ __launch_bounds__(kBlock) void k_ft_scatter(const T* __restrict__ w_e
     int woff = 0;
     for (int w = 0; w < wave; ++w) woff += s_wcnt[w];
     const int64_t out0 = (int64_t)b * 2 * rpb;            // bundle region
-    const int64_t base = out0 + tile_off[blockIdx.x] + woff + rank0;
+    // Survivors are compacted into LDS first and streamed out by the whole workgroup: every store instruction
+    // then writes 64 consecutive elements (the per-lane scatter wrote every other slot and took 2 instructions
+    // per row of a wave — half-used cache lines, 2.4 TB/s).
+    __shared__ T s_ex[kTile], s_ey[kTile], s_rh[kTile], s_th[kTile];
     double sq = 0.0;
-    int k = 0;
+    int k = woff + rank0;
 #pragma unroll
     for (int r = 0; r < kRPT; ++r) {
         if (keep[r]) {
-            const int64_t o = base + k;
-            const T rh = rr[r] / (T)a.rmax;                           // :142
-            if (ex) {                                                     // NULL outputs: statistics only
-                ex[o] = e_x[r];  ey[o] = e_y[r];  rho[o] = rh;  theta[o] = th[r];
-                ex[o + a.m] = -e_x[r];                                    // :141
-                ey[o + a.m] = e_y[r];                                     // :140
-                rho[o + a.m] = rh;                                        // :143
-                theta[o + a.m] = (T)3.141592653589793 - th[r];            // :144
-            }
+            s_ex[k] = e_x[r]; s_ey[k] = e_y[r]; s_th[k] = th[r];
+            s_rh[k] = rr[r] / (T)a.rmax;                                  // :142
             const double dx1 = (double)e_x[r] - a.mux, dx2 = -(double)e_x[r] - a.mux;
             const double dy = (double)e_y[r] - a.muy;
             sq += (dx1 * dx1 + dx2 * dx2) + (dy * dy + dy * dy);
             ++k;
+        }
+    }
+    __syncthreads();
+    if (ex) {                                                             // NULL outputs: statistics only
+        int cnt = 0;
+        for (int w = 0; w < kBlock / 64; ++w) cnt += s_wcnt[w];
+        const int64_t base = out0 + tile_off[blockIdx.x];
+        for (int j = tid; j < cnt; j += kBlock) {
+            const int64_t o = base + j;
+            const T vx = s_ex[j], vy = s_ey[j], vr = s_rh[j], vt = s_th[j];
+            ex[o] = vx;  ey[o] = vy;  rho[o] = vr;  theta[o] = vt;
+            ex[o + a.m] = -vx;                                            // :141
+            ey[o + a.m] = vy;                                             // :140
+            rho[o + a.m] = vr;                                            // :143
+            theta[o + a.m] = (T)3.141592653589793 - vt;                   // :144
         }
     }
     for (int off = 32; off > 0; off >>= 1) sq += __shfl_down(sq, off);
