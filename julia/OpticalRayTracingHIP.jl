@@ -153,4 +153,28 @@ function spot_batch(instances::Vector{<:AbstractMatrix}, a::AbstractVector, h′
     return cnt, rms
 end
 
+# full_trace(system::System{Layout{Aspheric}}, H, k_rays) for a batch of aspheric Layouts in ONE call
+# (ort_full_trace_layout_batch_f64): `layouts` :: Vector{Layout} of equal size, `coef` :: rows × ncoef power-series
+# table shared by the instances (or `nothing`).  Returns a Vector{RealRayError}, instance-major, field-minor.
+function full_trace_batch(layouts::Vector{<:Layout}, a::AbstractVector, h′::Float64, fields::Vector{Float64},
+                          k_rays::Int = 64; coef = nothing, flags::UInt32 = UInt32(0))
+    ninst = length(layouts); rows = size(layouts[1].M, 1); nf = length(fields)
+    col(j) = reduce(vcat, (Float64.(L.M[:, j]) for L in layouts))
+    R, t, n, K = col(1), col(2), col(3), reduce(vcat, (Float64.(L.K) for L in layouts))
+    ncoef = coef === nothing ? 0 : size(coef, 2)
+    coefT = coef === nothing ? nothing : repeat(vec(permutedims(coef)), ninst)          # [ninst][rows][ncoef]
+    av = repeat(Float64.(a), ninst); hp = fill(h′, ninst)
+    cap = 2 * k_rays * div(k_rays, 2); na = ninst * nf
+    εx = Matrix{Float64}(undef, cap, na); εy = similar(εx); ρ = similar(εx); θ = similar(εx)
+    cnt = Vector{Int64}(undef, na); rms = Vector{Float64}(undef, na)
+    GC.@preserve R t n K coefT av hp fields εx εy ρ θ cnt rms check(ccall((:ort_full_trace_layout_batch_f64, LIB), Cint,
+        (Ptr{Cvoid}, Cint, Cint, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Cint,
+         Ptr{Float64}, Ptr{Float64}, Cint, Ptr{Float64}, Cint, Ptr{Cvoid},
+         Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Int64}, Ptr{Float64}, UInt32),
+        ctx().h, ninst, rows, R, t, n, K, coefT === nothing ? C_NULL : pointer(coefT), ncoef,
+        av, hp, nf, fields, k_rays, C_NULL, εx, εy, ρ, θ, cnt, rms, flags))
+    return [RealRayError(εx[1:cnt[b], b], εy[1:cnt[b], b], NaN, ρ[1:cnt[b], b], θ[1:cnt[b], b], fields[(b - 1) % nf + 1], rms[b])
+            for b in 1:na]                              # nu (marginal.nu[end]) is in the first-order struct when fo_out is passed
+end
+
 end # module
