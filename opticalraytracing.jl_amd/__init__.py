@@ -19,7 +19,7 @@ from .api import (  # noqa: F401
     RealRay, RealRayError, RealRayT, Sagittal, Skew, Spherical, System, Tangential, TransferMatrix,
     VectorRealRay, compute_surfaces, extended_prescription, flatten, full_trace, full_trace_aim,
     full_trace_aim_batch, full_trace_batch, full_trace_grid, reversed_layout, incidences, linrange, linrange_batch, raytrace, reverse_transfer, sag, solve, surface_ray,
-    surface_to_focus, trace_chief_ray, trace_marginal_ray, transfer, transfer_real, wavegrad,
+    surface_to_focus, trace_chief_ray, trace_marginal_ray, transfer, transfer_real, wavegrad, refract, scale, raypoints,
 )
 from .analysis import SA, TSA, Aberration, RayError, Vignetting, aberrations, vignetting  # noqa: F401
 from .engine import HipEngine, Prescription, default_engine, set_default_engine  # noqa: F401

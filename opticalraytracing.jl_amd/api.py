@@ -848,7 +848,23 @@ def _mat(M):
     return np.asarray(M, dtype=np.float64).reshape(2, 2)
 
 
-def transfer(M, v, tau, tau_p, engine=None):                           # :10-11
+def refract(y, w, phi):                                                # RayTracing.jl:66-69
+    """Paraxial refraction of the reduced angle: ω′ = ω − y ϕ."""
+    return w - y * phi
+
+
+def transfer(*args, engine=None):
+    """transfer(y, ω, τ) → y′ and transfer(y, ω, τ, ϕ) → (y′, ω′): the paraxial primitives
+    (RayTracing.jl:55-64; a transfer over τ = Inf leaves y unchanged), on scalars as in the reference;
+    transfer(M, v, τ, τ′): image-space vector through an ABCD matrix (TransferMatrix.jl:10-11, on the GPU)."""
+    if np.ndim(args[0]) == 0 and not isinstance(args[0], (TransferMatrix, System)):
+        if len(args) == 3:                                             # :61-64
+            y, w, tau = args
+            return y + w * tau if math.isfinite(tau) else y
+        y, w, tau, phi = args                                          # :55-59
+        yp = transfer(y, w, tau)
+        return yp, refract(yp, w, phi)
+    M, v, tau, tau_p = args                                            # TransferMatrix.jl:10-11
     v = np.asarray(v, dtype=np.float64)
     out = _eng(engine).abcd_transfer(_mat(M), v, tau, tau_p, reverse=False)
     return out[0] if v.ndim == 1 else out
@@ -858,6 +874,21 @@ def reverse_transfer(M, v, tau_p, tau, engine=None):                   # :13-17
     v = np.asarray(v, dtype=np.float64)
     out = _eng(engine).abcd_transfer(_mat(M), v, tau, tau_p, reverse=True)
     return out[0] if v.ndim == 1 else out
+
+
+def scale(lens: "Lens") -> "Lens":
+    """`scale!(M::Lens)`: powers from 1/m to 1/mm, in place (RayTracing.jl:9-12)."""
+    lens.M[:, 1] *= 1e-3
+    return lens
+
+
+def raypoints(*args):
+    """Plot points of the paraxial marginal and chief rays (RayPlot.jl:4-24): (z, [y0, y1, y2, ȳ, y3, y4])."""
+    marginal, chief = (args[0].marginal, args[0].chief) if len(args) == 1 else args
+    z = marginal.z
+    y1 = marginal.y if marginal.u[0] == 0 else np.concatenate([[0.0], marginal.y[1:]])
+    yb = np.concatenate([[chief.y[1] + chief.nu[0] * z[0]], chief.y[1:]])
+    return z, [np.zeros_like(z), y1, -y1, yb, yb + y1, yb - y1]
 
 
 def flatten(M):                                                        # :19-28

@@ -110,3 +110,17 @@ def test_real_trace_keyword_forms(oracle_engine):
     xv, yv = ort.raytrace(surf, 3.0, 1.0, 0.02, 0.0, ort.VectorRealRay, K=np.zeros(8), engine=oracle_engine)
     xv0, yv0 = ort.raytrace(surf, 3.0, 1.0, 0.02, 0.0, ort.VectorRealRay, engine=oracle_engine)
     assert np.array_equal(xv, xv0) and np.array_equal(yv, yv0)
+
+
+def test_paraxial_primitives_and_raypoints(oracle_engine):
+    """transfer / refract scalar forms (RayTracing.jl:55-69), scale! (:9-12), raypoints (RayPlot.jl:4-24)."""
+    import math
+    assert ort.transfer(1.0, 0.1, 5.0) == 1.5 and ort.transfer(1.0, 0.1, math.inf) == 1.0
+    assert ort.transfer(1.0, 0.1, 5.0, 0.02) == (1.5, 0.1 - 1.5 * 0.02) and ort.refract(2.0, 0.3, 0.1) == 0.3 - 0.2
+    system = ort.solve(cm.cooke(), cm.COOKE_A, cm.COOKE_H, engine=oracle_engine)
+    z, ys = ort.raypoints(system)
+    assert len(ys) == 6 and all(len(y) == len(z) for y in ys)
+    assert np.array_equal(ys[2], -ys[1]) and np.allclose(ys[4] - ys[3], ys[1]) and np.allclose(ys[5] - ys[3], ys[2])
+    lens = ort.Lens(cm.cooke())
+    phi = lens.M[:, 1].copy()
+    assert ort.scale(lens) is lens and np.allclose(lens.M[:, 1], phi * 1e-3)
