@@ -229,9 +229,24 @@ typedef struct ort_first_order {
     double W040, W131, W222, W220, W311, W020, W111, W220P;     /* waves at lambda */
     int32_t stop, k;
 } ort_first_order;
+/* The last thickness of every prescription must be 0 or infinite (image space): with a finite non-zero one
+ * Lens() keeps the last row and the reference needs `rows` semi-diameters (DimensionMismatch for rows-1):
+ * ORT_EINVAL (host pointers; with ORT_DEVICE_PTRS the stop search is bounded to the rows-1 given).        */
 int ort_first_order_f64(ort_ctx *ctx, int nsys, int rows, const double *R, const double *t, const double *n,
                         const double *a, const double *dn, const double *hprime, double lambda,
                         ort_first_order *out, unsigned flags);
+
+/* The same solve with the PER-SURFACE third-order contributions of `aberrations` (the vectors of the
+ * Aberration struct, src/SeidelAberrations.jl:25-34, src/Types.jl:143-167) and the paraxial incidence table of
+ * `incidences(surfaces, system)` = [ni nī i ī] (src/RayTracing.jl:338-353), for every system of the batch:
+ *   surf : [ORT_SURF_COUNT][nsys][rows-1]   component-major; system s, surface j at surf[(c*nsys + s)*(rows-1) + j]
+ *   inc  : [4][nsys][rows-1]                 columns ni, nī, i, ī in that order
+ * either may be NULL.  `out` as in ort_first_order_f64 (W220M = W220P + W222, W220T = W220P + 1.5 W222).   */
+enum { ORT_SURF_SPHERICAL = 0, ORT_SURF_COMA, ORT_SURF_ASTIGMATISM, ORT_SURF_SAGITTAL, ORT_SURF_DISTORTION,
+       ORT_SURF_AXIAL, ORT_SURF_LATERAL, ORT_SURF_PETZVAL, ORT_SURF_MEDIAL, ORT_SURF_TANGENTIAL, ORT_SURF_COUNT };
+int ort_aberrations_f64(ort_ctx *ctx, int nsys, int rows, const double *R, const double *t, const double *n,
+                        const double *a, const double *dn, const double *hprime, double lambda,
+                        ort_first_order *out, double *surf, double *inc, unsigned flags);
 
 /* ---- device-resident spot pipeline: full_trace(solve(surfaces, a, h′), H, k_rays).RMS -------
  * for nsys spherical prescriptions x nfields fields in ONE call with no host round trip between

@@ -29,6 +29,9 @@ ORT_STATUS_VIGNETTED = 1 << 17
 ORT_MAX_ROWS = 64
 ORT_MAX_NCOEF = 12
 ORT_EDOMAIN = -2
+ORT_SURF_NAMES = ("spherical", "coma", "astigmatism", "sagittal", "distortion", "axial", "lateral", "petzval",
+                  "medial", "tangential")     # ORT_SURF_* order of include/ort.h
+ORT_INC_NAMES = ("ni", "nibar", "i", "ibar")
 
 
 class OrtError(RuntimeError):
@@ -114,6 +117,7 @@ SIGNATURES = {
     "ort_full_trace_f32": (_i, [_p, _p, _i, C.POINTER(ort_bundle), _p, _l, _i, _i, _p, _p, _p, _p, _p, _p, _u]),
     "ort_aim_f64": (_i, [_p, _p, _p, _i, C.POINTER(ort_aim_in), C.POINTER(ort_aim_out), _u]),
     "ort_first_order_f64": (_i, [_p, _i, _i, _p, _p, _p, _p, _p, _p, C.c_double, C.POINTER(ort_first_order), _u]),
+    "ort_aberrations_f64": (_i, [_p, _i, _i, _p, _p, _p, _p, _p, _p, C.c_double, C.POINTER(ort_first_order), _p, _p, _u]),
     "ort_spot_batch_f64": (_i, [_p, _i, _i, _p, _p, _p, _p, _p, _i, _p, _i, C.POINTER(ort_first_order), _p, _p, _u]),
     "ort_full_trace_batch_f64": (_i, [_p, _i, _i, _p, _p, _p, _p, _p, _i, _p, _i, C.POINTER(ort_first_order),
                                       _p, _p, _p, _p, _p, _p, _u]),

@@ -293,7 +293,8 @@ def image_hits(mats: np.ndarray, a, hprime, fields: Sequence[float], k: int, eng
     spec["y_marg"] = fo["y_marg"][inst]; spec["a_stop"] = a_stop; spec["chief_y_end"] = fo["chief_y_end"][inst]
     spec["chief_u_end"] = fo["chief_u_end"][inst]; spec["f"] = fo["f"][inst]; spec["atol"] = EPS
     aout = (_capi.ort_aim_out * nb)()
-    _capi.check(eng.ctx.lib.ort_aim_f64(eng.ctx.h, eng.system(fwd).h, eng.system(rev).h, nb, ain, aout, eng.base_flags))
+    sf, sr = eng.system(fwd), eng.system(rev)                    # objects held across the call (HipEngine.system)
+    _capi.check(eng.ctx.lib.ort_aim_f64(eng.ctx.h, sf.h, sr.h, nb, ain, aout, eng.base_flags))
     dt_out = np.dtype([(kk, np.float64) for kk in ("U", "y1", "y2", "y_EP", "hprime", "EP_t", "Ubar")] +
                       [("iters", np.int32), ("ok", np.int32)])
     aim = np.frombuffer(aout, dtype=dt_out, count=nb)
@@ -334,6 +335,7 @@ def image_hits(mats: np.ndarray, a, hprime, fields: Sequence[float], k: int, eng
         out = _capi.ort_grid_out_f64()
         trace = lib.ort_trace_grid_f64
     out.xf, out.yf, out.status = xf.data_ptr(), yf.data_ptr(), st.data_ptr()
-    _capi.check(trace(h, eng.system(ext).h, nb, barr, d_axes.data_ptr(), d_axes.numel(), k, k, C.byref(out), fl))
+    se = eng.system(ext)
+    _capi.check(trace(h, se.h, nb, barr, d_axes.data_ptr(), d_axes.numel(), k, k, C.byref(out), fl))
     eng.ctx.synchronize()
     return xf, yf, st

@@ -49,7 +49,7 @@ struct alignas(16) SurfRec {
     T ec;      // eta |c|                     MATH_FAST centre form
     int32_t finite;   // isfinite(R)          :2
     int32_t ncoef;    // coefficients in use for this row (0 -> p = zero)
-    int32_t kind;     // MATH_FAST row class: KIND_SPHERE / KIND_FLAT / KIND_CONIC / KIND_POLY
+    int32_t farmask;  // MATH_FAST centre form: v_cmp_class mask of the Qz that lie BEYOND the equator (sign(R) Qz > 0)
     int32_t cls;      // packed wave-uniform class bits (CLS_*), read once per surface
 };
 
@@ -76,6 +76,15 @@ template <> __device__ __forceinline__ double t_nan<double>() { return __builtin
 template <> __device__ __forceinline__ float t_nan<float>() { return __builtin_nanf(""); }
 
 template <typename T> __device__ __forceinline__ bool t_isnan(T a) { return a != a; }
+
+// v_cmp_class: does `a` belong to one of the classes of `mask` (bit 2/3/4 = -inf/-normal/-denormal, 7/8/9 = +denormal/
+// +normal/+inf; NaNs are bits 0-1)?  The mask is a runtime operand.
+__device__ __forceinline__ bool t_class(double a, int mask) { return __builtin_amdgcn_class(a, mask); }
+__device__ __forceinline__ bool t_class(float a, int mask) { return __builtin_amdgcn_classf(a, mask); }
+constexpr int kClassPositive = 0x380, kClassNegative = 0x01c;
+
+__device__ __forceinline__ double t_abs(double a) { return __builtin_fabs(a); }
+__device__ __forceinline__ float t_abs(float a) { return __builtin_fabsf(a); }
 
 template <typename T> __device__ __forceinline__ T t_max(T a, T b);
 template <> __device__ __forceinline__ double t_max<double>(double a, double b) { return __builtin_fmax(a, b); }
@@ -258,7 +267,11 @@ __device__ __forceinline__ float ieee_sqrt(float x) { return __builtin_sqrtf(x);
 // FINITE = isfinite(R) (:2), HASP = the row carries polynomial coefficients: both are
 // wave-uniform, so the kernel branches on them ONCE per surface and runs this straight-line
 // body for all of a lane's rays (the scheduler interleaves their div/sqrt chains).
-template <typename T, bool FINITE, bool HASP>
+// LAST = the final loop iteration: xv[i], yv[i] (:61-62) are fixed once the sag is added, and nothing the
+// reference computes afterwards in that iteration (tilt, refract!, slopes) reaches an output — skipped.
+// Rows without a polynomial drop the reference's `+ zero(y)` / `+ dp_dy(zero, .)` additions of 0.0: a + 0.0 == a
+// bit for bit except for a = -0.0 (-> +0.0), and a zero's sign reaches no output (no division by it).
+template <typename T, bool FINITE, bool HASP, bool LAST>
 __device__ __forceinline__ void surface_step_ieee(Ray<T>& r, const SurfRec<T>& s,
                                                   const T* __restrict__ coef)
 {
@@ -272,7 +285,6 @@ __device__ __forceinline__ void surface_step_ieee(Ray<T>& r, const SurfRec<T>& s
         const T D = beta * beta - r2 * ((s.opk + r.u * r.u) + r.v * r.v);   // :5
         sg = ieee_div(r2, beta + s.sgn * ieee_sqrt(D));          // :7
         if (HASP) sg = sg + poly_eval<T>(coef, s.ncoef, r.y);
-        else      sg = sg + T(0);
         sg = (D >= T(0)) ? sg : t_nan<T>();                      // :6,9
     } else {
         sg = T(0);                                               // :12
@@ -280,6 +292,7 @@ __device__ __forceinline__ void surface_step_ieee(Ray<T>& r, const SurfRec<T>& s
     r.y = r.y + sg * r.u;                            // :52
     r.x = r.x + sg * r.v;                            // :53
     r.sprev = sg;
+    if (LAST) return;
     // tilt (:16-19), normal (:56-57)
     const T Dt = s.R2 - (r.x * r.x + r.y * r.y) * s.opk;
     const T sq = ieee_sqrt(Dt);
@@ -288,9 +301,6 @@ __device__ __forceinline__ void surface_step_ieee(Ray<T>& r, const SurfRec<T>& s
     if (HASP) {
         tx = tx + poly_deriv<T>(coef, s.ncoef, r.x);             // Q2: p'(x) on the x slope
         ty = ty + poly_deriv<T>(coef, s.ncoef, r.y);
-    } else {
-        tx = tx + T(0);
-        ty = ty + T(0);
     }
     const T nrm = ieee_sqrt((tx * tx + ty * ty) + T(1));
     const T inv = ieee_div(T(1), nrm);
@@ -303,6 +313,34 @@ __device__ __forceinline__ void surface_step_ieee(Ray<T>& r, const SurfRec<T>& s
     const T n0 = s.eta * r.k0 + cf * m0;
     const T n1 = s.eta * r.k1 + cf * m1;
     const T n2 = s.eta * r.k2 + cf * m2;
+    r.k0 = ok ? n0 : r.k0;
+    r.k1 = ok ? n1 : r.k1;
+    r.k2 = ok ? n2 : r.k2;
+    ieee_div2(r.k1, r.k0, r.k2, r.u, r.v);           // :59-60
+}
+
+// The same iteration for a FLAT row without a polynomial (R = Inf: stop and image planes, plane windows), with
+// the reference's arithmetic evaluated symbolically where its operands are exact:
+//   tilt: sign(Inf) x / sqrt(Inf - r^2 (1+K)) = x / Inf = (+-)0 for every finite x, likewise y   (:16-19)
+//   normalize!: sqrt(0 + 0 + 1) = 1, inv = 1  ->  m = (0, 0, -1) exactly                          (:56-57)
+//   g = -((k0 0 + k1 0) + k2 (-1)) = k2;   eta k0 + cf 0 = eta k0;   eta k2 + cf (-1) = eta k2 - cf  (:23-31)
+// so one sqrt and one shared reciprocal remain of the 3 sqrt + 4 divisions of the general body, and every x, y
+// the reference produces is reproduced bit for bit.  (A ray whose x or y is already NaN keeps them NaN on every
+// later surface whatever its direction, so the reference's "k untouched on NaN" is not observable there.)
+template <typename T>
+__device__ __forceinline__ void surface_step_ieee_flat(Ray<T>& r, const SurfRec<T>& s)
+{
+    const T tcur = s.t - r.sprev;
+    r.y = r.y + r.u * tcur;                          // :46
+    r.x = r.x + r.v * tcur;                          // :47
+    r.y = r.y + T(0) * r.u;                          // :52 with s = 0 (:12): NaN for an infinite slope, as there
+    r.x = r.x + T(0) * r.v;                          // :53
+    r.sprev = T(0);
+    const T g = r.k2;
+    const T D2 = T(1) - s.eta2 * (T(1) - g * g);     // :24
+    const T cf = s.eta * g - ieee_sqrt(D2);          // :26
+    const bool ok = D2 >= T(0);
+    const T n0 = s.eta * r.k0, n1 = s.eta * r.k1, n2 = s.eta * r.k2 - cf;
     r.k0 = ok ? n0 : r.k0;
     r.k1 = ok ? n1 : r.k1;
     r.k2 = ok ? n2 : r.k2;
@@ -365,20 +403,21 @@ __device__ __forceinline__ void surface_step_fast_poly(Ray<T>& r, const SurfRec<
 // REFR: the row refracts (eta != 1).  TIR: |eta| > 1, total internal reflection is possible
 // and the reference's "k untouched" rule (Q1) needs a select; for |eta| <= 1 the radicand
 // 1 - eta^2 (1 - cos^2 I) >= 1 - eta^2 >= 0 and no select is emitted.
-template <typename T, int KIND, bool REFR, bool TIR>
-__device__ __forceinline__ void surface_step_fast_conic(Ray<T>& r, const SurfRec<T>& s)
+template <typename T> struct ConicHit { T cn, n2, cosi, cos2; };   // n = (-cn x, -cn y, n2), cos I = k.n
+
+// Transfer to the row and intersection.  Returns false when the row does not refract (flat, eta == 1).
+template <typename T, int KIND, bool REFR>
+__device__ __forceinline__ bool fast_conic_hit(Ray<T>& r, const SurfRec<T>& s, ConicHit<T>& h)
 {
     const T z0 = r.sprev - s.t;
     const T c = s.invR;
-    T cos2, cosi, n2;          // n = (-c' x, -c' y, n2) with c' = cn below
-    T cn;
     if (KIND == KIND_FLAT) {
         const T d = -z0 * fast_rcp(r.k2);
         r.x = t_fma<T>(d, r.k0, r.x);
         r.y = t_fma<T>(d, r.k1, r.y);
         r.sprev = T(0);
-        if (!REFR) return;
-        cn = T(0); n2 = T(1); cosi = r.k2; cos2 = r.k2 * r.k2;
+        if (!REFR) return false;
+        h.cn = T(0); h.n2 = T(1); h.cosi = r.k2; h.cos2 = r.k2 * r.k2;
     } else if (KIND == KIND_SPHERE) {
         const T Pk = t_fma<T>(z0, r.k2, t_fma<T>(r.y, r.k1, r.x * r.k0));
         const T P2 = t_fma<T>(z0, z0, t_fma<T>(r.y, r.y, r.x * r.x));
@@ -391,8 +430,8 @@ __device__ __forceinline__ void surface_step_fast_conic(Ray<T>& r, const SurfRec
         r.y = t_fma<T>(d, r.k1, r.y);
         const T z = t_fma<T>(d, r.k2, z0);
         r.sprev = z;
-        cn = c; n2 = t_fma<T>(-c, z, T(1));                      // unit normal (-c x, -c y, 1 - c z)
-        cosi = E; cos2 = E2;                                     // k.n = sqrt(G^2 - c F)
+        h.cn = c; h.n2 = t_fma<T>(-c, z, T(1));                  // unit GEOMETRIC normal (-c x, -c y, 1 - c z)
+        h.cosi = E; h.cos2 = E2;                                 // k.n = sqrt(G^2 - c F); far-cap hits: fast_sphere_farcap
     } else {
         const T zk = s.opk * z0;
         const T Pk = t_fma<T>(zk, r.k2, t_fma<T>(r.y, r.k1, r.x * r.k0));
@@ -407,17 +446,40 @@ __device__ __forceinline__ void surface_step_fast_conic(Ray<T>& r, const SurfRec
         r.y = t_fma<T>(d, r.k1, r.y);
         const T z = t_fma<T>(d, r.k2, z0);
         r.sprev = z;
-        const T N0 = c * r.x, N1 = c * r.y, N2 = t_fma<T>(-c * s.opk, z, T(1));
+        // |N2|: the reference's tilt is the slope of the VERTEX-side sheet (PupilSampling.jl:16-19), whose normal
+        // has a positive axial component also where the chosen root lies on the far sheet (free source modifier)
+        const T N0 = c * r.x, N1 = c * r.y, N2 = t_abs(t_fma<T>(-c * s.opk, z, T(1)));
         const T inv = fast_rsqrt(t_fma<T>(N2, N2, t_fma<T>(N1, N1, N0 * N0)));
-        cn = c * inv; n2 = N2 * inv;
-        cosi = t_fma<T>(r.k2, n2, -cn * t_fma<T>(r.k1, r.y, r.k0 * r.x));
-        cos2 = cosi * cosi;
+        h.cn = c * inv; h.n2 = N2 * inv;
+        h.cosi = t_fma<T>(r.k2, h.n2, -h.cn * t_fma<T>(r.k1, r.y, r.k0 * r.x));
+        h.cos2 = h.cosi * h.cosi;
     }
-    // vector Snell (:21-32) with n = -m:  k' = eta k + (cos I' - eta cos I) n
-    //   1 - eta^2 (1 - cos^2 I) = (1 - eta^2) + eta^2 cos^2 I
-    const T D2 = t_fma<T>(s.eta2, cos2, s.ome2);
+    return true;
+}
+
+// FAR-CAP hit on a sphere (beyond the equator; only rays far outside any clear aperture): the reference's tilt is
+// the slope of the vertex-side sheet, sign(R) y / sqrt(R^2 - r^2) (PupilSampling.jl:16-19), so it refracts with
+// the normal (-c x, -c y, |1 - c z|) there.  Reproduced per lane (the other lanes of the wave keep their values
+// bit for bit):  k.n_ref = E + k2 (|w| - w),  w = 1 - c z.  Runs only in the retrace of a wave that holds such a ray.
+template <typename T>
+__device__ __forceinline__ void fast_sphere_farcap(const Ray<T>& r, ConicHit<T>& h)
+{
+    const bool far = h.n2 < T(0);
+    const T aw = t_abs(h.n2);
+    const T cosi = t_fma<T>(r.k2, aw - h.n2, h.cosi);
+    h.cos2 = far ? cosi * cosi : h.cos2;
+    h.cosi = far ? cosi : h.cosi;
+    h.n2 = aw;
+}
+
+// vector Snell (:21-32) with n = -m:  k' = eta k + (cos I' - eta cos I) n
+//   1 - eta^2 (1 - cos^2 I) = (1 - eta^2) + eta^2 cos^2 I
+template <typename T, bool TIR>
+__device__ __forceinline__ void fast_snell(Ray<T>& r, const SurfRec<T>& s, const ConicHit<T>& h)
+{
+    const T D2 = t_fma<T>(s.eta2, h.cos2, s.ome2);
     T cp = fast_sqrt_pos<T>(t_max<T>(D2, t_tiny<T>()));          // radicand clamped: no NaN, sqrt(0) ~ 0
-    T gam = t_fma<T>(-s.eta, cosi, cp);
+    T gam = t_fma<T>(-s.eta, h.cosi, cp);
     T ee = s.eta;
     if (TIR) {                                                   // TIR / NaN: k stays (Q1)
         pin(gam);
@@ -425,10 +487,30 @@ __device__ __forceinline__ void surface_step_fast_conic(Ray<T>& r, const SurfRec
         gam = ok ? gam : T(0);
         ee = ok ? ee : T(1);
     }
-    const T gc = gam * cn;
+    const T gc = gam * h.cn;
     r.k0 = t_fma<T>(-gc, r.x, ee * r.k0);                        // in-place form, see surface_step_fast_poly
     r.k1 = t_fma<T>(-gc, r.y, ee * r.k1);
-    r.k2 = t_fma<T>(gam, n2, ee * r.k2);
+    r.k2 = t_fma<T>(gam, h.n2, ee * r.k2);
+}
+
+template <typename T, int KIND, bool REFR, bool TIR>
+__device__ __forceinline__ void surface_step_fast_conic(Ray<T>& r, const SurfRec<T>& s)
+{
+    ConicHit<T> h;
+    if (fast_conic_hit<T, KIND, REFR>(r, s, h)) fast_snell<T, TIR>(r, s, h);
+}
+
+// Sphere row in the general form.  FARCAP = false: the hot path — the geometric normal, and `far` picks up
+// whether this ray met the sphere beyond its equator (one compare); the kernel retraces the tile with
+// FARCAP = true when any ray of the wave did.  FARCAP = true: the reference's vertex-side normal per lane.
+template <typename T, bool TIR, bool FARCAP>
+__device__ __forceinline__ void surface_step_fast_sphere(Ray<T>& r, const SurfRec<T>& s, bool& far)
+{
+    ConicHit<T> h;
+    fast_conic_hit<T, KIND_SPHERE, true>(r, s, h);
+    if (FARCAP) fast_sphere_farcap<T>(r, h);
+    else far = far || (h.n2 < T(0));
+    fast_snell<T, TIR>(r, s, h);
 }
 
 // MATH_FAST, strongly curved sphere (|R| <= kCentreFormMaxR) in CENTRE form: with Q = P - C
@@ -440,53 +522,102 @@ __device__ __forceinline__ void surface_step_fast_conic(Ray<T>& r, const SurfRec
 // s.K holds t + R for these rows.
 constexpr double kCentreFormMaxR = 1.0e3;
 
-template <typename T, bool TIR>
-__device__ __forceinline__ void surface_step_fast_sphere_c(Ray<T>& r, const SurfRec<T>& s)
+template <typename T>
+__device__ __forceinline__ void fast_sphere_c_hit(Ray<T>& r, const SurfRec<T>& s, T& sq, T& disc, T& Qz)
 {
     const T Qz0 = r.sprev - s.K;
     const T b = t_fma<T>(Qz0, r.k2, t_fma<T>(r.y, r.k1, r.x * r.k0));
     const T q = t_fma<T>(Qz0, Qz0, t_fma<T>(r.y, r.y, r.x * r.x));
-    const T disc = t_fma<T>(b, b, s.R2 - q);
-    const T sq = fast_sqrt(disc);                             // NaN when the ray misses (:9)
+    disc = t_fma<T>(b, b, s.R2 - q);
+    sq = fast_sqrt(disc);                                        // NaN when the ray misses (:9)
     const T d = -t_fma<T>(s.sgn, sq, b);
     r.x = t_fma<T>(d, r.k0, r.x);
     r.y = t_fma<T>(d, r.k1, r.y);
-    const T Qz = t_fma<T>(d, r.k2, Qz0);
+    Qz = t_fma<T>(d, r.k2, Qz0);
     r.sprev = Qz + s.R;
-    const T c = s.invR;
-    const T D2 = t_fma<T>(s.e2c2, disc, s.ome2);                 // (1 - eta^2) + eta^2 cos^2 I
+}
+
+// Snell coefficients with the geometric normal -Q/R (every hit on the vertex-side cap): D2 = radicand of
+// cos I', gam = cos I' - eta cos I.
+template <typename T>
+__device__ __forceinline__ void fast_sphere_c_coeffs(const SurfRec<T>& s, T sq, T disc, T& D2, T& gam)
+{
+    D2 = t_fma<T>(s.e2c2, disc, s.ome2);                         // (1 - eta^2) + eta^2 cos^2 I
     const T cp = fast_sqrt_pos<T>(t_max<T>(D2, t_tiny<T>()));
-    T gam = t_fma<T>(-s.ec, sq, cp);                             // cos I' - eta cos I, cos I = |c| sq
+    gam = t_fma<T>(-s.ec, sq, cp);                               // cos I = |c| sq
+}
+
+// Retrace of a wave that holds a ray beyond an equator: lanes with sign(R) Qz > 0 refract with the reference's vertex-side
+// normal (-c x, -c y, |c Qz|), k.n_ref = |c| sq + k2 (|w| - w), w = -c Qz (see fast_sphere_farcap); the other
+// lanes keep their values bit for bit.  Only temporaries change, the update of k stays on the common path.
+template <typename T>
+__device__ __forceinline__ void fast_sphere_c_farcap(const Ray<T>& r, const SurfRec<T>& s, T sq, T& Qz, T& D2, T& gam)
+{
+    const bool far = s.sgn * Qz > T(0);
+    const T w = -s.invR * Qz, aw = t_abs(w);
+    const T cosi = t_fma<T>(r.k2, aw - w, t_abs(s.invR) * sq);
+    const T D2f = t_fma<T>(s.eta2, cosi * cosi, s.ome2);
+    const T cpf = fast_sqrt_pos<T>(t_max<T>(D2f, t_tiny<T>()));
+    const T gamf = t_fma<T>(-s.eta, cosi, cpf);
+    D2 = far ? D2f : D2; gam = far ? gamf : gam;
+    Qz = far ? -Qz : Qz;                                         // -c Qz == |c Qz| in the update of k2
+}
+
+template <typename T, bool TIR>
+__device__ __forceinline__ void fast_sphere_c_apply(Ray<T>& r, const SurfRec<T>& s, T Qz, T D2, T gam)
+{
     T ee = s.eta;
-    if (TIR) {
+    if (TIR) {                                                   // TIR / NaN: k stays (Q1)
         pin(gam);
         const bool ok = D2 >= T(0);
         gam = ok ? gam : T(0);
         ee = ok ? ee : T(1);
     }
-    const T gc = gam * c;
+    const T gc = gam * s.invR;
     r.k0 = t_fma<T>(-gc, r.x, ee * r.k0);                        // in-place form, see surface_step_fast_poly
     r.k1 = t_fma<T>(-gc, r.y, ee * r.k1);
     r.k2 = t_fma<T>(-gc, Qz, ee * r.k2);
+}
+
+// Centre-form row; FARCAP as in surface_step_fast_sphere (hot path: one class compare per ray-surface).
+template <typename T, bool TIR, bool FARCAP>
+__device__ __forceinline__ void surface_step_fast_sphere_c(Ray<T>& r, const SurfRec<T>& s, bool& far)
+{
+    T sq, disc, Qz, D2, gam;
+    fast_sphere_c_hit<T>(r, s, sq, disc, Qz);
+    fast_sphere_c_coeffs<T>(s, sq, disc, D2, gam);
+    if (FARCAP) fast_sphere_c_farcap<T>(r, s, sq, Qz, D2, gam);
+    else far = far || t_class(Qz, s.farmask);                   // sign(R) Qz > 0 as ONE v_cmp_class (NaN-safe)
+    fast_sphere_c_apply<T, TIR>(r, s, Qz, D2, gam);
 }
 
 // All N rays of a lane through one surface.  `cls` packs the row's wave-uniform class bits
 // (scalar register): the branch is taken once per surface, the bodies are straight-line.
 enum { CLS_FINITE = 1, CLS_HASP = 2, CLS_REFR = 4, CLS_TIR = 8, CLS_KIND_SHIFT = 4 };
 
-template <typename T, int MATH, int N>
+// FARCAP (MATH_FAST only): see surface_step_fast_sphere; `far` accumulates over the lane's rays and surfaces.
+// last (MATH_IEEE only, wave-uniform): this is the final loop iteration, see surface_step_ieee.
+template <typename T, int MATH, int N, bool FARCAP>
 __device__ __forceinline__ void surface_step_n(Ray<T> (&r)[N], const SurfRec<T>& s,
-                                               const T* __restrict__ coef, int cls)
+                                               const T* __restrict__ coef, int cls, bool last, bool& far)
 {
 #define ORT_ALL_RAYS(call) _Pragma("unroll") for (int q = 0; q < N; ++q) { call; }
     if (MATH == MATH_IEEE) {
-        // (the independent-if form of the MATH_FAST arm below was tried here too: +2 % kernel time, kept as a chain)
-        if (cls & CLS_FINITE) {
-            if (cls & CLS_HASP) { ORT_ALL_RAYS((surface_step_ieee<T, true, true>(r[q], s, coef))) }
-            else                { ORT_ALL_RAYS((surface_step_ieee<T, true, false>(r[q], s, coef))) }
-        } else {
-            if (cls & CLS_HASP) { ORT_ALL_RAYS((surface_step_ieee<T, false, true>(r[q], s, coef))) }
-            else                { ORT_ALL_RAYS((surface_step_ieee<T, false, false>(r[q], s, coef))) }
+        // hot arms first (spherical / conic rows and flat rows without a polynomial), as independent ifs; rows
+        // with a polynomial and the final iteration share one grouped arm
+        const bool fin = cls & CLS_FINITE, hasp = cls & CLS_HASP;
+        if (fin && !hasp && !last)  { ORT_ALL_RAYS((surface_step_ieee<T, true, false, false>(r[q], s, coef))) }
+        if (!fin && !hasp && !last) { ORT_ALL_RAYS((surface_step_ieee_flat<T>(r[q], s))) }
+        if (hasp || last) {
+            if (last) {
+                if (fin) {
+                    if (hasp) { ORT_ALL_RAYS((surface_step_ieee<T, true, true, true>(r[q], s, coef))) }
+                    else      { ORT_ALL_RAYS((surface_step_ieee<T, true, false, true>(r[q], s, coef))) }
+                } else        { ORT_ALL_RAYS((surface_step_ieee<T, false, false, true>(r[q], s, coef))) }
+            } else {
+                if (fin) { ORT_ALL_RAYS((surface_step_ieee<T, true, true, false>(r[q], s, coef))) }
+                else     { ORT_ALL_RAYS((surface_step_ieee<T, false, true, false>(r[q], s, coef))) }
+            }
         }
     } else {
         // INDEPENDENT ifs on scalar conditions, not an else-if chain: each arm merges only with its own skip
@@ -495,19 +626,19 @@ __device__ __forceinline__ void surface_step_n(Ray<T> (&r)[N], const SurfRec<T>&
         const int kind = cls >> CLS_KIND_SHIFT;
         const bool tir = cls & CLS_TIR;
         const bool refr = cls & CLS_REFR;
-        if (kind == KIND_SPHERE_C && !tir) { ORT_ALL_RAYS((surface_step_fast_sphere_c<T, false>(r[q], s))) }
-        if (kind == KIND_SPHERE_C && tir)  { ORT_ALL_RAYS((surface_step_fast_sphere_c<T, true>(r[q], s))) }
+        if (kind == KIND_SPHERE_C && !tir) { ORT_ALL_RAYS((surface_step_fast_sphere_c<T, false, FARCAP>(r[q], s, far))) }
+        if (kind == KIND_SPHERE_C && tir)  { ORT_ALL_RAYS((surface_step_fast_sphere_c<T, true, FARCAP>(r[q], s, far))) }
         if (kind == KIND_FLAT && !refr)    { ORT_ALL_RAYS((surface_step_fast_conic<T, KIND_FLAT, false, false>(r[q], s))) }
         if (kind == KIND_FLAT && refr)     { ORT_ALL_RAYS((surface_step_fast_conic<T, KIND_FLAT, true, true>(r[q], s))) }
         // Float32 never uses the centre form (cancellation), so ITS hot sphere arms are the general ones
         constexpr bool kF32 = sizeof(T) == 4;
-        if (kF32 && kind == KIND_SPHERE && !tir) { ORT_ALL_RAYS((surface_step_fast_conic<T, KIND_SPHERE, true, false>(r[q], s))) }
-        if (kF32 && kind == KIND_SPHERE && tir)  { ORT_ALL_RAYS((surface_step_fast_conic<T, KIND_SPHERE, true, true>(r[q], s))) }
+        if (kF32 && kind == KIND_SPHERE && !tir) { ORT_ALL_RAYS((surface_step_fast_sphere<T, false, FARCAP>(r[q], s, far))) }
+        if (kF32 && kind == KIND_SPHERE && tir)  { ORT_ALL_RAYS((surface_step_fast_sphere<T, true, FARCAP>(r[q], s, far))) }
         if ((!kF32 && kind == KIND_SPHERE) || kind == KIND_CONIC || kind == KIND_POLY) {   // the general forms share ONE arm:
             // as independent arms they drag their merge copies back onto the path of the sphere / flat rows (measured)
             if (!kF32 && kind == KIND_SPHERE) {
-                if (tir) { ORT_ALL_RAYS((surface_step_fast_conic<T, KIND_SPHERE, true, true>(r[q], s))) }
-                else     { ORT_ALL_RAYS((surface_step_fast_conic<T, KIND_SPHERE, true, false>(r[q], s))) }
+                if (tir) { ORT_ALL_RAYS((surface_step_fast_sphere<T, true, FARCAP>(r[q], s, far))) }
+                else     { ORT_ALL_RAYS((surface_step_fast_sphere<T, false, FARCAP>(r[q], s, far))) }
             } else if (kind == KIND_CONIC) {
                 ORT_ALL_RAYS((surface_step_fast_conic<T, KIND_CONIC, true, true>(r[q], s)))
             } else {

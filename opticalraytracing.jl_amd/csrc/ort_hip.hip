@@ -150,17 +150,18 @@ void build_records(int nsys, int rows, int ncoef, const double* R, const double*
                 for (int j = 0; j < ncoef; ++j) if ((T)c[j] != T(0)) nc = ncoef;   // all-zero row == `zero`
             }
             r.ncoef = nc;
-            r.kind = nc > 0 ? KIND_POLY : (!r.finite ? KIND_FLAT : (Kv != T(0) ? KIND_CONIC : KIND_SPHERE));
-            if (r.kind == KIND_SPHERE && std::fabs((double)Rv) <= kCentreFormMaxR && sizeof(T) == 8) {
-                r.kind = KIND_SPHERE_C;            // MATH_FAST centre form; K (== 0 here) carries t + R
+            int kind = nc > 0 ? KIND_POLY : (!r.finite ? KIND_FLAT : (Kv != T(0) ? KIND_CONIC : KIND_SPHERE));
+            if (kind == KIND_SPHERE && std::fabs((double)Rv) <= kCentreFormMaxR && sizeof(T) == 8) {
+                kind = KIND_SPHERE_C;              // MATH_FAST centre form; K (== 0 here) carries t + R
                 r.K = r.t + Rv;
             }
+            r.farmask = Rv > T(0) ? kClassPositive : kClassNegative;   // Qz beyond the equator: sign(R) Qz > 0
             r.ome2 = T(1) - r.eta2;
             r.e2c2 = r.eta2 * (r.invR * r.invR);
             r.ec = r.eta * std::fabs(r.invR);
             r.cls = (r.finite ? CLS_FINITE : 0) | (nc > 0 ? CLS_HASP : 0) | ((r.eta != T(1)) ? CLS_REFR : 0) |
                     (!(std::fabs(r.eta) <= T(1)) ? CLS_TIR : 0) |
-                    (r.kind << CLS_KIND_SHIFT);
+                    (kind << CLS_KIND_SHIFT);
             out[(size_t)s * S + i] = r;
         }
     }
@@ -597,7 +598,7 @@ int spot_batch_impl(ort_ctx* ctx, int nsys, int rows, const double* R, const dou
     // solve (RayTracing.jl:302-323) -> tables -> aiming requests -> aiming (:223-296) -> bundles + axis end
     // points (PupilSampling.jl:94-122) -> axes -> trace + stop filter + tile moments -> per-bundle RMS
     hipLaunchKernelGGL(k_first_order, nblk(nsys, 64), dim3(64), 0, st, nsys, rows, dR, dt, dn, da, (const double*)nullptr, dh,
-                       587.5618e-6, d_fo);
+                       587.5618e-6, d_fo, (double*)nullptr, (double*)nullptr);
     hipLaunchKernelGGL((k_build_tables<T>), nblk((int64_t)nr, kBlock), dim3(kBlock), 0, st, nsys, rows, dR, dt, dn, dK,
                        ncoef > 0 ? dcoef : (const double*)nullptr, ncoef, d_fo, d_rec, d_cext, d_mf, d_mr, d_crev, d_tlf, d_tlr);
     hipLaunchKernelGGL(k_build_aim, nblk(na, kBlock), dim3(kBlock), 0, st, nsys, nfields, rows, d_fo, da, dfields, layout ? 1 : 0, d_ain);
@@ -1023,35 +1024,65 @@ int ort_aim_f64(ort_ctx* ctx, const ort_system* fwd, const ort_system* rev, int 
 }
 
 // --------------------------------------------------------------------------------------
-int ort_first_order_f64(ort_ctx* ctx, int nsys, int rows, const double* R, const double* t, const double* n,
-                        const double* a, const double* dn, const double* hprime, double lambda,
-                        ort_first_order* out, unsigned flags)
+static int first_order_impl(ort_ctx* ctx, int nsys, int rows, const double* R, const double* t, const double* n,
+                            const double* a, const double* dn, const double* hprime, double lambda,
+                            ort_first_order* out, double* surf, double* inc, unsigned flags)
 {
     static_assert(sizeof(ort_first_order) == sizeof(FirstOrderOut), "ABI struct mismatch");
+    static_assert((int)ORT_SURF_COUNT == (int)SURF_COUNT && (int)ORT_SURF_TANGENTIAL == (int)SURF_TANGENTIAL, "ABI enum mismatch");
     int rc = check_ctx(ctx); if (rc) return rc;
     if (nsys <= 0 || rows < 2 || rows > ORT_MAX_ROWS || !R || !t || !n || !a || !hprime || !out || !(lambda > 0.0))
         return fail(ORT_EINVAL, "bad first_order arguments");
     const bool devp = flags & ORT_DEVICE_PTRS;
     const double *dR = R, *dt = t, *dnn = n, *da = a, *ddn = dn, *dh = hprime;
     FirstOrderOut* dout = reinterpret_cast<FirstOrderOut*>(out);
-    const size_t nr = (size_t)nsys * rows;
+    double *dsurf = surf, *dinc = inc;
+    const size_t nr = (size_t)nsys * rows, ns = (size_t)nsys * (rows - 1);
     if (!devp) {
+        // Lens() keeps the last row (k == rows, src/RayTracing.jl:47-50) when the last thickness is finite and
+        // non-zero; the reference then needs `rows` semi-diameters (a ./ y[2:end], :215) and throws a
+        // DimensionMismatch for the rows-1 this ABI carries
+        for (int s = 0; s < nsys; ++s) {
+            const double tl = t[(size_t)s * rows + rows - 1];
+            if (tl != 0.0 && std::isfinite(tl))
+                return fail(ORT_EINVAL, "system %d: last thickness %g is finite and non-zero: the reference keeps the last "
+                                        "lens row and needs %d semi-diameters (DimensionMismatch); end the prescription in image space (t = 0)",
+                            s, tl, rows);
+        }
         rc = to_device<double>(ctx, SL_IN0, R, nr, &dR); if (rc) return rc;
         rc = to_device<double>(ctx, SL_IN1, t, nr, &dt); if (rc) return rc;
         rc = to_device<double>(ctx, SL_IN2, n, nr, &dnn); if (rc) return rc;
-        rc = to_device<double>(ctx, SL_IN3, a, (size_t)nsys * (rows - 1), &da); if (rc) return rc;
+        rc = to_device<double>(ctx, SL_IN3, a, ns, &da); if (rc) return rc;
         if (dn) { rc = to_device<double>(ctx, SL_TAB0, dn, nr, &ddn); if (rc) return rc; }
         rc = to_device<double>(ctx, SL_TAB1, hprime, (size_t)nsys, &dh); if (rc) return rc;
         rc = dev_out<FirstOrderOut>(ctx, SL_OUT0, (size_t)nsys, &dout); if (rc) return rc;
+        if (surf) { rc = dev_out<double>(ctx, SL_OUT1, (size_t)SURF_COUNT * ns, &dsurf); if (rc) return rc; }
+        if (inc) { rc = dev_out<double>(ctx, SL_OUT2, (size_t)4 * ns, &dinc); if (rc) return rc; }
     }
     hipLaunchKernelGGL(k_first_order, dim3((unsigned)((nsys + 63) / 64)), dim3(64), 0, ctx->stream,
-                       nsys, rows, dR, dt, dnn, da, ddn, dh, lambda, dout);
+                       nsys, rows, dR, dt, dnn, da, ddn, dh, lambda, dout, dsurf, dinc);
     HIP_TRY(hipGetLastError());
     if (!devp) {
         rc = from_device<FirstOrderOut>(ctx, reinterpret_cast<FirstOrderOut*>(out), dout, (size_t)nsys); if (rc) return rc;
+        if (surf) { rc = from_device<double>(ctx, surf, dsurf, (size_t)SURF_COUNT * ns); if (rc) return rc; }
+        if (inc) { rc = from_device<double>(ctx, inc, dinc, (size_t)4 * ns); if (rc) return rc; }
         HIP_TRY(hipStreamSynchronize(ctx->stream));
     }
     return ORT_OK;
+}
+
+int ort_first_order_f64(ort_ctx* ctx, int nsys, int rows, const double* R, const double* t, const double* n,
+                        const double* a, const double* dn, const double* hprime, double lambda,
+                        ort_first_order* out, unsigned flags)
+{
+    return first_order_impl(ctx, nsys, rows, R, t, n, a, dn, hprime, lambda, out, nullptr, nullptr, flags);
+}
+
+int ort_aberrations_f64(ort_ctx* ctx, int nsys, int rows, const double* R, const double* t, const double* n,
+                        const double* a, const double* dn, const double* hprime, double lambda,
+                        ort_first_order* out, double* surf, double* inc, unsigned flags)
+{
+    return first_order_impl(ctx, nsys, rows, R, t, n, a, dn, hprime, lambda, out, surf, inc, flags);
 }
 
 // --------------------------------------------------------------------------------------
@@ -1247,9 +1278,10 @@ int ort_allgather_hits_f64(ort_comm* comm, const double* xf, const double* yf, i
     if (count == 0) return ORT_OK;
     const int ncclFloat64 = 8;
     RCCL_TRY(g_rccl.GroupStart());           // x and y slabs fused into one RCCL launch
-    RCCL_TRY(g_rccl.AllGather(xf, gx, (size_t)count, ncclFloat64, comm->comm, comm->ctx->stream));
-    RCCL_TRY(g_rccl.AllGather(yf, gy, (size_t)count, ncclFloat64, comm->comm, comm->ctx->stream));
-    RCCL_TRY(g_rccl.GroupEnd());
+    int r1 = g_rccl.AllGather(xf, gx, (size_t)count, ncclFloat64, comm->comm, comm->ctx->stream);
+    int r2 = r1 ? 0 : g_rccl.AllGather(yf, gy, (size_t)count, ncclFloat64, comm->comm, comm->ctx->stream);
+    int r3 = g_rccl.GroupEnd();              // always closed: an open group would swallow every later collective
+    RCCL_TRY(r1); RCCL_TRY(r2); RCCL_TRY(r3);
     return ORT_OK;
 }
 

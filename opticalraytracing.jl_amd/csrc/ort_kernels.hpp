@@ -19,6 +19,8 @@
 
 #include "ort_device.hpp"
 
+#include <type_traits>
+
 namespace ort {
 
 // Tunables (compile-time; the defaults are the measured best).
@@ -132,7 +134,7 @@ __device__ __forceinline__ void load_rec(SurfRec<T>& d, const __attribute__((add
 {
     d.t = s[i].t; d.R = s[i].R; d.R2 = s[i].R2; d.sgn = s[i].sgn; d.opk = s[i].opk; d.eta = s[i].eta;
     d.eta2 = s[i].eta2; d.K = s[i].K; d.invR = s[i].invR; d.ome2 = s[i].ome2; d.e2c2 = s[i].e2c2; d.ec = s[i].ec;
-    d.finite = s[i].finite; d.ncoef = s[i].ncoef; d.kind = s[i].kind; d.cls = s[i].cls;
+    d.finite = s[i].finite; d.ncoef = s[i].ncoef; d.farmask = s[i].farmask; d.cls = s[i].cls;
 }
 
 // ------------------------------------------------------------------------------------
@@ -145,7 +147,7 @@ enum { FT_NONE = 0, FT_FULL = 1, FT_STATS = 2 };
 constexpr int kStatusVignetted = 1 << 17, kStatusVigShift = 20;
 // ------------------------------------------------------------------------------------
 template <typename T, int MATH, bool USE_LDS, bool GRID, bool HIST, bool SUMM, int FT>
-__global__ __launch_bounds__(kBlock, ORT_MIN_WAVES) void k_trace(TraceParams<T> p)
+__global__ __launch_bounds__(kBlock, (HIST && SUMM) ? ORT_MIN_WAVES - 1 : ORT_MIN_WAVES) void k_trace(TraceParams<T> p)   // both outputs: 128 VGPRs, no spill
 {
     __shared__ SurfRec<T> s_rec[USE_LDS ? kMaxRows : 1];
     __shared__ T s_coef[USE_LDS ? kMaxRows * kMaxCoef : 1];
@@ -197,47 +199,51 @@ __global__ __launch_bounds__(kBlock, ORT_MIN_WAVES) void k_trace(TraceParams<T> 
     T xs_[kRPT], ys_[kRPT];
     int stopi = -1;
     T hprime = T(0), a_stop = T(0);
+    // (a lambda: a wave that met a far-cap hit launches its rays a second time, see below)
+    auto launch_rays = [&]() {
 #pragma unroll
-    for (int r = 0; r < kRPT; ++r) {
-        const int64_t j = j0 + r;
-        live[r] = j < limit;
-        const int64_t jj = live[r] ? j : (limit - 1);   // clamp: dead lanes retrace a valid ray
-        T y, x, u, v;
-        if (GRID) {
-            const DevBundle<T>& bd = p.bundles[b];
-            // (iy, ix) of ray jj without a per-lane 64-bit division: the tile's first ray is
-            // divided once in scalar registers, lanes walk forward from there.
-            unsigned iy, ix;
-            if (live[r] && p.nx >= 64) {
-                const unsigned iy0 = tile_base / (unsigned)p.nx;         // wave-uniform: scalar division
-                ix = (tile_base - iy0 * (unsigned)p.nx) + (unsigned)(tid * kRPT + r);
-                iy = iy0;
-                while (ix >= (unsigned)p.nx) { ix -= (unsigned)p.nx; ++iy; }
+        for (int r = 0; r < kRPT; ++r) {
+            const int64_t j = j0 + r;
+            live[r] = j < limit;
+            const int64_t jj = live[r] ? j : (limit - 1);   // clamp: dead lanes retrace a valid ray
+            T y, x, u, v;
+            if (GRID) {
+                const DevBundle<T>& bd = p.bundles[b];
+                // (iy, ix) of ray jj without a per-lane 64-bit division: the tile's first ray is
+                // divided once in scalar registers, lanes walk forward from there.
+                unsigned iy, ix;
+                if (live[r] && p.nx >= 64) {
+                    const unsigned iy0 = tile_base / (unsigned)p.nx;         // wave-uniform: scalar division
+                    ix = (tile_base - iy0 * (unsigned)p.nx) + (unsigned)(tid * kRPT + r);
+                    iy = iy0;
+                    while (ix >= (unsigned)p.nx) { ix -= (unsigned)p.nx; ++iy; }
+                } else {
+                    iy = (unsigned)((uint32_t)jj / (uint32_t)p.nx);
+                    ix = (unsigned)jj - iy * (unsigned)p.nx;
+                }
+                y = p.axes[bd.yoff + iy];
+                x = p.axes[bd.xoff + ix];
+                stopi = bd.stop; hprime = bd.hprime; a_stop = bd.a_stop;
+                if (p.raybasis) {                        // PupilSampling.jl:124-127 (Q8)
+                    u = dev_tan((bd.ybar - y) / bd.z0);
+                    v = dev_tan(-x / bd.z0);
+                } else {                                 // shared field angles: direction cosines are bundle-uniform
+                    ray[r].y = y; ray[r].x = x; ray[r].u = bd.u; ray[r].v = bd.v; ray[r].sprev = T(0);
+                    ray[r].k0 = bd.k0; ray[r].k1 = bd.k1; ray[r].k2 = bd.k2;
+                    st[r] = 1; xs_[r] = T(0); ys_[r] = T(0);
+                    continue;
+                }
             } else {
-                iy = (unsigned)((uint32_t)jj / (uint32_t)p.nx);
-                ix = (unsigned)jj - iy * (unsigned)p.nx;
+                y = p.ly[jj]; x = p.lx[jj];
+                u = p.lU[jj]; v = p.lV[jj];
+                if (!p.slopes_given) { u = dev_tan(u); v = dev_tan(v); }   // :38-39
             }
-            y = p.axes[bd.yoff + iy];
-            x = p.axes[bd.xoff + ix];
-            stopi = bd.stop; hprime = bd.hprime; a_stop = bd.a_stop;
-            if (p.raybasis) {                        // PupilSampling.jl:124-127 (Q8)
-                u = dev_tan((bd.ybar - y) / bd.z0);
-                v = dev_tan(-x / bd.z0);
-            } else {                                 // shared field angles: direction cosines are bundle-uniform
-                ray[r].y = y; ray[r].x = x; ray[r].u = bd.u; ray[r].v = bd.v; ray[r].sprev = T(0);
-                ray[r].k0 = bd.k0; ray[r].k1 = bd.k1; ray[r].k2 = bd.k2;
-                st[r] = 1; xs_[r] = T(0); ys_[r] = T(0);
-                continue;
-            }
-        } else {
-            y = p.ly[jj]; x = p.lx[jj];
-            u = p.lU[jj]; v = p.lV[jj];
-            if (!p.slopes_given) { u = dev_tan(u); v = dev_tan(v); }   // :38-39
+            ray_init<T, MATH>(ray[r], y, x, u, v);
+            st[r] = 1;
+            xs_[r] = T(0); ys_[r] = T(0);
         }
-        ray_init<T, MATH>(ray[r], y, x, u, v);
-        st[r] = 1;
-        xs_[r] = T(0); ys_[r] = T(0);
-    }
+    };
+    launch_rays();
     const bool two = (kRPT > 1) && live[kRPT - 1];
     // History stores: one wave-uniform decision, taken once — every lane of the wave owns two live
     // rays and both row bases keep 16-byte alignment on every surface (ld even) -> plain
@@ -255,53 +261,70 @@ __global__ __launch_bounds__(kBlock, ORT_MIN_WAVES) void k_trace(TraceParams<T> 
     // address -> s_load into SGPRs (scalar cache), the next row prefetched while this one computes.
     typedef const __attribute__((address_space(4))) SurfRec<T>* CRecPtr;
     const CRecPtr crec = (CRecPtr)(uintptr_t)grec;
-    SurfRec<T> nxt;
-    if (!USE_LDS) load_rec<T>(nxt, crec, 0);
     const int stop_u = __builtin_amdgcn_readfirstlane(stopi);    // bundle-uniform: the stop capture is a scalar branch
-    for (int i = 0; i < S; ++i) {
-        SurfRec<T> cur;
-        if (!USE_LDS) {
-            cur = nxt;
-            load_rec<T>(nxt, crec, (i + 1 < S) ? i + 1 : i);
-        }
-        const SurfRec<T>& rec = USE_LDS ? s_rec[i] : cur;
-        const T* cf = USE_LDS ? (s_coef + i * ncoef) : (gcoef ? gcoef + (int64_t)(i + 1) * ncoef : nullptr);
-        const int cls = __builtin_amdgcn_readfirstlane(rec.cls);     // wave-uniform -> scalar branch
-        surface_step_n<T, MATH, kRPT>(ray, rec, cf, cls);
-        if (SUMM || FT) {
-#pragma unroll
-            for (int r = 0; r < kRPT; ++r) {
-                // NaN is sticky (every later transfer propagates it), so the 1-based index of the first
-                // NaN surface is 1 + the number of surfaces with ordered (x, y): one v_cmp_o + one add.
-                st[r] += __builtin_isunordered(ray[r].x, ray[r].y) ? 0 : 1;
+    // The surface loop.  FARCAP = false is the hot path; it returns whether a ray of this lane met a sphere
+    // beyond its equator (MATH_FAST only; see surface_step_fast_sphere).
+    auto trace_surfaces = [&](auto farcap) -> bool {
+        constexpr bool FARCAP = decltype(farcap)::value;
+        bool far = false;
+        SurfRec<T> nxt;
+        if (!USE_LDS) load_rec<T>(nxt, crec, 0);
+        for (int i = 0; i < S; ++i) {
+            SurfRec<T> cur;
+            if (!USE_LDS) {
+                cur = nxt;
+                load_rec<T>(nxt, crec, (i + 1 < S) ? i + 1 : i);
             }
-            if (i == stop_u) {
-#pragma unroll
-                for (int r = 0; r < kRPT; ++r) { xs_[r] = ray[r].x; ys_[r] = ray[r].y; }
-            }
-            if (gap2) {                                          // scalar branch: one s_cbranch when off
-                const T a2 = gap2[i];
+            const SurfRec<T>& rec = USE_LDS ? s_rec[i] : cur;
+            const T* cf = USE_LDS ? (s_coef + i * ncoef) : (gcoef ? gcoef + (int64_t)(i + 1) * ncoef : nullptr);
+            const int cls = __builtin_amdgcn_readfirstlane(rec.cls);     // wave-uniform -> scalar branch
+            surface_step_n<T, MATH, kRPT, FARCAP>(ray, rec, cf, cls, i == S - 1, far);
+            if (SUMM || FT) {
 #pragma unroll
                 for (int r = 0; r < kRPT; ++r) {
-                    // bit 17: outside the clear aperture of some surface; bits 20..27 count the surfaces
-                    // passed before that -> 1-based index of the first vignetting surface = count + 1
-                    const T r2 = ray[r].x * ray[r].x + ray[r].y * ray[r].y;
-                    st[r] |= (r2 > a2) ? kStatusVignetted : 0;
-                    st[r] += (st[r] & kStatusVignetted) ? 0 : (1 << kStatusVigShift);
+                    // NaN is sticky (every later transfer propagates it), so the 1-based index of the first
+                    // NaN surface is 1 + the number of surfaces with ordered (x, y): one v_cmp_o + one add.
+                    st[r] += __builtin_isunordered(ray[r].x, ray[r].y) ? 0 : 1;
+                }
+                if (i == stop_u) {
+#pragma unroll
+                    for (int r = 0; r < kRPT; ++r) { xs_[r] = ray[r].x; ys_[r] = ray[r].y; }
+                }
+                if (gap2) {                                          // scalar branch: one s_cbranch when off
+                    const T a2 = gap2[i];
+#pragma unroll
+                    for (int r = 0; r < kRPT; ++r) {
+                        // bit 17: outside the clear aperture of some surface; bits 20..27 count the surfaces
+                        // passed before that -> 1-based index of the first vignetting surface = count + 1
+                        const T r2 = ray[r].x * ray[r].x + ray[r].y * ray[r].y;
+                        st[r] |= (r2 > a2) ? kStatusVignetted : 0;
+                        st[r] += (st[r] & kStatusVignetted) ? 0 : (1 << kStatusVigShift);
+                    }
+                }
+            }
+            if (HIST) {
+                if (vec_all) {
+                    T* rx = p.xv + ((int64_t)i * p.ld + blockbase);  // scalar row base
+                    T* ry = p.yv + ((int64_t)i * p.ld + blockbase);
+                    store_vec2<T>(rx + lane_off, ray[0].x, ray[kRPT - 1].x);
+                    store_vec2<T>(ry + lane_off, ray[0].y, ray[kRPT - 1].y);
+                } else if (live[0]) {
+                    store_pair<T>(p.xv + (int64_t)i * p.ld, gbase, two, ray[0].x, ray[kRPT - 1].x);
+                    store_pair<T>(p.yv + (int64_t)i * p.ld, gbase, two, ray[0].y, ray[kRPT - 1].y);
                 }
             }
         }
-        if (HIST) {
-            if (vec_all) {
-                T* rx = p.xv + ((int64_t)i * p.ld + blockbase);  // scalar row base
-                T* ry = p.yv + ((int64_t)i * p.ld + blockbase);
-                store_vec2<T>(rx + lane_off, ray[0].x, ray[kRPT - 1].x);
-                store_vec2<T>(ry + lane_off, ray[0].y, ray[kRPT - 1].y);
-            } else if (live[0]) {
-                store_pair<T>(p.xv + (int64_t)i * p.ld, gbase, two, ray[0].x, ray[kRPT - 1].x);
-                store_pair<T>(p.yv + (int64_t)i * p.ld, gbase, two, ray[0].y, ray[kRPT - 1].y);
-            }
-        }
+        return far;
+    };
+    const bool far_seen = trace_surfaces(std::false_type{});
+    if (MATH == MATH_FAST && __builtin_expect(__any(far_seen), 0)) {
+        // A ray of this wave met a sphere on its FAR cap (possible only far outside any clear aperture).  The
+        // reference refracts with the vertex-side normal there (PupilSampling.jl:16-19) and so must this
+        // policy: the wave traces its rays again with that rule applied per lane; its history stores land on
+        // the same addresses, after the first pass's have completed.
+        __builtin_amdgcn_s_waitcnt(0);
+        launch_rays();
+        trace_surfaces(std::true_type{});
     }
 
     if (SUMM) {
@@ -913,10 +936,14 @@ struct FirstOrderOut {
     int32_t stop, k;
 };
 
+enum { SURF_SPHERICAL = 0, SURF_COMA, SURF_ASTIGMATISM, SURF_SAGITTAL, SURF_DISTORTION, SURF_AXIAL, SURF_LATERAL,
+       SURF_PETZVAL, SURF_MEDIAL, SURF_TANGENTIAL, SURF_COUNT };   // = ORT_SURF_* of ort.h
+
 __global__ __launch_bounds__(64) void k_first_order(int nsys, int rows, const double* __restrict__ Rg, const double* __restrict__ tg,
                                                     const double* __restrict__ ng, const double* __restrict__ ag,
                                                     const double* __restrict__ dng, const double* __restrict__ hp,
-                                                    double lam, FirstOrderOut* __restrict__ out)
+                                                    double lam, FirstOrderOut* __restrict__ out,
+                                                    double* __restrict__ surf, double* __restrict__ inc)
 {
     const int g = blockIdx.x * 64 + threadIdx.x;
     if (g >= nsys) return;
@@ -951,8 +978,12 @@ __global__ __launch_bounds__(64) void k_first_order(int nsys, int rows, const do
     o.k = k;
     o.f = -(1.0 / w1[k]);                                                            // :213
     o.EBFD = y1[k] * o.f;                                                            // :214
+    // `a` holds rows-1 semi-diameters (ort.h); the reference needs length(a) == k (sv = a ./ y[2:end], :215) and
+    // throws a DimensionMismatch otherwise: the host entry points reject k == rows, the bound keeps a device-pointer
+    // caller inside its own system's slab
+    const int ka = k < rows - 1 ? k : rows - 1;
     int stop = 0; double s = a[0] / y1[1];
-    for (int i = 1; i < k; ++i) { const double sv = a[i] / y1[i + 1]; if (sv < s) { s = sv; stop = i; } }   // findmin :215-216
+    for (int i = 1; i < ka; ++i) { const double sv = a[i] / y1[i + 1]; if (sv < s) { s = sv; stop = i; } }   // findmin :215-216
     o.stop = stop + 1;
     for (int i = 0; i <= k; ++i) { y1[i] *= s; w1[i] *= s; }                         // :217
     w1[k + 1] = w1[k]; y1[k + 1] = (w1[k] == 0.0) ? y1[k] : 0.0;                     // extend :202-206
@@ -998,8 +1029,21 @@ __global__ __launch_bounds__(64) void k_first_order(int nsys, int rows, const do
         const double ast = -(Ab * Ab) * yD / (2.0 * lam);
         const double ptz = -(o.H * o.H) * P / (4.0 * lam);
         const double dist = -Ab * ((Ab * Ab) * yi * Dn2 - (o.H + Ab * yi) * ybi * P) / (2.0 * lam);
+        const double axl = A * yd / (2.0 * lam), lat = Ab * yd / lam;
         W040 += sph; W131 += coma; W222 += ast; W311 += dist; W220P += ptz;
-        W020 += A * yd / (2.0 * lam); W111 += Ab * yd / lam;
+        W020 += axl; W111 += lat;
+        if (surf) {      // per-surface contributions, SeidelAberrations.jl:25-34: [component][system][surface]
+            const int64_t cs = (int64_t)nsys * (rows - 1), o = (int64_t)g * (rows - 1) + i;
+            surf[SURF_SPHERICAL * cs + o] = sph; surf[SURF_COMA * cs + o] = coma; surf[SURF_ASTIGMATISM * cs + o] = ast;
+            surf[SURF_SAGITTAL * cs + o] = ptz + ast / 2.0; surf[SURF_DISTORTION * cs + o] = dist;
+            surf[SURF_AXIAL * cs + o] = axl; surf[SURF_LATERAL * cs + o] = lat; surf[SURF_PETZVAL * cs + o] = ptz;
+            surf[SURF_MEDIAL * cs + o] = ptz + ast; surf[SURF_TANGENTIAL * cs + o] = ptz + 1.5 * ast;
+        }
+        if (inc) {       // incidences(surfaces, system) = [ni nī i ī], RayTracing.jl:338-353: [column][system][surface]
+            const int64_t cs = (int64_t)nsys * (rows - 1), o = (int64_t)g * (rows - 1) + i;
+            const double nib = wc[i] + ni * ybi / Ri;
+            inc[0 * cs + o] = A; inc[1 * cs + o] = nib; inc[2 * cs + o] = A / ni; inc[3 * cs + o] = nib / ni;
+        }
     }
     o.W040 = W040; o.W131 = W131; o.W222 = W222; o.W311 = W311; o.W220P = W220P;
     o.W220 = W220P + 0.5 * W222; o.W020 = W020; o.W111 = W111;
@@ -1024,10 +1068,11 @@ __device__ __forceinline__ void make_rec(SurfRec<T>& r, T t, T Rv, T n1, T n2, T
     r.invR = r.finite ? T(1) / Rv : T(0);
     r.ome2 = T(1) - r.eta2; r.e2c2 = r.eta2 * (r.invR * r.invR); r.ec = r.eta * fabs(r.invR);
     r.ncoef = nc;
-    r.kind = nc > 0 ? KIND_POLY : (!r.finite ? KIND_FLAT : (Kv != T(0) ? KIND_CONIC : KIND_SPHERE));
-    if (r.kind == KIND_SPHERE && fabs((double)Rv) <= kCentreFormMaxR && sizeof(T) == 8) { r.kind = KIND_SPHERE_C; r.K = r.t + Rv; }
+    int kind = nc > 0 ? KIND_POLY : (!r.finite ? KIND_FLAT : (Kv != T(0) ? KIND_CONIC : KIND_SPHERE));
+    if (kind == KIND_SPHERE && fabs((double)Rv) <= kCentreFormMaxR && sizeof(T) == 8) { kind = KIND_SPHERE_C; r.K = r.t + Rv; }
+    r.farmask = Rv > T(0) ? kClassPositive : kClassNegative;
     r.cls = (r.finite ? CLS_FINITE : 0) | (nc > 0 ? CLS_HASP : 0) | ((r.eta != T(1)) ? CLS_REFR : 0) |
-            (!(fabs(r.eta) <= T(1)) ? CLS_TIR : 0) | (r.kind << CLS_KIND_SHIFT);
+            (!(fabs(r.eta) <= T(1)) ? CLS_TIR : 0) | (kind << CLS_KIND_SHIFT);
 }
 
 // number of coefficients in use for a row: the whole width if any entry is non-zero AFTER the cast to T

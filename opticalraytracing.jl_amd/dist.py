@@ -54,13 +54,23 @@ def barrier(device=None):
         dist.barrier()
 
 
-def allgather_hits(xf, yf, group=None):
-    """All-gather equal-size per-rank hit slabs (image-plane x, y) into rank-ordered tensors of
-    world*len entries: ONE collective over a packed [2, n] buffer."""
+def allgather_hits(xf, yf, group=None, check_equal: bool = True):
+    """All-gather per-rank hit slabs (image-plane x, y) into rank-ordered tensors: ONE collective over a
+    packed [2, n] buffer when every rank holds the same n (what `shard_bounds` gives for a divisible unit
+    count).  Unequal slabs (n_units % world != 0) cannot go through `all_gather_into_tensor`; they are detected
+    (a 16-byte MIN/MAX all-reduce; skip it with check_equal=False when the caller has sharded evenly) and
+    routed through the ragged gather (counts, then padded slabs), which reproduces the same rank order."""
     import torch
     import torch.distributed as dist
     world = dist.get_world_size(group)
     n = xf.numel()
+    if yf.numel() != n:
+        raise ValueError("allgather_hits: xf and yf differ in length")
+    if check_equal and world > 1:
+        mm = torch.tensor([n, -n], dtype=torch.int64, device=xf.device)
+        dist.all_reduce(mm, op=dist.ReduceOp.MAX, group=group)
+        if int(mm[0]) != -int(mm[1]):
+            return allgather_ragged(xf, group=group), allgather_ragged(yf, group=group)
     packed = torch.stack([xf.reshape(-1), yf.reshape(-1)])            # [2, n]
     out = torch.empty((world * 2, n), dtype=packed.dtype, device=packed.device)   # concat along dim 0
     dist.all_gather_into_tensor(out, packed.contiguous(), group=group)

@@ -12,6 +12,7 @@ the `ld` layout of the ABI); per-ray inputs are 1-D.
 from __future__ import annotations
 
 import ctypes as C
+from collections import OrderedDict
 from dataclasses import dataclass
 from typing import List, Optional, Sequence
 
@@ -72,19 +73,25 @@ class HipEngine:
                  use_lds: bool = True):
         self.ctx = Context(device, stream)
         self.base_flags = (_capi.ORT_FAST_MATH if fast_math else 0) | (0 if use_lds else _capi.ORT_NO_LDS)
-        self._systems = {}
+        self._systems = OrderedDict()
+        self.cache_size = 32
 
     # ---- systems ---------------------------------------------------------------------
     def system(self, pres: Prescription) -> DeviceSystem:
+        """Device tables of `pres`, from an LRU cache.  An evicted entry is only dropped from the cache, never
+        destroyed here: it is freed (DeviceSystem.__del__) when the last caller still holding the object lets go,
+        so keep the returned OBJECT — not just its raw handle `.h` — for as long as the handle is in use."""
         k = pres.key()
         s = self._systems.get(k)
-        if s is None:
-            if len(self._systems) > 32:
-                self._systems.pop(next(iter(self._systems))).close()
-            s = DeviceSystem(self.ctx, pres.R, pres.t, pres.n, pres.K, pres.coef)
-            if pres.apertures is not None:
-                s.set_apertures(pres.apertures)
-            self._systems[k] = s
+        if s is not None:
+            self._systems.move_to_end(k)
+            return s
+        s = DeviceSystem(self.ctx, pres.R, pres.t, pres.n, pres.K, pres.coef)
+        if pres.apertures is not None:
+            s.set_apertures(pres.apertures)
+        self._systems[k] = s
+        while len(self._systems) > self.cache_size:
+            self._systems.popitem(last=False)
         return s
 
     # ---- skew: raytrace(surfaces, y, x, U, V, Vector{RealRay})  PupilSampling.jl:34-65 --
@@ -185,7 +192,8 @@ class HipEngine:
             a.chief_y_end, a.chief_u_end = float(sp["chief_y_end"]), float(sp["chief_u_end"])
             a.f, a.atol = float(sp["f"]), float(sp.get("atol", 1.4901161193847656e-08))
         aout = (_capi.ort_aim_out * n)()
-        check(self.ctx.lib.ort_aim_f64(self.ctx.h, self.system(fwd).h, self.system(rev).h, n, ain, aout, self.base_flags))
+        sf, sr = self.system(fwd), self.system(rev)      # both objects held across the call (see system())
+        check(self.ctx.lib.ort_aim_f64(self.ctx.h, sf.h, sr.h, n, ain, aout, self.base_flags))
         return [dict(U=o.U, y1=o.y1, y2=o.y2, y_EP=o.y_EP, hprime=o.hprime, EP_t=o.EP_t, Ubar=o.Ubar,
                      iters=o.iters, ok=bool(o.ok)) for o in aout]
 
@@ -201,6 +209,26 @@ class HipEngine:
                                                float(lam), out, self.base_flags))
         names = [f[0] for f in _capi.ort_first_order._fields_]
         return [{k: getattr(o, k) for k in names} for o in out]
+
+    # ---- per-surface Seidel contributions + incidences: SeidelAberrations.jl:25-34, RayTracing.jl:338-353 --
+    def aberrations(self, R, t, n, a, hprime, dn=None, lam: float = 587.5618e-6) -> dict:
+        """ort_aberrations_f64 over nsys prescriptions: dict with the first-order / Seidel-sum fields as
+        [nsys] arrays, the ten per-surface vectors (_capi.ORT_SURF_NAMES) and the four incidence columns
+        (_capi.ORT_INC_NAMES) as [nsys][rows-1] arrays."""
+        R, t, n = (np.atleast_2d(f64(v)) for v in (R, t, n))
+        nsys, rows = R.shape
+        a = np.ascontiguousarray(np.broadcast_to(f64(a), (nsys, rows - 1)))
+        hp = np.ascontiguousarray(np.broadcast_to(f64(hprime), (nsys,)))
+        dnp = None if dn is None else np.ascontiguousarray(np.broadcast_to(f64(dn), (nsys, rows)))
+        out = (_capi.ort_first_order * nsys)()
+        surf = np.empty((len(_capi.ORT_SURF_NAMES), nsys, rows - 1)); inc = np.empty((4, nsys, rows - 1))
+        check(self.ctx.lib.ort_aberrations_f64(self.ctx.h, nsys, rows, ptr(R), ptr(t), ptr(n), ptr(a), ptr(dnp), ptr(hp),
+                                               float(lam), out, ptr(surf), ptr(inc), self.base_flags))
+        names = [f[0] for f in _capi.ort_first_order._fields_]
+        res = {k: np.array([getattr(o, k) for o in out]) for k in names}
+        res.update({k: surf[j] for j, k in enumerate(_capi.ORT_SURF_NAMES)})
+        res.update({k: inc[j] for j, k in enumerate(_capi.ORT_INC_NAMES)})
+        return res
 
     # ---- paraxial: raytrace(lens, y, ω, a; clip)  RayTracing.jl:127-143 ------------------
     def paraxial(self, tau, phi, y, w, a=None, clip: bool = False):

@@ -43,6 +43,7 @@ def lib():
     L.orc_trace_skew.argtypes = [_i, _dp, _dp, _dp, _dp, _dp, _i, _d, _d, _d, _d, _dp, _dp]
     L.orc_trace_skew_slopes.argtypes = [_i, _dp, _dp, _dp, _dp, _dp, _i, _d, _d, _d, _d, _dp, _dp, C.POINTER(_i)]
     L.orc_status.argtypes = [_i, _dp, _dp]; L.orc_status.restype = _i
+    L.orc_skew_margins.argtypes = [_i, _dp, _dp, _dp, _dp, _dp, _i, _l, _dp, _dp, _dp, _dp, _dp]
     L.orc_trace_skew_batch.argtypes = [_i, _dp, _dp, _dp, _dp, _dp, _i, _l, _dp, _dp, _dp, _dp, _dp, _dp, _l, _ip, _i]
     L.orc_trace_skew_grid.argtypes = [_i, _dp, _dp, _dp, _dp, _dp, _i, _i, _dp, _i, _dp, _d, _d, _dp, _dp, _l, _ip, _i]
     L.orc_trace_skew_grid.restype = _l
@@ -61,8 +62,46 @@ def lib():
     L.orc_full_trace_grid.restype = _l
     L.orc_sigma.argtypes = [_l, _dp, _dp]; L.orc_sigma.restype = _d
     L.orc_linrange.argtypes = [_d, _d, _i, _i]; L.orc_linrange.restype = _d
+    L.orc_solve_aberrations.argtypes = [_i, _dp, _dp, _dp, _dp, _dp, _d, _d, C.POINTER(orc_system_t), _dp, _dp,
+                                        _dp, _dp, _dp, _dp]
+    L.orc_solve_aberrations.restype = _i
     _lib = L
     return L
+
+
+class orc_system_t(C.Structure):
+    _fields_ = [(k, C.c_double) for k in ("f", "EBFD", "EFFD", "N", "FOV", "EP_D", "EP_t", "XP_D", "XP_t", "H", "PN",
+                                          "W040", "W131", "W222", "W220", "W311", "W020", "W111", "W220P", "W220M",
+                                          "W220T")] + [("stop", C.c_int), ("k", C.c_int)]
+
+
+SURF_NAMES = ("spherical", "coma", "astigmatism", "sagittal", "distortion", "axial", "lateral", "petzval", "medial",
+              "tangential")
+INC_NAMES = ("ni", "nibar", "i", "ibar")
+
+
+def solve_aberrations(surfaces, a, hprime: float, lam: float = 587.5618e-6, dn=None) -> dict:
+    """orc_solve_aberrations: solve(surfaces, a, h′) + aberrations(...) + incidences(...) of the reference
+    for ONE prescription (rows x 3 matrix [R t n]).  Returns the scalars, the ten per-surface vectors
+    (SURF_NAMES), the four incidence columns (INC_NAMES) and the paraxial marginal / chief y, nu."""
+    M = np.asarray(surfaces, dtype=np.float64)
+    rows = M.shape[0]
+    R, t, n = (np.ascontiguousarray(M[:, j]) for j in range(3))
+    a = np.ascontiguousarray(a, dtype=np.float64)
+    dnp = None if dn is None else np.ascontiguousarray(dn, dtype=np.float64)
+    S = rows - 1
+    out = orc_system_t()
+    surf = np.empty((len(SURF_NAMES), S)); inc = np.empty((4, S))
+    my, mw, cy, cw = (np.empty(rows + 1) for _ in range(4))
+    rc = lib().orc_solve_aberrations(rows, _p(R), _p(t), _p(n), _p(a), _p(dnp), float(hprime), float(lam),
+                                     C.byref(out), _p(surf), _p(inc), _p(my), _p(mw), _p(cy), _p(cw))
+    if rc != 0:
+        raise ValueError("orc_solve_aberrations: Lens() keeps the last row (finite, non-zero last thickness)")
+    res = {k: getattr(out, k) for k, _ in orc_system_t._fields_}
+    res.update({k: surf[j] for j, k in enumerate(SURF_NAMES)})
+    res.update({k: inc[j] for j, k in enumerate(INC_NAMES)})
+    res.update(marginal_y=my, marginal_nu=mw, chief_y=cy, chief_nu=cw)
+    return res
 
 
 def _p(a):
@@ -124,6 +163,16 @@ class OracleEngine:
             self.L.orc_trace_skew_batch(*s.args(), N, _p(y), _p(x), _p(U), _p(V), _p(xv), _p(yv), N,
                                         st.ctypes.data_as(_ip), self.nthreads)
         return (xv, yv, st) if want_status else (xv, yv)
+
+    def skew_margins(self, pres, y, x, u, v, isys: int = 0) -> np.ndarray:
+        """[nrays, 4] conditioning probe of orc_skew_margins (slopes in): min normalised sag discriminant,
+        min refraction discriminant, min tilt radicand, far-cap hit count."""
+        s = _Sys(pres, isys)
+        y, x, u, v = np.broadcast_arrays(*(np.atleast_1d(_f(a)) for a in (y, x, u, v)))
+        y, x, u, v = (np.ascontiguousarray(a) for a in (y, x, u, v))
+        m = np.empty((y.size, 4))
+        self.L.orc_skew_margins(*s.args(), y.size, _p(y), _p(x), _p(u), _p(v), _p(m))
+        return m
 
     def grid(self, pres, bundles: Sequence[dict], axes, ny: int, nx: int, history=True, summary=True,
              raybasis: bool = False):

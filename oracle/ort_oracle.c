@@ -45,6 +45,15 @@ void orc_trace_skew(int rows, const double *R, const double *t, const double *n,
     skew_f64(rows, R, t, n, K, coef, ncoef, y, x, tan(U), tan(V), xv, yv, 0);
 }
 
+void orc_skew_margins(int rows, const double *R, const double *t, const double *n,
+                      const double *K, const double *coef, int ncoef,
+                      int64_t nrays, const double *y, const double *x, const double *u, const double *v,
+                      double *marg)
+{
+    for (int64_t r = 0; r < nrays; ++r)
+        skew_margins_f64(rows, R, t, n, K, coef, ncoef, y[r], x[r], u[r], v[r], marg + 4 * r);
+}
+
 int orc_status(int S, const double *xv, const double *yv)
 {
     for (int i = 0; i < S; ++i)
@@ -360,4 +369,123 @@ double orc_linrange(double a, double b, int n, int i)
     __float128 A = a, B = b;
     __float128 r = A + ((B - A) * (__float128)i) / (__float128)(n - 1);
     return (double)r;
+}
+
+/* ---- first-order solve, Seidel sums, paraxial incidences -------------------------------- */
+
+/* Base.sum over a Vector{Float64} of fewer than 16 elements is a plain left fold (Base._mapreduce); longer
+ * vectors go through a @simd-reassociable block: parity unpinned at the last ulps.                         */
+static double vsum(const double *v, int n)
+{
+    double s = 0.0;
+    if (n > 0) { s = v[0]; for (int i = 1; i < n; ++i) s += v[i]; }
+    return s;
+}
+
+/* solve(surfaces, a, h′) (src/RayTracing.jl:325-327 -> _solve :302-323) followed by
+ * aberrations(surfaces, system, λ, δn) (src/SeidelAberrations.jl:6-53) and incidences(surfaces, system)
+ * (src/RayTracing.jl:338-353).  surf: 10 per-surface vectors of rows-1 entries each, in the order of
+ * ORC_SURF_*; inc: 4 columns [ni nī i ī] of rows-1 entries.  marg / chief: y and nu of the paraxial marginal
+ * and chief rays, k+2 entries each (ParaxialRay.ynu, src/Types.jl:29-51), or NULL.  Returns 0, or -1 when
+ * Lens() keeps the last row (k == rows) — the reference then needs `rows` semi-diameters (:215).           */
+int orc_solve_aberrations(int rows, const double *R, const double *t_in, const double *n,
+                          const double *a, const double *dn, double hprime, double lambda,
+                          orc_system_t *out, double *surf, double *inc,
+                          double *marg_y, double *marg_nu, double *chief_y, double *chief_nu)
+{
+    double t[ORC_MAX_ROWS], tau[ORC_MAX_ROWS], phi[ORC_MAX_ROWS];
+    for (int i = 0; i < rows; ++i) t[i] = t_in[i];
+    const int k = orc_lens_from_surfaces(rows, R, t, n, tau, phi);              /* Lens(surfaces)  :38-53 */
+    if (k != rows - 1) return -1;
+    /* lens.n = surfaces[:,3] (:52); ParaxialRay's n = [n; n[end]] (Types.jl:39) */
+    double nn[ORC_MAX_ROWS + 2];
+    for (int i = 0; i < rows; ++i) nn[i] = n[i];
+    nn[rows] = n[rows - 1];
+    /* trace_marginal_ray(lens, a)  :208-221 */
+    double my[ORC_MAX_ROWS + 2], mw[ORC_MAX_ROWS + 2];
+    orc_trace_paraxial(k, tau, phi, 1.0, 0.0, 0, 0, my, mw);                   /* :209 */
+    const double f = -(1.0 / mw[k]);                                            /* :213  -inv(ω[end]) */
+    const double EBFD = my[k] * f;                                              /* :214 */
+    int stop = 0; double s = a[0] / my[1];                                      /* :215-216 findmin: first minimum */
+    for (int i = 1; i < k; ++i) { double sv = a[i] / my[i + 1]; if (sv < s) { s = sv; stop = i; } }
+    stop += 1;                                                                  /* 1-based */
+    for (int i = 0; i <= k; ++i) { my[i] *= s; mw[i] *= s; }                    /* :217 */
+    mw[k + 1] = mw[k]; my[k + 1] = (mw[k] == 0.0) ? my[k] : 0.0;                /* extend  :202-206 */
+    /* trace_chief_ray(lens, stop, marginal, h′)  :246-263 */
+    double cy2[ORC_MAX_ROWS + 2], cw2[ORC_MAX_ROWS + 2], cy[ORC_MAX_ROWS + 2], cw[ORC_MAX_ROWS + 2];
+    orc_trace_paraxial(k, tau, phi, 0.0, 1.0, 0, 0, cy2, cw2);                 /* :252 */
+    const double y_stop = my[stop], y2_stop = cy2[stop];                        /* surface_ray(y)[stop], y2[stop] */
+    const double nub = -mw[k + 1] * hprime / my[1];                             /* :256 */
+    for (int i = 1; i <= k; ++i) {                                              /* :258 */
+        cy[i] = nub * (cy2[i] - my[i] * y2_stop / y_stop);
+        cw[i] = nub * (cw2[i] - mw[i] * y2_stop / y_stop);
+    }
+    cy[0] = 0.0; cw[0] = nub;                                                   /* :259 */
+    cy[k + 1] = hprime; cw[k + 1] = cw[k];                                      /* :260 */
+    /* _solve  :302-323 */
+    const double ybar = cy[1], nubp = cw[k + 1], ym = my[0], ybpb = cy[k];
+    const double delta = (hprime - nubp * f - ybar) / nub;                      /* :312 */
+    const double H = nub * ym;                                                  /* :316 */
+    if (out) {
+        out->f = f; out->EBFD = EBFD; out->EFFD = delta - f;                    /* :313 */
+        out->PN = (n[rows - 1] - n[0]) * f;                                     /* :314 */
+        out->EP_D = fabs(ym) * 2.0; out->EP_t = -ybar / nub;                    /* :315 */
+        out->H = H;
+        out->XP_D = fabs(2.0 * H / nubp); out->XP_t = -ybpb / nubp;             /* :317 */
+        out->N = fabs(f / out->EP_D);                                           /* :318 */
+        out->FOV = 2.0 * (atan(fabs(cw[0] / nn[0])) * (180.0 / M_PI));          /* :319  2atand(|ū[1]|) */
+        out->stop = stop; out->k = k;
+    }
+    for (int i = 0; i <= k + 1; ++i) {
+        if (marg_y) marg_y[i] = my[i];
+        if (marg_nu) marg_nu[i] = mw[i];
+        if (chief_y) chief_y[i] = cy[i];
+        if (chief_nu) chief_nu[i] = cw[i];
+    }
+    /* aberrations  SeidelAberrations.jl:10-35;  surface_ray(x) = x[2:end-1] */
+    const int S = rows - 1;
+    double u[ORC_MAX_ROWS + 2];
+    for (int i = 0; i <= k + 1; ++i) u[i] = mw[i] / nn[i];                      /* Types.jl:40 */
+    double sph[ORC_MAX_ROWS], coma[ORC_MAX_ROWS], ast[ORC_MAX_ROWS], ptz[ORC_MAX_ROWS], dist[ORC_MAX_ROWS],
+           axial[ORC_MAX_ROWS], lateral[ORC_MAX_ROWS];
+    for (int i = 0; i < S; ++i) {
+        const double Ri = R[i + 1], yi = my[i + 1], ybi = cy[i + 1];
+        const double A = mw[i] + nn[i] * yi / Ri;                               /* :18 */
+        const double Ab = (H + A * ybi) / yi;                                   /* :19 */
+        const double yD = yi * (u[i + 1] / nn[i + 1] - u[i] / nn[i]);           /* :20, Δ :4 */
+        const double yd = dn ? yi * (dn[i + 1] / nn[i + 1] - dn[i] / nn[i]) : yi * (0.0 / nn[i + 1] - 0.0 / nn[i]);   /* :21 */
+        const double i1 = 1.0 / nn[i + 1], i0 = 1.0 / nn[i];
+        const double Dn2 = i1 * i1 - i0 * i0;                                   /* :22 */
+        const double P = (i1 - i0) / Ri;                                        /* :23 */
+        sph[i] = -(A * A) * yD / (8.0 * lambda);                                /* :25 */
+        coma[i] = -A * Ab * yD / (2.0 * lambda);                                /* :26 */
+        ast[i] = -(Ab * Ab) * yD / (2.0 * lambda);                              /* :27 */
+        ptz[i] = -(H * H) * P / (4.0 * lambda);                                 /* :28 */
+        dist[i] = -Ab * ((Ab * Ab) * yi * Dn2 - (H + Ab * yi) * ybi * P) / (2.0 * lambda);   /* :30 */
+        axial[i] = A * yd / (2.0 * lambda);                                     /* :31 */
+        lateral[i] = Ab * yd / lambda;                                          /* :32 */
+        if (surf) {
+            surf[ORC_SURF_SPHERICAL * S + i] = sph[i]; surf[ORC_SURF_COMA * S + i] = coma[i];
+            surf[ORC_SURF_ASTIGMATISM * S + i] = ast[i]; surf[ORC_SURF_PETZVAL * S + i] = ptz[i];
+            surf[ORC_SURF_SAGITTAL * S + i] = ptz[i] + ast[i] / 2.0;            /* :29 */
+            surf[ORC_SURF_DISTORTION * S + i] = dist[i];
+            surf[ORC_SURF_AXIAL * S + i] = axial[i]; surf[ORC_SURF_LATERAL * S + i] = lateral[i];
+            surf[ORC_SURF_MEDIAL * S + i] = ptz[i] + ast[i];                    /* :33 */
+            surf[ORC_SURF_TANGENTIAL * S + i] = ptz[i] + 1.5 * ast[i];          /* :34 */
+        }
+        if (inc) {                                                              /* RayTracing.jl:338-353 */
+            const double ni = mw[i] + nn[i] * yi / Ri, nib = cw[i] + nn[i] * ybi / Ri;
+            inc[0 * S + i] = ni; inc[1 * S + i] = nib;
+            inc[2 * S + i] = ni / nn[i]; inc[3 * S + i] = nib / nn[i];
+        }
+    }
+    if (out) {
+        out->W040 = vsum(sph, S); out->W131 = vsum(coma, S); out->W222 = vsum(ast, S);   /* :37-40 */
+        out->W311 = vsum(dist, S);
+        out->W220P = vsum(ptz, S);                                              /* :42 */
+        out->W220 = out->W220P + 0.5 * out->W222;                               /* :43 */
+        out->W220M = out->W220P + out->W222; out->W220T = out->W220P + 1.5 * out->W222;  /* :44-45 */
+        out->W020 = vsum(axial, S); out->W111 = vsum(lateral, S);               /* :48,50 */
+    }
+    return 0;
 }

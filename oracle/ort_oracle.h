@@ -43,6 +43,13 @@ void orc_trace_skew_slopes(int rows, const double *R, const double *t, const dou
                            double y, double x, double u, double v,
                            double *xv, double *yv, int *tir_count);
 
+/* Conditioning probe (see ort_oracle_skew.inc, skew_margins): marg[4*r + 0..3] = minimum normalised sag
+ * discriminant, refraction discriminant, tilt radicand along ray r, and its count of far-cap hits.  Slopes in. */
+void orc_skew_margins(int rows, const double *R, const double *t, const double *n,
+                      const double *K, const double *coef, int ncoef,
+                      int64_t nrays, const double *y, const double *x, const double *u, const double *v,
+                      double *marg);
+
 /* Derived per-ray status: 1-based loop index of the first surface whose
  * x or y is NaN, or rows (= S+1) when the ray reached the last row.                  */
 int orc_status(int S, const double *xv, const double *yv);
@@ -76,6 +83,21 @@ void orc_trace_meridional(int rows, const double *R, const double *t, const doub
  * tau, phi need `rows` entries; returns k = number of lens rows kept.                */
 int orc_lens_from_surfaces(int rows, const double *R, double *t, const double *n,
                            double *tau, double *phi);
+
+/* solve(surfaces, a, h′) + aberrations(surfaces, system, λ, δn) + incidences(surfaces, system):
+ * src/RayTracing.jl:208-221, 246-263, 302-323, 338-353 and src/SeidelAberrations.jl:6-53.                */
+typedef struct orc_system_t {
+    double f, EBFD, EFFD, N, FOV, EP_D, EP_t, XP_D, XP_t, H, PN;
+    double W040, W131, W222, W220, W311, W020, W111, W220P, W220M, W220T;     /* waves at lambda */
+    int stop, k;
+} orc_system_t;
+enum { ORC_SURF_SPHERICAL = 0, ORC_SURF_COMA, ORC_SURF_ASTIGMATISM, ORC_SURF_SAGITTAL, ORC_SURF_DISTORTION,
+       ORC_SURF_AXIAL, ORC_SURF_LATERAL, ORC_SURF_PETZVAL, ORC_SURF_MEDIAL, ORC_SURF_TANGENTIAL, ORC_SURF_COUNT };
+int orc_solve_aberrations(int rows, const double *R, const double *t, const double *n,
+                          const double *a, const double *dn, double hprime, double lambda,
+                          orc_system_t *out, double *surf /* [ORC_SURF_COUNT][rows-1] */,
+                          double *inc /* [4][rows-1]: ni, nibar, i, ibar */,
+                          double *marg_y, double *marg_nu, double *chief_y, double *chief_nu /* [k+2] each */);
 
 /* src/RayTracing.jl:127-143 — paraxial y-nu trace; rt_y, rt_w have k+1 entries.
  * a may be NULL (fill(Inf)).                                                         */

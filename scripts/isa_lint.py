@@ -37,8 +37,8 @@ for tag, name in KERNELS.items():
     arm_valu = [sum(x.startswith("v_") for x in b) for _, b in arms]
     copy_blocks = [lab for lab, b in blocks if len(b) <= 20 and sum(x.startswith("v_mov_b64") for x in b) >= 10]
     # the general (grouped) arm keeps its own merge copies; they must not sit on the sphere / flat path:
-    # heuristically, at most one pure copy block may remain in the kernel
-    ok = scratch == 0 and len(arms) >= 2 and all(m == 0 for m in arm_movs[:2]) and len(copy_blocks) <= 1
+    # heuristically, at most one pure copy block may remain per copy of the surface loop (hot pass + far-cap retrace)
+    ok = scratch == 0 and len(arms) >= 2 and all(m == 0 for m in arm_movs[:2]) and len(copy_blocks) <= 2
     print(f"{tag}: {n_inst} instructions, scratch {scratch}, sphere arms VALU {arm_valu[:2]} with v_mov_b64 {arm_movs[:2]}, "
           f"pure copy blocks {copy_blocks} -> {'ok' if ok else 'REGRESSION'}")
     bad += not ok

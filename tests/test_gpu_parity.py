@@ -509,30 +509,46 @@ def test_full_trace_batch_end_to_end(hip_engine, oracle_engine):
 
 
 def test_first_order_and_seidel_batch(hip_engine, oracle_engine):
-    """ort_first_order_f64 over 300 perturbed Double-Gauss instances (config 5's Monte-Carlo) +
-    the Cooke triplet with its dispersion vector: == solve() + aberrations() of the host mirror
-    (whose values are pinned to the reference's known answers on the CPU)."""
-    from opticalraytracing_jl_amd import analysis as an, workloads
+    """ort_first_order_f64 / ort_aberrations_f64 over 300 perturbed Double-Gauss instances (config 5's
+    Monte-Carlo), the Cooke triplet with its dispersion vector and the Tessar, against the C oracle
+    oracle/ort_oracle.c::orc_solve_aberrations (pinned to Smith's tables on the CPU): first-order
+    properties, Seidel sums, the ten per-surface vectors of `aberrations` (src/SeidelAberrations.jl:25-34)
+    and the four columns of `incidences` (src/RayTracing.jl:338-353)."""
+    from opticalraytracing_jl_amd import _capi, workloads
+    from oracle import cpu
     mats = workloads.config5(None, ninst=300)
     res = hip_engine.first_order(mats[:, :, 0], mats[:, :, 1], mats[:, :, 2], cm.DG_A, cm.DG_H)
+    full = hip_engine.aberrations(mats[:, :, 0], mats[:, :, 1], mats[:, :, 2], cm.DG_A, cm.DG_H)
+    scal = ("f", "EBFD", "EFFD", "N", "FOV", "H", "EP_D", "EP_t", "XP_D", "XP_t", "PN", "W040", "W131", "W222", "W220",
+            "W311", "W020", "W111", "W220P")
+
+    def close(got, ref, what):
+        assert np.all(np.abs(np.asarray(got) - np.asarray(ref)) <= 1e-12 * np.maximum(1.0, np.abs(ref))), what
+
     for i in (0, 7, 123, 299):
-        s = ort.solve(mats[i].copy(), cm.DG_A, cm.DG_H, engine=oracle_engine)
-        ab = an.aberrations(mats[i], s)
-        r = res[i]
-        assert r["stop"] == s.stop and r["k"] == s.lens.M.shape[0]
-        for key, ref in (("f", s.f), ("EBFD", s.EBFD), ("EFFD", s.EFFD), ("N", s.N), ("FOV", s.FOV), ("H", s.H),
-                         ("EP_D", s.EP.D), ("EP_t", s.EP.t), ("XP_D", s.XP.D), ("XP_t", s.XP.t), ("PN", s.PN),
-                         ("y_marg", s.marginal.y[0]), ("chief_y_end", s.chief.y[-1]), ("chief_u_end", s.chief.u[-1]),
-                         ("nu_end", s.marginal.nu[-1]), ("BFD", s.marginal.z[-1] - s.marginal.z[-2]),
-                         ("W040", ab.W040), ("W131", ab.W131), ("W222", ab.W222), ("W220", ab.W220),
-                         ("W311", ab.W311), ("W220P", ab.W220P)):
-            assert abs(r[key] - ref) <= 1e-11 * max(1.0, abs(ref)), (i, key, r[key], ref)
-    surf = cm.cooke()
-    r = hip_engine.first_order(surf[:, 0], surf[:, 1], surf[:, 2], cm.COOKE_A, cm.COOKE_H, dn=cm.COOKE_DN)[0]
+        o = cpu.solve_aberrations(mats[i], cm.DG_A, cm.DG_H)
+        assert res[i]["stop"] == o["stop"] == full["stop"][i] and res[i]["k"] == o["k"]
+        for key in scal:
+            close(res[i][key], o[key], (i, key)); close(full[key][i], o[key], (i, key))
+        close(res[i]["y_marg"], o["marginal_y"][0], i); close(res[i]["chief_y_end"], o["chief_y"][-1], i)
+        close(res[i]["nu_end"], o["marginal_nu"][-1], i)
+        for key in _capi.ORT_SURF_NAMES + _capi.ORT_INC_NAMES:
+            close(full[key][i], o[key], (i, key))
+    for surf, a, h, dn in ((cm.cooke(), cm.COOKE_A, cm.COOKE_H, cm.COOKE_DN), (cm.tessar(), cm.TESSAR_A, cm.TESSAR_H, None)):
+        r = hip_engine.aberrations(surf[:, 0], surf[:, 1], surf[:, 2], a, h, dn=dn)
+        o = cpu.solve_aberrations(surf, a, h, dn=dn)
+        for key in scal:
+            close(r[key][0], o[key], key)
+        for key in _capi.ORT_SURF_NAMES + _capi.ORT_INC_NAMES:
+            close(r[key][0], o[key], key)
+    r = hip_engine.first_order(cm.cooke()[:, 0], cm.cooke()[:, 1], cm.cooke()[:, 2], cm.COOKE_A, cm.COOKE_H, dn=cm.COOKE_DN)[0]
     assert abs(r["f"] - 101.181) < 1e-3 and abs(r["EBFD"] - 77.405) < 1e-3 and r["stop"] == 5   # test/runtests.jl:53-60
-    s = ort.solve(cm.cooke(), cm.COOKE_A, cm.COOKE_H, engine=oracle_engine)
-    ab = an.aberrations(cm.cooke(), s, dn=cm.COOKE_DN)
-    assert abs(r["W020"] - ab.W020) <= 1e-11 and abs(r["W111"] - ab.W111) <= 1e-11
+    # a finite, non-zero last thickness: Lens() keeps the last row and the reference needs `rows` semi-diameters
+    # (DimensionMismatch for rows-1) -> rejected instead of reading the next system's first aperture
+    bad = cm.cooke(); bad[-1, 1] = 3.0
+    with pytest.raises(_capi.OrtError) as e:
+        hip_engine.first_order(bad[:, 0], bad[:, 1], bad[:, 2], cm.COOKE_A, cm.COOKE_H)
+    assert e.value.code == -1 and "last thickness" in str(e.value)
 
 
 def test_native_rccl_allgather_single_rank():
@@ -596,14 +612,41 @@ def _random_system(rng, rows, aspheric):
     return R, t, n, K, coef
 
 
+# FAST-policy attribution thresholds (tests below; measured tables: scripts/fast_attribution.py, profiles/).
+# A deviation of the FAST forms from the reference sequence is rounding-level (<= a few 1e-16 per operation)
+# amplified by the conditioning of the ray's path: 1 / sqrt(margin) at a square root whose normalised radicand
+# (sag discriminant, refraction discriminant, tilt radicand: oracle `skew_margins`) is `margin`.
+FAST_MARGIN = 1e-6        # rays whose smallest margin is above this must agree to FAST_TOL, status included
+FAST_TOL = 1e-10          # BASELINE north_star: 1e-10 relative
+
+
+def _fast_attribution(fast, oracle_engine, pres, y, x, u, v, rows, tag):
+    """One prescription: FAST vs oracle, every ray classified by the oracle's conditioning probe.  Returns
+    (rays, ill-conditioned rays, far-cap rays).  Asserts: status identical and coordinates within FAST_TOL on
+    every ray whose smallest margin exceeds FAST_MARGIN — far-cap hits, post-TIR paths and huge coordinates
+    included; every deviating ray is therefore attributed to a discriminant within FAST_MARGIN of zero."""
+    ox, oy, os_ = oracle_engine.skew(pres, y, x, u, v, slopes=True, want_status=True)
+    fx, fy, fs = fast.skew(pres, y, x, u, v, slopes=True, want_status=True)
+    mg = oracle_engine.skew_margins(pres, y, x, u, v)
+    cond = np.min(np.abs(mg[:, :3]), axis=1)
+    well = cond > FAST_MARGIN
+    scale = np.maximum(1.0, np.maximum(np.nanmax(np.abs(ox), axis=0, initial=0.0), np.nanmax(np.abs(oy), axis=0, initial=0.0)))
+    err = np.maximum(np.nanmax(np.abs(fx - ox), axis=0, initial=0.0), np.nanmax(np.abs(fy - oy), axis=0, initial=0.0)) / scale
+    nanpat = (np.isnan(fx) != np.isnan(ox)).any(axis=0) | (np.isnan(fy) != np.isnan(oy)).any(axis=0)
+    bad = well & ((fs != os_) | nanpat | (err > FAST_TOL))
+    assert not bad.any(), (tag, int(bad.sum()), float(err[bad].max()), float(cond[bad].min()), int((mg[bad, 3] > 0).sum()))
+    return y.size, int((~well).sum()), int((mg[:, 3] > 0).sum())
+
+
 def test_random_systems_property(hip_engine, oracle_engine):
     """120 random prescriptions (2-14 rows; flat rows, both curvature signs, conics, polynomial
     terms, glass/air sequences that TIR and miss) x 1500 random skew rays each: the IEEE policy is
-    BIT-IDENTICAL to the oracle on every ray incl. NaN patterns and status; the fast policy agrees
-    to 1e-9 on all but a <=0.2 % fringe of rays sitting on a TIR / miss branch boundary."""
+    BIT-IDENTICAL to the oracle on every ray incl. NaN patterns and status; the FAST policy agrees to
+    1e-10 with identical status on EVERY ray that is not within 1e-6 (normalised) of a miss / TIR /
+    equator boundary, and those rays are rare (attribution, not a blanket tolerance)."""
     rng = np.random.default_rng(2024)
     fast = ort.HipEngine(0, fast_math=True)
-    nfring = ntot = 0
+    ntot = nill = nfar = 0
     for case in range(120):
         rows = int(rng.integers(2, 15))
         aspheric = case % 3 == 0
@@ -619,12 +662,32 @@ def test_random_systems_property(hip_engine, oracle_engine):
             assert cm.rel_err(gx, ox, 1.0).max() <= 1e-11 and cm.rel_err(gy, oy, 1.0).max() <= 1e-11, case
         else:
             assert np.array_equal(gx, ox, equal_nan=True) and np.array_equal(gy, oy, equal_nan=True), case
-        fx, fy, fs = fast.skew(pres, y, x, u, v, slopes=True, want_status=True)
-        sane = (os_ == rows) & (np.nanmax(np.abs(ox), axis=0) < 1e3) & (np.nanmax(np.abs(oy), axis=0) < 1e3)
-        err = np.maximum(cm.rel_err(fx, ox, 1.0).max(axis=0), cm.rel_err(fy, oy, 1.0).max(axis=0))
-        bad = (fs != os_) | (sane & (err > 1e-9))
-        nfring += int(bad.sum()); ntot += m
-    assert nfring <= 0.002 * ntot, (nfring, ntot)
+        a, b, c = _fast_attribution(fast, oracle_engine, pres, y, x, u, v, rows, case)
+        ntot += a; nill += b; nfar += c
+    assert nill <= 1e-4 * ntot, (nill, ntot)
+
+
+def test_fast_policy_far_cap_and_wide_bundles(oracle_engine):
+    """The FAST policy on what a lens designer never traces but the reference defines: strongly curved rows
+    (|R| 6.5-30 mm) under +-14 mm, +-0.2 rad bundles — thousands of FAR-CAP hits (beyond a sphere's equator,
+    where the reference refracts with the vertex-side normal, src/PupilSampling.jl:16-19), TIR and miss
+    sequences.  Same attribution assert: every ray outside the 1e-6 margin agrees to 1e-10, status included."""
+    rng = np.random.default_rng(31337)
+    fast = ort.HipEngine(0, fast_math=True)
+    ntot = nill = nfar = 0
+    for case in range(60):
+        rows = int(rng.integers(3, 15))
+        aspheric = case % 3 == 0
+        R, t, n, K, coef = _random_system(rng, rows, aspheric)
+        fin = np.isfinite(R); R[fin] = np.sign(R[fin]) * rng.uniform(6.5, 30.0, int(fin.sum()))
+        pres = Prescription(R, t, n, K if aspheric else None, coef[None] if aspheric else None)
+        m = 2000
+        y = rng.uniform(-14, 14, m); x = rng.uniform(-14, 14, m)
+        u = np.tan(rng.uniform(-0.2, 0.2, m)); v = np.tan(rng.uniform(-0.2, 0.2, m))
+        a, b, c = _fast_attribution(fast, oracle_engine, pres, y, x, u, v, rows, case)
+        ntot += a; nill += b; nfar += c
+    assert nfar >= 1000, nfar                      # the far-cap rule is exercised, not vacuous
+    assert nill <= 2e-3 * ntot, (nill, ntot)
 
 
 def test_random_systems_meridional_and_paraxial(hip_engine, oracle_engine):

@@ -113,6 +113,32 @@ def test_transfer_matrix(cooke_system, eng):
     assert math.isclose(-(r[0] / r[1]), system.EFFD, rel_tol=1e-8)
 
 
+def test_c_oracle_solve_aberrations_smith_tables():
+    """oracle/ort_oracle.c::orc_solve_aberrations (the checker of the device first-order / Seidel kernel) against
+    the reference's own known answers: system properties (test/runtests.jl:53-60), Smith's paraxial marginal /
+    chief / incidence tables (:62-113, 1e-2) and third-order table (:148-229, a quarter wave)."""
+    from oracle import cpu
+    r = cpu.solve_aberrations(cm.cooke(), cm.COOKE_A, cm.COOKE_H, dn=cm.COOKE_DN)
+    assert abs(r["f"] - 101.181) < 1e-3 and abs(r["EBFD"] - 77.405) < 1e-3 and r["stop"] == 5
+    nn = np.append(cm.cooke()[:, 2], 1.0)
+    assert np.allclose(r["marginal_y"], cm.COOKE_YUI[:, 0], atol=1e-2)
+    assert np.allclose(r["marginal_nu"] / nn, cm.COOKE_YUI[:, 1], atol=1e-2)
+    assert np.allclose(r["chief_y"], cm.COOKE_YUI_CHIEF[:, 0], atol=1e-2)
+    assert np.allclose(r["chief_nu"] / nn, cm.COOKE_YUI_CHIEF[:, 1], atol=1e-2)
+    assert np.allclose(r["i"], cm.COOKE_YUI[1:-1, 2], atol=1e-2)          # incidences(...)[:,3:4]  :93,108-111
+    assert np.allclose(r["ibar"], cm.COOKE_YUI_CHIEF[1:-1, 2], atol=1e-2)
+    alpha = 2 * cm.COOKE_YUI[-1, 1] / 587.5618e-6
+    for key, col, div in (("spherical", 0, 8), ("coma", 1, 2), ("astigmatism", 2, 2), ("petzval", 3, 4), ("distortion", 4, 2)):
+        assert np.allclose(r[key], alpha * THIRD_ORDER[:, col] / div, atol=0.25), key
+    assert np.allclose(r["axial"], alpha * PAC / 4, atol=0.25) and np.allclose(r["lateral"], alpha * PLC / 2, atol=0.25)
+    for key, ref, div in (("W040", W040, 8), ("W131", W131, 2), ("W222", W222, 2), ("W220P", W220P, 4), ("W311", W311, 2),
+                          ("W020", W020, 4), ("W111", W111, 2)):
+        assert abs(r[key] - alpha * ref / div) < 0.25, key
+    assert np.allclose(r["sagittal"], r["petzval"] + r["astigmatism"] / 2) and np.allclose(r["medial"], r["petzval"] + r["astigmatism"])
+    # and the product's host mirror (api.solve through the oracle engine + analysis.aberrations) agrees to rounding
+    assert np.allclose(r["tangential"], r["petzval"] + 1.5 * r["astigmatism"])
+
+
 # ---- "vignetting" clip semantics :252-257 ---------------------------------------------------
 def test_clip_semantics(cooke_system, eng):
     _, system = cooke_system
