@@ -165,7 +165,11 @@ def load() -> C.CDLL:
             pass
     lib = C.CDLL(LIB_PATH, mode=C.RTLD_GLOBAL)
     for name, (res, args) in SIGNATURES.items():
-        fn = getattr(lib, name)
+        fn = getattr(lib, name, None)
+        if fn is None:
+            if os.environ.get("ORT_HIP_LIB"):      # an older build loaded for an A/B run: it may lack newer entry points
+                continue
+            raise ImportError(f"{LIB_PATH} lacks {name}: rebuild it (python -c 'import __graft_entry__ as g; g.build()')")
         fn.restype = res
         fn.argtypes = args
     _lib = lib

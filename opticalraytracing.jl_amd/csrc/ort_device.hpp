@@ -20,7 +20,11 @@
 //              refined by ONE cubically convergent step to <= 1 ulp.  Rows carrying a
 //              polynomial term keep the reference's slope form (its additive p(y) is a quirk,
 //              not a geometric intersection, Q2).  Differs from MATH_IEEE by rounding only
-//              (tested <= 1e-12 relative, bar 1e-10).
+//              (tested <= 1e-12 relative, bar 1e-10).  The forms hold for the rays a lens passes; where the
+//              reference's formulas stop being the geometry — a hit beyond a sphere's equator (it keeps the
+//              vertex-side slope, PupilSampling.jl:16-19), a direction refracted backward (it keeps tracing the
+//              line by its slopes), a polynomial row met outside its conic's radius (NaN tilt, k untouched) —
+//              the step raises `odd` and the kernel retraces that wave with the MATH_IEEE sequence.
 #pragma once
 
 #include <hip/hip_runtime.h>
@@ -263,6 +267,37 @@ __device__ __forceinline__ double ieee_sqrt(double x)
 }
 __device__ __forceinline__ float ieee_sqrt(float x) { return __builtin_sqrtf(x); }
 
+// The same square root for a radicand that only ever feeds a DIVISOR (tilt :17, normalize! :57), together with the
+// reciprocal of the result.  (1) No special-case select: x = 0, inf or < 0 gives NaN here where IEEE gives 0 /
+// inf / NaN, and every one of those ends in a NaN normal in the reference too (x / 0 = inf -> norm inf -> inf * 0),
+// i.e. in "k untouched" (Q1) — no output can tell.  (2) The iteration's h = 1 / (2 sqrt x) (~2^-49) seeds the
+// reciprocal of g = RN(sqrt x): ONE Newton step replaces v_rcp_f64 + two (the quotients built on r are then
+// corrected by their exact remainder as in ieee_div_with: same bits as the correctly rounded division, asserted
+// against the CPU oracle by the bit-exact suites of tests/test_gpu_parity.py).
+__device__ __forceinline__ void ieee_sqrt_rcp(double x, double& g, double& r)
+{
+    const double y = __builtin_amdgcn_rsq(x);
+    g = x * y;
+    double h = y * 0.5;
+    const double e = __builtin_fma(-h, g, 0.5);
+    g = __builtin_fma(g, e, g);
+    h = __builtin_fma(h, e, h);
+    double d = __builtin_fma(-g, g, x);
+    g = __builtin_fma(d, h, g);
+    d = __builtin_fma(-g, g, x);
+    g = __builtin_fma(d, h, g);
+    const double r0 = h + h;
+    const double f = __builtin_fma(-g, r0, 1.0);
+    r = __builtin_fma(r0, f, r0);
+}
+// a / b with r ~ 1 / b given, no special-case fixup (see ieee_sqrt_rcp for when that is safe)
+__device__ __forceinline__ double ieee_div_nofix(double a, double b, double r)
+{
+    const double q0 = a * r;
+    const double rem = __builtin_fma(-b, q0, a);
+    return __builtin_fma(rem, r, q0);
+}
+
 // One loop iteration of src/PupilSampling.jl:45-63 in the reference's operation order.
 // FINITE = isfinite(R) (:2), HASP = the row carries polynomial coefficients: both are
 // wave-uniform, so the kernel branches on them ONCE per surface and runs this straight-line
@@ -283,9 +318,10 @@ __device__ __forceinline__ void surface_step_ieee(Ray<T>& r, const SurfRec<T>& s
         const T beta = (s.R - r.y * r.u) - r.x * r.v;            // :3
         const T r2 = r.x * r.x + r.y * r.y;                      // :4
         const T D = beta * beta - r2 * ((s.opk + r.u * r.u) + r.v * r.v);   // :5
-        sg = ieee_div(r2, beta + s.sgn * ieee_sqrt(D));          // :7
+        // :7; sign(R) sqrt(D) is exact, so the fused beta + sign(R) sqrt(D) rounds once, like the reference's sum
+        sg = ieee_div(r2, t_fma<T>(s.sgn, ieee_sqrt(D), beta));
         if (HASP) sg = sg + poly_eval<T>(coef, s.ncoef, r.y);
-        sg = (D >= T(0)) ? sg : t_nan<T>();                      // :6,9
+        // :6,9 — D < 0 or NaN: sqrt(D) is NaN and so is sg, no select needed
     } else {
         sg = T(0);                                               // :12
     }
@@ -295,16 +331,29 @@ __device__ __forceinline__ void surface_step_ieee(Ray<T>& r, const SurfRec<T>& s
     if (LAST) return;
     // tilt (:16-19), normal (:56-57)
     const T Dt = s.R2 - (r.x * r.x + r.y * r.y) * s.opk;
-    const T sq = ieee_sqrt(Dt);
-    T tx, ty;
-    ieee_div2(s.sgn * r.x, s.sgn * r.y, sq, tx, ty);             // one refined reciprocal, two quotients
-    if (HASP) {
-        tx = tx + poly_deriv<T>(coef, s.ncoef, r.x);             // Q2: p'(x) on the x slope
-        ty = ty + poly_deriv<T>(coef, s.ncoef, r.y);
+    T m0, m1, m2;
+    if (sizeof(T) == 8 && !HASP) {
+        // sign(R) x / sqrt(Dt), sign(R) y / sqrt(Dt): the sign is applied to the quotient (exact either way); the
+        // reciprocals of sqrt(Dt) and of the norm come out of their own square-root iterations (ieee_sqrt_rcp)
+        double sq, rq, nrm, inv0;
+        ieee_sqrt_rcp((double)Dt, sq, rq);
+        const double tx = ieee_div_nofix((double)r.x, sq, rq), ty = ieee_div_nofix((double)r.y, sq, rq);
+        ieee_sqrt_rcp((tx * tx + ty * ty) + 1.0, nrm, inv0);
+        const double inv = ieee_div_nofix(1.0, nrm, inv0);
+        const double si = (double)s.sgn * inv;                   // exact: (sign(R) t) inv == t (sign(R) inv)
+        m0 = (T)(tx * si); m1 = (T)(ty * si); m2 = (T)(-inv);
+    } else {
+        const T sq = ieee_sqrt(Dt);
+        T tx, ty;
+        ieee_div2(s.sgn * r.x, s.sgn * r.y, sq, tx, ty);         // one refined reciprocal, two quotients
+        if (HASP) {
+            tx = tx + poly_deriv<T>(coef, s.ncoef, r.x);         // Q2: p'(x) on the x slope
+            ty = ty + poly_deriv<T>(coef, s.ncoef, r.y);
+        }
+        const T nrm = ieee_sqrt((tx * tx + ty * ty) + T(1));
+        const T inv = ieee_div(T(1), nrm);
+        m0 = tx * inv; m1 = ty * inv; m2 = -inv;
     }
-    const T nrm = ieee_sqrt((tx * tx + ty * ty) + T(1));
-    const T inv = ieee_div(T(1), nrm);
-    const T m0 = tx * inv, m1 = ty * inv, m2 = -inv;
     // refract! (:21-32)
     const T g = -((r.k0 * m0 + r.k1 * m1) + r.k2 * m2);
     const T D2 = T(1) - s.eta2 * (T(1) - g * g);
@@ -351,7 +400,7 @@ __device__ __forceinline__ void surface_step_ieee_flat(Ray<T>& r, const SurfRec<
 // with fused arithmetic.  r.sprev is the z offset of the ray point from the current vertex.
 template <typename T>
 __device__ __forceinline__ void surface_step_fast_poly(Ray<T>& r, const SurfRec<T>& s,
-                                                       const T* __restrict__ coef)
+                                                       const T* __restrict__ coef, bool& odd)
 {
     const T ik = fast_rcp(r.k2);
     const T u = r.k1 * ik, v = r.k0 * ik;                        // :59-60
@@ -369,7 +418,9 @@ __device__ __forceinline__ void surface_step_fast_poly(Ray<T>& r, const SurfRec<
         r.y = t_fma<T>(sg, u, r.y);
         r.x = t_fma<T>(sg, v, r.x);
         const T rr = t_fma<T>(r.x, r.x, r.y * r.y);
-        is = s.sgn * fast_rsqrt(t_fma<T>(-rr, s.opk, s.R2));
+        const T rad = t_fma<T>(-rr, s.opk, s.R2);
+        odd = odd || t_class(rad, kClassNegative);   // outside the conic's radius: NaN tilt in the reference (:17), k untouched
+        is = s.sgn * fast_rsqrt(rad);
     }                                                // flat row: sag = 0 without p(y) (:12), tilt = p' only (:18)
     r.sprev = sg;
     T dpy, dpx;
@@ -390,6 +441,7 @@ __device__ __forceinline__ void surface_step_fast_poly(Ray<T>& r, const SurfRec<
     r.k0 = t_fma<T>(cf, m0, ee * r.k0);
     r.k1 = t_fma<T>(cf, m1, ee * r.k1);
     r.k2 = t_fma<T>(cf, m2, ee * r.k2);
+    odd = odd || t_class(r.k2, kClassNegative);
 }
 
 // MATH_FAST, conic row (sphere, flat, conic) in direction-cosine form.  With the ray point
@@ -431,7 +483,7 @@ __device__ __forceinline__ bool fast_conic_hit(Ray<T>& r, const SurfRec<T>& s, C
         const T z = t_fma<T>(d, r.k2, z0);
         r.sprev = z;
         h.cn = c; h.n2 = t_fma<T>(-c, z, T(1));                  // unit GEOMETRIC normal (-c x, -c y, 1 - c z)
-        h.cosi = E; h.cos2 = E2;                                 // k.n = sqrt(G^2 - c F); far-cap hits: fast_sphere_farcap
+        h.cosi = E; h.cos2 = E2;                                 // k.n = sqrt(G^2 - c F)
     } else {
         const T zk = s.opk * z0;
         const T Pk = t_fma<T>(zk, r.k2, t_fma<T>(r.y, r.k1, r.x * r.k0));
@@ -457,21 +509,6 @@ __device__ __forceinline__ bool fast_conic_hit(Ray<T>& r, const SurfRec<T>& s, C
     return true;
 }
 
-// FAR-CAP hit on a sphere (beyond the equator; only rays far outside any clear aperture): the reference's tilt is
-// the slope of the vertex-side sheet, sign(R) y / sqrt(R^2 - r^2) (PupilSampling.jl:16-19), so it refracts with
-// the normal (-c x, -c y, |1 - c z|) there.  Reproduced per lane (the other lanes of the wave keep their values
-// bit for bit):  k.n_ref = E + k2 (|w| - w),  w = 1 - c z.  Runs only in the retrace of a wave that holds such a ray.
-template <typename T>
-__device__ __forceinline__ void fast_sphere_farcap(const Ray<T>& r, ConicHit<T>& h)
-{
-    const bool far = h.n2 < T(0);
-    const T aw = t_abs(h.n2);
-    const T cosi = t_fma<T>(r.k2, aw - h.n2, h.cosi);
-    h.cos2 = far ? cosi * cosi : h.cos2;
-    h.cosi = far ? cosi : h.cosi;
-    h.n2 = aw;
-}
-
 // vector Snell (:21-32) with n = -m:  k' = eta k + (cos I' - eta cos I) n
 //   1 - eta^2 (1 - cos^2 I) = (1 - eta^2) + eta^2 cos^2 I
 template <typename T, bool TIR>
@@ -493,24 +530,16 @@ __device__ __forceinline__ void fast_snell(Ray<T>& r, const SurfRec<T>& s, const
     r.k2 = t_fma<T>(gam, h.n2, ee * r.k2);
 }
 
+// `odd`: see the MATH_FAST notes at the top.  Flat rows cannot raise it (k2' = cos I' >= 0); curved rows test the
+// refracted k2 (one v_cmp_class) and, spheres, the side of the equator the hit lies on (one more).
 template <typename T, int KIND, bool REFR, bool TIR>
-__device__ __forceinline__ void surface_step_fast_conic(Ray<T>& r, const SurfRec<T>& s)
+__device__ __forceinline__ void surface_step_fast_conic(Ray<T>& r, const SurfRec<T>& s, bool& odd)
 {
     ConicHit<T> h;
-    if (fast_conic_hit<T, KIND, REFR>(r, s, h)) fast_snell<T, TIR>(r, s, h);
-}
-
-// Sphere row in the general form.  FARCAP = false: the hot path — the geometric normal, and `far` picks up
-// whether this ray met the sphere beyond its equator (one compare); the kernel retraces the tile with
-// FARCAP = true when any ray of the wave did.  FARCAP = true: the reference's vertex-side normal per lane.
-template <typename T, bool TIR, bool FARCAP>
-__device__ __forceinline__ void surface_step_fast_sphere(Ray<T>& r, const SurfRec<T>& s, bool& far)
-{
-    ConicHit<T> h;
-    fast_conic_hit<T, KIND_SPHERE, true>(r, s, h);
-    if (FARCAP) fast_sphere_farcap<T>(r, h);
-    else far = far || (h.n2 < T(0));
+    if (!fast_conic_hit<T, KIND, REFR>(r, s, h)) return;
+    if (KIND == KIND_SPHERE) odd = odd || t_class(h.n2, kClassNegative);    // beyond the equator: 1 - c z < 0
     fast_snell<T, TIR>(r, s, h);
+    if (KIND != KIND_FLAT) odd = odd || t_class(r.k2, kClassNegative);
 }
 
 // MATH_FAST, strongly curved sphere (|R| <= kCentreFormMaxR) in CENTRE form: with Q = P - C
@@ -547,22 +576,6 @@ __device__ __forceinline__ void fast_sphere_c_coeffs(const SurfRec<T>& s, T sq, 
     gam = t_fma<T>(-s.ec, sq, cp);                               // cos I = |c| sq
 }
 
-// Retrace of a wave that holds a ray beyond an equator: lanes with sign(R) Qz > 0 refract with the reference's vertex-side
-// normal (-c x, -c y, |c Qz|), k.n_ref = |c| sq + k2 (|w| - w), w = -c Qz (see fast_sphere_farcap); the other
-// lanes keep their values bit for bit.  Only temporaries change, the update of k stays on the common path.
-template <typename T>
-__device__ __forceinline__ void fast_sphere_c_farcap(const Ray<T>& r, const SurfRec<T>& s, T sq, T& Qz, T& D2, T& gam)
-{
-    const bool far = s.sgn * Qz > T(0);
-    const T w = -s.invR * Qz, aw = t_abs(w);
-    const T cosi = t_fma<T>(r.k2, aw - w, t_abs(s.invR) * sq);
-    const T D2f = t_fma<T>(s.eta2, cosi * cosi, s.ome2);
-    const T cpf = fast_sqrt_pos<T>(t_max<T>(D2f, t_tiny<T>()));
-    const T gamf = t_fma<T>(-s.eta, cosi, cpf);
-    D2 = far ? D2f : D2; gam = far ? gamf : gam;
-    Qz = far ? -Qz : Qz;                                         // -c Qz == |c Qz| in the update of k2
-}
-
 template <typename T, bool TIR>
 __device__ __forceinline__ void fast_sphere_c_apply(Ray<T>& r, const SurfRec<T>& s, T Qz, T D2, T gam)
 {
@@ -579,27 +592,28 @@ __device__ __forceinline__ void fast_sphere_c_apply(Ray<T>& r, const SurfRec<T>&
     r.k2 = t_fma<T>(-gc, Qz, ee * r.k2);
 }
 
-// Centre-form row; FARCAP as in surface_step_fast_sphere (hot path: one class compare per ray-surface).
-template <typename T, bool TIR, bool FARCAP>
-__device__ __forceinline__ void surface_step_fast_sphere_c(Ray<T>& r, const SurfRec<T>& s, bool& far)
+// Centre-form row.  `odd` (see the MATH_FAST notes at the top): sign(R) Qz > 0 is a hit beyond the equator — ONE
+// v_cmp_class against the row's mask, NaN-safe — and a negative refracted k2 one more.
+template <typename T, bool TIR>
+__device__ __forceinline__ void surface_step_fast_sphere_c(Ray<T>& r, const SurfRec<T>& s, bool& odd)
 {
     T sq, disc, Qz, D2, gam;
     fast_sphere_c_hit<T>(r, s, sq, disc, Qz);
     fast_sphere_c_coeffs<T>(s, sq, disc, D2, gam);
-    if (FARCAP) fast_sphere_c_farcap<T>(r, s, sq, Qz, D2, gam);
-    else far = far || t_class(Qz, s.farmask);                   // sign(R) Qz > 0 as ONE v_cmp_class (NaN-safe)
+    odd = odd || t_class(Qz, s.farmask);
     fast_sphere_c_apply<T, TIR>(r, s, Qz, D2, gam);
+    odd = odd || t_class(r.k2, kClassNegative);
 }
 
 // All N rays of a lane through one surface.  `cls` packs the row's wave-uniform class bits
 // (scalar register): the branch is taken once per surface, the bodies are straight-line.
 enum { CLS_FINITE = 1, CLS_HASP = 2, CLS_REFR = 4, CLS_TIR = 8, CLS_KIND_SHIFT = 4 };
 
-// FARCAP (MATH_FAST only): see surface_step_fast_sphere; `far` accumulates over the lane's rays and surfaces.
+// odd (MATH_FAST only): raised when a ray of this lane leaves the domain of the fast forms (see the notes at the top).
 // last (MATH_IEEE only, wave-uniform): this is the final loop iteration, see surface_step_ieee.
-template <typename T, int MATH, int N, bool FARCAP>
+template <typename T, int MATH, int N>
 __device__ __forceinline__ void surface_step_n(Ray<T> (&r)[N], const SurfRec<T>& s,
-                                               const T* __restrict__ coef, int cls, bool last, bool& far)
+                                               const T* __restrict__ coef, int cls, bool last, bool& odd)
 {
 #define ORT_ALL_RAYS(call) _Pragma("unroll") for (int q = 0; q < N; ++q) { call; }
     if (MATH == MATH_IEEE) {
@@ -626,23 +640,23 @@ __device__ __forceinline__ void surface_step_n(Ray<T> (&r)[N], const SurfRec<T>&
         const int kind = cls >> CLS_KIND_SHIFT;
         const bool tir = cls & CLS_TIR;
         const bool refr = cls & CLS_REFR;
-        if (kind == KIND_SPHERE_C && !tir) { ORT_ALL_RAYS((surface_step_fast_sphere_c<T, false, FARCAP>(r[q], s, far))) }
-        if (kind == KIND_SPHERE_C && tir)  { ORT_ALL_RAYS((surface_step_fast_sphere_c<T, true, FARCAP>(r[q], s, far))) }
-        if (kind == KIND_FLAT && !refr)    { ORT_ALL_RAYS((surface_step_fast_conic<T, KIND_FLAT, false, false>(r[q], s))) }
-        if (kind == KIND_FLAT && refr)     { ORT_ALL_RAYS((surface_step_fast_conic<T, KIND_FLAT, true, true>(r[q], s))) }
+        if (kind == KIND_SPHERE_C && !tir) { ORT_ALL_RAYS((surface_step_fast_sphere_c<T, false>(r[q], s, odd))) }
+        if (kind == KIND_SPHERE_C && tir)  { ORT_ALL_RAYS((surface_step_fast_sphere_c<T, true>(r[q], s, odd))) }
+        if (kind == KIND_FLAT && !refr)    { ORT_ALL_RAYS((surface_step_fast_conic<T, KIND_FLAT, false, false>(r[q], s, odd))) }
+        if (kind == KIND_FLAT && refr)     { ORT_ALL_RAYS((surface_step_fast_conic<T, KIND_FLAT, true, true>(r[q], s, odd))) }
         // Float32 never uses the centre form (cancellation), so ITS hot sphere arms are the general ones
         constexpr bool kF32 = sizeof(T) == 4;
-        if (kF32 && kind == KIND_SPHERE && !tir) { ORT_ALL_RAYS((surface_step_fast_sphere<T, false, FARCAP>(r[q], s, far))) }
-        if (kF32 && kind == KIND_SPHERE && tir)  { ORT_ALL_RAYS((surface_step_fast_sphere<T, true, FARCAP>(r[q], s, far))) }
+        if (kF32 && kind == KIND_SPHERE && !tir) { ORT_ALL_RAYS((surface_step_fast_conic<T, KIND_SPHERE, true, false>(r[q], s, odd))) }
+        if (kF32 && kind == KIND_SPHERE && tir)  { ORT_ALL_RAYS((surface_step_fast_conic<T, KIND_SPHERE, true, true>(r[q], s, odd))) }
         if ((!kF32 && kind == KIND_SPHERE) || kind == KIND_CONIC || kind == KIND_POLY) {   // the general forms share ONE arm:
             // as independent arms they drag their merge copies back onto the path of the sphere / flat rows (measured)
             if (!kF32 && kind == KIND_SPHERE) {
-                if (tir) { ORT_ALL_RAYS((surface_step_fast_sphere<T, true, FARCAP>(r[q], s, far))) }
-                else     { ORT_ALL_RAYS((surface_step_fast_sphere<T, false, FARCAP>(r[q], s, far))) }
+                if (tir) { ORT_ALL_RAYS((surface_step_fast_conic<T, KIND_SPHERE, true, true>(r[q], s, odd))) }
+                else     { ORT_ALL_RAYS((surface_step_fast_conic<T, KIND_SPHERE, true, false>(r[q], s, odd))) }
             } else if (kind == KIND_CONIC) {
-                ORT_ALL_RAYS((surface_step_fast_conic<T, KIND_CONIC, true, true>(r[q], s)))
+                ORT_ALL_RAYS((surface_step_fast_conic<T, KIND_CONIC, true, true>(r[q], s, odd)))
             } else {
-                ORT_ALL_RAYS((surface_step_fast_poly<T>(r[q], s, coef)))
+                ORT_ALL_RAYS((surface_step_fast_poly<T>(r[q], s, coef, odd)))
             }
         }
     }

@@ -68,7 +68,7 @@ enum { SL_IN0 = 0, SL_IN1, SL_IN2, SL_IN3, SL_OUT0, SL_OUT1, SL_OUT2, SL_OUT3, S
        SL_BUNDLES, SL_AXES, SL_WEX, SL_WEY, SL_WR, SL_WTH, SL_TCNT, SL_TSX, SL_TSY, SL_TRM,
        SL_TOFF, SL_TSQ, SL_AGG, SL_RES0, SL_RES1, SL_TAB0, SL_TAB1, SL_TAB2, SL_TAB3,
        SL_SB_FO, SL_SB_REC, SL_SB_MF, SL_SB_MR, SL_SB_TLF, SL_SB_TLR, SL_SB_AIN, SL_SB_AOUT, SL_SB_ENDS, SL_SB_FLAG,
-       SL_SB_FIELDS, SL_SB_A, SL_SB_HP, SL_SB_PACK, SL_SB_CEXT, SL_SB_CREV, SL_COUNT };
+       SL_SB_FIELDS, SL_SB_A, SL_SB_HP, SL_SB_PACK, SL_SB_CEXT, SL_SB_CREV, SL_FTSTATE, SL_FTTICKET, SL_COUNT };
 
 }  // namespace
 
@@ -81,6 +81,10 @@ struct ort_ctx {
     std::vector<unsigned char> bundle_cache;   // last uploaded DevBundle bytes
     void* pin = nullptr;                       // page-locked staging for the packed small transfers
     size_t pin_cap = 0;
+    // full_trace look-back (k_trace<FT_FULL>): words of earlier launches are told apart by the epoch, tickets by the base
+    size_t ft_state_cap = 0;                   // capacity of SL_FTSTATE the zero fill was done for
+    unsigned ft_epoch = 0;
+    unsigned long long ft_ticket_base = 0;
     int pinned(size_t bytes, unsigned char** out)
     {
         if (bytes > pin_cap) {
@@ -448,13 +452,8 @@ int run_full_trace(ort_ctx* ctx, TraceParams<T>& p, int nb, T* ex, T* ey, T* rho
         }
         return ORT_OK;
     }
-    rc = dev_out<T>(ctx, SL_WEX, (size_t)N, &p.w_ex); if (rc) return rc;
-    rc = dev_out<T>(ctx, SL_WEY, (size_t)N, &p.w_ey); if (rc) return rc;
-    rc = dev_out<T>(ctx, SL_WR, (size_t)N, &p.w_r); if (rc) return rc;
-    rc = dev_out<T>(ctx, SL_WTH, (size_t)N, &p.w_th); if (rc) return rc;
-    int64_t* tile_off; double* tile_sq; FtBundleAgg* agg;
-    rc = dev_out<int64_t>(ctx, SL_TOFF, (size_t)tiles, &tile_off); if (rc) return rc;
-    rc = dev_out<double>(ctx, SL_TSQ, (size_t)tiles, &tile_sq); if (rc) return rc;
+    double* chunk_sq; FtBundleAgg* agg;
+    rc = dev_out<double>(ctx, SL_TSQ, (size_t)tiles, &chunk_sq); if (rc) return rc;
     rc = dev_out<FtBundleAgg>(ctx, SL_AGG, (size_t)nb, &agg); if (rc) return rc;
     T *dex = ex, *dey = ey, *drho = rho, *dth = theta;
     if (!devp) {
@@ -463,16 +462,36 @@ int run_full_trace(ort_ctx* ctx, TraceParams<T>& p, int nb, T* ex, T* ey, T* rho
         rc = dev_out<T>(ctx, SL_OUT2, (size_t)2 * N, &drho); if (rc) return rc;
         rc = dev_out<T>(ctx, SL_OUT4, (size_t)2 * N, &dth); if (rc) return rc;
     }
+    // look-back state: one 8-byte word per tile + the ticket counter; zero-filled when (re)allocated only — the
+    // epoch tells the words of this launch from older ones, the base does the same for tickets
+    rc = dev_out<unsigned long long>(ctx, SL_FTSTATE, (size_t)tiles, &p.ft_state); if (rc) return rc;
+    if (ctx->slot[SL_FTSTATE].cap != ctx->ft_state_cap) {
+        HIP_TRY(hipMemsetAsync(p.ft_state, 0, ctx->slot[SL_FTSTATE].cap, ctx->stream));
+        ctx->ft_state_cap = ctx->slot[SL_FTSTATE].cap;
+    }
+    if (!ctx->slot[SL_FTTICKET].p) {
+        rc = dev_out<unsigned long long>(ctx, SL_FTTICKET, 1, &p.ft_ticket); if (rc) return rc;
+        HIP_TRY(hipMemsetAsync(p.ft_ticket, 0, sizeof(unsigned long long), ctx->stream));
+        ctx->ft_ticket_base = 0;
+    }
+    p.ft_ticket = static_cast<unsigned long long*>(ctx->slot[SL_FTTICKET].p);
+    ctx->ft_epoch = (ctx->ft_epoch + 1) & 0x3fffffffu;
+    if (ctx->ft_epoch == 0) ctx->ft_epoch = 1;
+    p.ft_epoch = ctx->ft_epoch;
+    p.ft_ticket_base = ctx->ft_ticket_base;
+    ctx->ft_ticket_base += (unsigned long long)tiles;
+    p.out_ex = dex; p.out_ey = dey; p.out_r = drho; p.out_th = dth;
+    // trace + stop filter + ordered compaction of the first half | bundle aggregates | rho, mirror half, squared
+    // deviations (survivors only) | sigma
     rc = launch_trace<T, true, false, false, FT_FULL>(ctx, p, tiles, flags); if (rc) return rc;
     hipLaunchKernelGGL(k_ft_scan, dim3((unsigned)nb), dim3(kBlock), 0, ctx->stream,
-                       p.tile_cnt, p.tile_sx, p.tile_sy, p.tile_rmax, p.tiles_per_bundle, tile_off, agg);
+                       p.tile_cnt, p.tile_sx, p.tile_sy, p.tile_rmax, p.tiles_per_bundle, agg);
     HIP_TRY(hipGetLastError());
-    hipLaunchKernelGGL((k_ft_scatter<T>), dim3((unsigned)tiles), dim3(kBlock), 0, ctx->stream,
-                       p.w_ex, p.w_ey, p.w_r, p.w_th, rpb, p.tiles_per_bundle, tile_off, agg,
-                       dex, dey, drho, dth, tile_sq);
+    hipLaunchKernelGGL((k_ft_mirror<T>), dim3((unsigned)tiles), dim3(kBlock), 0, ctx->stream,
+                       rpb, p.tiles_per_bundle, agg, dex, dey, drho, dth, chunk_sq);
     HIP_TRY(hipGetLastError());
     hipLaunchKernelGGL(k_ft_finalize, dim3((unsigned)nb), dim3(kBlock), 0, ctx->stream,
-                       tile_sq, p.tiles_per_bundle, agg, dcount, drms);
+                       chunk_sq, p.tiles_per_bundle, agg, dcount, drms);
     HIP_TRY(hipGetLastError());
     if (!devp) {
         rc = from_device<int64_t>(ctx, count, dcount, (size_t)nb); if (rc) return rc;

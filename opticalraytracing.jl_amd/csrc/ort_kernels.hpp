@@ -80,8 +80,14 @@ struct TraceParams {
     T* xv; T* yv; int64_t ld;
     T* xf; T* yf; T* xs; T* ys;
     int32_t* status;
-    // full_trace dense workspace + tile aggregates
-    T* w_ex; T* w_ey; T* w_r; T* w_th;
+    // full_trace (FT_FULL): the first half of the error vectors is written by the trace kernel itself —
+    // out_* = caller's ex / ey / rho / theta, [nb][2*rpb]; rho holds the UN-normalised stop radius until
+    // k_ft_mirror divides it — at an offset found by a decoupled look-back over the bundle's tiles
+    T* out_ex; T* out_ey; T* out_r; T* out_th;
+    unsigned long long* ft_state;       // [tiles] look-back words: state (2 bits) | epoch (30 bits) | prefix (32 bits)
+    unsigned long long* ft_ticket;      // tiles are taken in ticket order: every predecessor of a tile has started
+    unsigned long long ft_ticket_base;  // tickets handed out by earlier launches
+    unsigned ft_epoch;                  // launch number: words of earlier launches read as "not yet written"
     int32_t* tile_cnt; double* tile_sx; double* tile_sy; double* tile_rmax;
     double* tile_m2x; double* tile_m2y;     // FT_STATS: sums of squared deviations about the tile means
 };
@@ -156,14 +162,25 @@ __global__ __launch_bounds__(kBlock, (HIST && SUMM) ? ORT_MIN_WAVES - 1 : ORT_MI
 
     const int tid = threadIdx.x;
     const int S = p.S;
+    // FT_FULL: the tile index is a TICKET, not blockIdx — the look-back below waits on tiles with lower indices,
+    // and a ticket order guarantees they are running or done whatever order the hardware dispatches blocks in
+    __shared__ unsigned s_bid;
+    if (FT == FT_FULL) {
+        if (tid == 0) {
+            const unsigned long long tk = atomicAdd(p.ft_ticket, 1ull) - p.ft_ticket_base;
+            s_bid = tk < gridDim.x ? (unsigned)tk : gridDim.x - 1;   // (never out of the grid, whatever the host passed)
+        }
+        __syncthreads();
+    }
+    const unsigned bid = (FT == FT_FULL) ? s_bid : blockIdx.x;
     int sysid, b = 0;
     int64_t j0;          // first ray of this thread inside its bundle / list
     int64_t gbase;       // global index of ray j0
     int64_t limit;       // rays in this bundle / list
     unsigned tile_base = 0;   // first ray of this workgroup's tile inside its bundle (wave-uniform)
     if (GRID) {
-        b = blockIdx.x / p.tiles_per_bundle;
-        const int tile = blockIdx.x - b * p.tiles_per_bundle;
+        b = bid / p.tiles_per_bundle;
+        const int tile = bid - b * p.tiles_per_bundle;
         tile_base = (unsigned)tile * (unsigned)kTile;
         sysid = p.bundles[b].system;
         j0 = (int64_t)tile * kTile + (int64_t)tid * kRPT;
@@ -171,7 +188,7 @@ __global__ __launch_bounds__(kBlock, (HIST && SUMM) ? ORT_MIN_WAVES - 1 : ORT_MI
         gbase = (int64_t)b * p.rpb + j0;
     } else {
         sysid = p.isys;
-        j0 = (int64_t)blockIdx.x * kTile + (int64_t)tid * kRPT;
+        j0 = (int64_t)bid * kTile + (int64_t)tid * kRPT;
         limit = p.nrays;
         gbase = j0;
     }
@@ -199,8 +216,9 @@ __global__ __launch_bounds__(kBlock, (HIST && SUMM) ? ORT_MIN_WAVES - 1 : ORT_MI
     T xs_[kRPT], ys_[kRPT];
     int stopi = -1;
     T hprime = T(0), a_stop = T(0);
-    // (a lambda: a wave that met a far-cap hit launches its rays a second time, see below)
-    auto launch_rays = [&]() {
+    // (a lambda: a wave whose rays leave the domain of the fast forms launches them a second time, see below)
+    auto launch_rays = [&](auto math) {
+        constexpr int M = decltype(math)::value;
 #pragma unroll
         for (int r = 0; r < kRPT; ++r) {
             const int64_t j = j0 + r;
@@ -238,12 +256,12 @@ __global__ __launch_bounds__(kBlock, (HIST && SUMM) ? ORT_MIN_WAVES - 1 : ORT_MI
                 u = p.lU[jj]; v = p.lV[jj];
                 if (!p.slopes_given) { u = dev_tan(u); v = dev_tan(v); }   // :38-39
             }
-            ray_init<T, MATH>(ray[r], y, x, u, v);
+            ray_init<T, M>(ray[r], y, x, u, v);
             st[r] = 1;
             xs_[r] = T(0); ys_[r] = T(0);
         }
     };
-    launch_rays();
+    launch_rays(std::integral_constant<int, MATH>{});
     const bool two = (kRPT > 1) && live[kRPT - 1];
     // History stores: one wave-uniform decision, taken once — every lane of the wave owns two live
     // rays and both row bases keep 16-byte alignment on every surface (ld even) -> plain
@@ -262,11 +280,11 @@ __global__ __launch_bounds__(kBlock, (HIST && SUMM) ? ORT_MIN_WAVES - 1 : ORT_MI
     typedef const __attribute__((address_space(4))) SurfRec<T>* CRecPtr;
     const CRecPtr crec = (CRecPtr)(uintptr_t)grec;
     const int stop_u = __builtin_amdgcn_readfirstlane(stopi);    // bundle-uniform: the stop capture is a scalar branch
-    // The surface loop.  FARCAP = false is the hot path; it returns whether a ray of this lane met a sphere
-    // beyond its equator (MATH_FAST only; see surface_step_fast_sphere).
-    auto trace_surfaces = [&](auto farcap) -> bool {
-        constexpr bool FARCAP = decltype(farcap)::value;
-        bool far = false;
+    // The surface loop in arithmetic policy M.  MATH_FAST returns whether a ray of this lane left the domain of
+    // the fast forms (`odd`, ort_device.hpp).
+    auto trace_surfaces = [&](auto math) -> bool {
+        constexpr int M = decltype(math)::value;
+        bool odd = false;
         SurfRec<T> nxt;
         if (!USE_LDS) load_rec<T>(nxt, crec, 0);
         for (int i = 0; i < S; ++i) {
@@ -278,7 +296,7 @@ __global__ __launch_bounds__(kBlock, (HIST && SUMM) ? ORT_MIN_WAVES - 1 : ORT_MI
             const SurfRec<T>& rec = USE_LDS ? s_rec[i] : cur;
             const T* cf = USE_LDS ? (s_coef + i * ncoef) : (gcoef ? gcoef + (int64_t)(i + 1) * ncoef : nullptr);
             const int cls = __builtin_amdgcn_readfirstlane(rec.cls);     // wave-uniform -> scalar branch
-            surface_step_n<T, MATH, kRPT, FARCAP>(ray, rec, cf, cls, i == S - 1, far);
+            surface_step_n<T, M, kRPT>(ray, rec, cf, cls, i == S - 1, odd);
             if (SUMM || FT) {
 #pragma unroll
                 for (int r = 0; r < kRPT; ++r) {
@@ -314,17 +332,18 @@ __global__ __launch_bounds__(kBlock, (HIST && SUMM) ? ORT_MIN_WAVES - 1 : ORT_MI
                 }
             }
         }
-        return far;
+        return odd;
     };
-    const bool far_seen = trace_surfaces(std::false_type{});
-    if (MATH == MATH_FAST && __builtin_expect(__any(far_seen), 0)) {
-        // A ray of this wave met a sphere on its FAR cap (possible only far outside any clear aperture).  The
-        // reference refracts with the vertex-side normal there (PupilSampling.jl:16-19) and so must this
-        // policy: the wave traces its rays again with that rule applied per lane; its history stores land on
-        // the same addresses, after the first pass's have completed.
+    const bool odd_seen = trace_surfaces(std::integral_constant<int, MATH>{});
+    if (MATH == MATH_FAST && __builtin_expect(__any(odd_seen), 0)) {
+        // A ray of this wave went where the reference's formulas are no longer the geometry the fast forms compute
+        // (a far-cap hit, a direction refracted backward, a polynomial row outside its conic: possible only far
+        // outside any clear aperture).  What the reference does there is defined by its operation sequence, so the
+        // wave traces its rays again with exactly that — MATH_IEEE, bit-identical to the CPU reference; its history
+        // stores land on the same addresses, after the first pass's have completed.
         __builtin_amdgcn_s_waitcnt(0);
-        launch_rays();
-        trace_surfaces(std::true_type{});
+        launch_rays(std::integral_constant<int, MATH_IEEE>{});
+        trace_surfaces(std::integral_constant<int, MATH_IEEE>{});
     }
 
     if (SUMM) {
@@ -349,27 +368,32 @@ __global__ __launch_bounds__(kBlock, (HIST && SUMM) ? ORT_MIN_WAVES - 1 : ORT_MI
     }
 
     if (FT) {
-        // stop filter + dense staging (PupilSampling.jl:129-137); survivors are compacted,
-        // in ray order, by k_ft_scatter.
+        // stop filter (PupilSampling.jl:129-137).  FT_FULL: the tile's survivors are compacted IN RAY ORDER (two
+        // 64-bit ballots + popcount prefix per wave, wave offsets through LDS) and streamed to the first half of
+        // the bundle's output slab; FT_STATS: per-tile moments only.
         int cnt = 0; double sx = 0.0, sy = 0.0, rmax = -1.0;
         T exv[kRPT], eyv[kRPT], rv[kRPT], thv[kRPT];
+        bool keep[kRPT];
 #pragma unroll
         for (int r = 0; r < kRPT; ++r) {
             const T xf = ray[r].x, yf = ray[r].y;
             const T ri = dev_hypot(xs_[r], ys_[r]);                  // :131
             const bool drop = (ri > a_stop) || t_isnan(xf) || t_isnan(yf) || !live[r] ||   // :132
                               (st[r] & kStatusVignetted);
-            thv[r] = dev_atan2(ys_[r], xs_[r]);                      // :133
+            keep[r] = !drop;
+            if (FT == FT_FULL) thv[r] = dev_atan2(ys_[r], xs_[r]);   // :133
             eyv[r] = yf - hprime;                                    // :134
             exv[r] = xf;                                             // :135
             rv[r] = drop ? T(-1) : ri;                               // :136, -1 marks a dropped ray
             if (!drop) { ++cnt; sx += (double)exv[r]; sy += (double)eyv[r]; rmax = fmax(rmax, (double)ri); }
         }
-        if (FT == FT_FULL && live[0]) {
-            store_pair<T>(p.w_ex, gbase, two, exv[0], exv[kRPT - 1]);
-            store_pair<T>(p.w_ey, gbase, two, eyv[0], eyv[kRPT - 1]);
-            store_pair<T>(p.w_r, gbase, two, rv[0], rv[kRPT - 1]);
-            store_pair<T>(p.w_th, gbase, two, thv[0], thv[kRPT - 1]);
+        const int lane = tid & 63, wave = tid >> 6;
+        int rank0 = 0;
+        if (FT == FT_FULL) {
+            const unsigned long long m0 = __ballot(keep[0]);
+            const unsigned long long m1 = (kRPT > 1) ? __ballot(keep[kRPT - 1]) : 0ull;
+            const unsigned long long lt = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+            rank0 = __popcll(m0 & lt) + __popcll(m1 & lt);
         }
         // tile aggregates: fixed-shape tree -> bitwise reproducible
         for (int off = 32; off > 0; off >>= 1) {
@@ -378,15 +402,66 @@ __global__ __launch_bounds__(kBlock, (HIST && SUMM) ? ORT_MIN_WAVES - 1 : ORT_MI
             sy += __shfl_down(sy, off);
             rmax = fmax(rmax, __shfl_down(rmax, off));
         }
-        const int wave = tid >> 6;
-        if ((tid & 63) == 0) { s_wcnt[wave] = cnt; s_wsx[wave] = sx; s_wsy[wave] = sy; s_wmax[wave] = rmax; }
+        if (lane == 0) { s_wcnt[wave] = cnt; s_wsx[wave] = sx; s_wsy[wave] = sy; s_wmax[wave] = rmax; }
         __syncthreads();
         if (FT == FT_FULL) {
-            if (tid == 0) {
-                int c = 0; double ax = 0.0, ay = 0.0, mx = -1.0;
-                for (int w = 0; w < kBlock / 64; ++w) { c += s_wcnt[w]; ax += s_wsx[w]; ay += s_wsy[w]; mx = fmax(mx, s_wmax[w]); }
-                p.tile_cnt[blockIdx.x] = c; p.tile_sx[blockIdx.x] = ax; p.tile_sy[blockIdx.x] = ay;
-                p.tile_rmax[blockIdx.x] = mx;
+            __shared__ T s_cx[FT == FT_FULL ? kTile : 1], s_cy[FT == FT_FULL ? kTile : 1], s_cr[FT == FT_FULL ? kTile : 1],
+                         s_ct[FT == FT_FULL ? kTile : 1];
+            __shared__ long long s_base;
+            int woff = 0, c = 0;
+            for (int w = 0; w < kBlock / 64; ++w) { woff += (w < wave) ? s_wcnt[w] : 0; c += s_wcnt[w]; }
+            int k = woff + rank0;
+#pragma unroll
+            for (int r = 0; r < kRPT; ++r)
+                if (keep[r]) { s_cx[k] = exv[r]; s_cy[k] = eyv[r]; s_cr[k] = rv[r]; s_ct[k] = thv[r]; ++k; }
+            const int tile = (int)(bid - (unsigned)b * (unsigned)p.tiles_per_bundle);
+            if (wave == 0) {
+                // Exclusive offset of this tile among its bundle's survivors: decoupled look-back (Merrill & Garland) over
+                // the bundle's earlier tiles, 64 at a time.  One 8-byte word per tile carries everything, so relaxed
+                // agent-scope atomics suffice: state 1 = the tile's own count, state 2 = inclusive prefix.
+                double ax = 0.0, ay = 0.0, mx = -1.0;
+                for (int w = 0; w < kBlock / 64; ++w) { ax += s_wsx[w]; ay += s_wsy[w]; mx = fmax(mx, s_wmax[w]); }
+                const unsigned long long ep = (unsigned long long)(p.ft_epoch & 0x3fffffffu) << 32;
+                unsigned long long* stw = p.ft_state + (size_t)b * p.tiles_per_bundle;
+                if (lane == 0) {
+                    p.tile_cnt[bid] = c; p.tile_sx[bid] = ax; p.tile_sy[bid] = ay; p.tile_rmax[bid] = mx;
+                    __hip_atomic_store(stw + tile, ((tile == 0 ? 2ull : 1ull) << 62) | ep | (unsigned)c, __ATOMIC_RELAXED,
+                                       __HIP_MEMORY_SCOPE_AGENT);
+                }
+                long long excl = 0;
+                int hi = tile - 1;                               // next predecessor to look at
+                while (hi >= 0) {
+                    const int t = hi - lane;                     // lane l looks at tile hi - l
+                    unsigned long long wd = 2ull << 62 | ep;     // beyond the first tile: an inclusive prefix of 0
+                    if (t >= 0) {
+                        // every tile with a lower ticket is running or done, so this wait ends; the cap is a guard
+                        // against a host-side bookkeeping error only (the wave then leaves with a zero prefix)
+                        for (int spin = 0; spin < (1 << 24); ++spin) {
+                            wd = __hip_atomic_load(stw + t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                            if ((wd >> 62) != 0 && (wd & (0x3fffffffull << 32)) == ep) break;
+                            wd = 2ull << 62 | ep;
+                            __builtin_amdgcn_s_sleep(1);
+                        }
+                    }
+                    const unsigned long long incl = __ballot((wd >> 62) == 2);
+                    const int first = incl ? __builtin_ctzll(incl) : 64;       // nearest tile holding an inclusive prefix
+                    long long v = (lane <= first) ? (long long)(wd & 0xffffffffull) : 0;
+                    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off);
+                    excl += __shfl(v, 0);
+                    if (incl) break;
+                    hi -= 64;
+                }
+                if (lane == 0) {
+                    if (tile != 0)
+                        __hip_atomic_store(stw + tile, (2ull << 62) | ep | (unsigned long long)(unsigned)(excl + c), __ATOMIC_RELAXED,
+                                           __HIP_MEMORY_SCOPE_AGENT);
+                    s_base = excl;
+                }
+            }
+            __syncthreads();
+            const int64_t o0 = (int64_t)b * 2 * p.rpb + s_base;
+            for (int j = tid; j < c; j += kBlock) {
+                p.out_ex[o0 + j] = s_cx[j]; p.out_ey[o0 + j] = s_cy[j]; p.out_r[o0 + j] = s_cr[j]; p.out_th[o0 + j] = s_ct[j];
             }
         } else {
             // FT_STATS: two-pass INSIDE the tile (the tile's survivors are still in registers): tile means,
@@ -473,8 +548,8 @@ __global__ __launch_bounds__(kBlock) void k_ft_stats_reduce(const int32_t* __res
 }
 
 // ------------------------------------------------------------------------------------
-// full_trace, stage B: per bundle, exclusive scan of the tile survivor counts and the
-// bundle aggregates (count, centroid, max radius).  One workgroup per bundle.
+// full_trace, stage B: per bundle, the aggregates of its tiles (count, centroid, max radius).
+// One workgroup per bundle; fixed-shape tree: bitwise reproducible.
 // ------------------------------------------------------------------------------------
 struct FtBundleAgg {
     int64_t m;        // survivors (first half)
@@ -488,46 +563,27 @@ __global__ __launch_bounds__(kBlock) void k_ft_scan(const int32_t* __restrict__ 
                                                     const double* __restrict__ tile_sy,
                                                     const double* __restrict__ tile_rmax,
                                                     int tiles_per_bundle,
-                                                    int64_t* __restrict__ tile_off,
                                                     FtBundleAgg* __restrict__ agg)
 {
-    __shared__ int64_t s_w[kBlock / 64];
-    __shared__ int64_t s_carry;
+    __shared__ long long s_rc[kBlock];
     __shared__ double s_rx[kBlock], s_ry[kBlock], s_rm[kBlock];
-    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int b = blockIdx.x, tid = threadIdx.x;
     const int64_t base = (int64_t)b * tiles_per_bundle;
-    if (tid == 0) s_carry = 0;
-    double ax = 0.0, ay = 0.0, mx = -1.0;
-    __syncthreads();
-    for (int t0 = 0; t0 < tiles_per_bundle; t0 += kBlock) {
-        const int t = t0 + tid;
-        const int64_t c = (t < tiles_per_bundle) ? tile_cnt[base + t] : 0;
-        if (t < tiles_per_bundle) { ax += tile_sx[base + t]; ay += tile_sy[base + t]; mx = fmax(mx, tile_rmax[base + t]); }
-        // inclusive wave scan
-        int64_t v = c;
-        for (int off = 1; off < 64; off <<= 1) {
-            const int64_t nb = __shfl_up(v, off);
-            if (lane >= off) v += nb;
-        }
-        if (lane == 63) s_w[wave] = v;
-        __syncthreads();
-        int64_t woff = 0;
-        for (int w = 0; w < wave; ++w) woff += s_w[w];
-        const int64_t carry = s_carry;
-        if (t < tiles_per_bundle) tile_off[base + t] = carry + woff + v - c;
-        __syncthreads();
-        if (tid == kBlock - 1) s_carry = carry + woff + v;
-        __syncthreads();
+    long long ac = 0; double ax = 0.0, ay = 0.0, mx = -1.0;
+    for (int t = tid; t < tiles_per_bundle; t += kBlock) {
+        ac += tile_cnt[base + t]; ax += tile_sx[base + t]; ay += tile_sy[base + t]; mx = fmax(mx, tile_rmax[base + t]);
     }
-    // deterministic tree over the 256 per-thread partials
-    s_rx[tid] = ax; s_ry[tid] = ay; s_rm[tid] = mx;
+    s_rc[tid] = ac; s_rx[tid] = ax; s_ry[tid] = ay; s_rm[tid] = mx;
     __syncthreads();
     for (int off = kBlock / 2; off > 0; off >>= 1) {
-        if (tid < off) { s_rx[tid] += s_rx[tid + off]; s_ry[tid] += s_ry[tid + off]; s_rm[tid] = fmax(s_rm[tid], s_rm[tid + off]); }
+        if (tid < off) {
+            s_rc[tid] += s_rc[tid + off]; s_rx[tid] += s_rx[tid + off]; s_ry[tid] += s_ry[tid + off];
+            s_rm[tid] = fmax(s_rm[tid], s_rm[tid + off]);
+        }
         __syncthreads();
     }
     if (tid == 0) {
-        const int64_t m = s_carry;
+        const int64_t m = s_rc[0];
         FtBundleAgg a;
         a.m = m;
         // mean of [ex; -ex] and of [ey; ey] over n = 2m entries
@@ -540,79 +596,39 @@ __global__ __launch_bounds__(kBlock) void k_ft_scan(const int32_t* __restrict__ 
 }
 
 // ------------------------------------------------------------------------------------
-// full_trace, stage C: order-preserving compaction (wave ballot + popcount prefix, then
-// wave offsets through LDS), mirror, rho/theta, squared deviations per tile.
+// full_trace, stage C: survivors only.  The first half (written by the trace kernel) is read once; rho is
+// normalised in place (r ./ maximum(r), :142), the mirrored half [-ex; ey; rho; pi - theta] goes to offset m
+// (:139-144), and the squared deviations about the centroid are summed per chunk (two-pass sigma, :169-173).
+// Grid: nb * chunks_per_bundle blocks of kTile entries; chunks beyond the bundle's m survivors leave at once.
 // ------------------------------------------------------------------------------------
 template <typename T>
-__global__ __launch_bounds__(kBlock) void k_ft_scatter(const T* __restrict__ w_ex, const T* __restrict__ w_ey,
-                                                       const T* __restrict__ w_r, const T* __restrict__ w_th,
-                                                       int64_t rpb, int tiles_per_bundle,
-                                                       const int64_t* __restrict__ tile_off,
-                                                       const FtBundleAgg* __restrict__ agg,
-                                                       T* __restrict__ ex, T* __restrict__ ey,
-                                                       T* __restrict__ rho, T* __restrict__ theta,
-                                                       double* __restrict__ tile_sq)
+__global__ __launch_bounds__(kBlock) void k_ft_mirror(int64_t rpb, int chunks_per_bundle,
+                                                      const FtBundleAgg* __restrict__ agg,
+                                                      T* __restrict__ ex, T* __restrict__ ey,
+                                                      T* __restrict__ rho, T* __restrict__ theta,
+                                                      double* __restrict__ chunk_sq)
 {
-    __shared__ int s_wcnt[kBlock / 64];
     __shared__ double s_wsq[kBlock / 64];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int b = blockIdx.x / tiles_per_bundle;
-    const int tile = blockIdx.x - b * tiles_per_bundle;
-    const int64_t j0 = (int64_t)tile * kTile + (int64_t)tid * kRPT;
-    const int64_t g0 = (int64_t)b * rpb + j0;
+    const int b = blockIdx.x / chunks_per_bundle;
+    const int chunk = blockIdx.x - b * chunks_per_bundle;
     const FtBundleAgg a = agg[b];
-    T e_x[kRPT], e_y[kRPT], rr[kRPT], th[kRPT];
-    bool keep[kRPT];
-#pragma unroll
-    for (int r = 0; r < kRPT; ++r) {
-        const bool in = (j0 + r) < rpb;
-        e_x[r] = in ? w_ex[g0 + r] : T(0);
-        e_y[r] = in ? w_ey[g0 + r] : T(0);
-        rr[r] = in ? w_r[g0 + r] : T(-1);
-        th[r] = in ? w_th[g0 + r] : T(0);
-        keep[r] = in && !(rr[r] < T(0));
-    }
-    const unsigned long long m0 = __ballot(keep[0]);
-    const unsigned long long m1 = (kRPT > 1) ? __ballot(keep[kRPT - 1]) : 0ull;
-    const unsigned long long lt = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
-    const int rank0 = __popcll(m0 & lt) + __popcll(m1 & lt);
-    const int wtot = __popcll(m0) + __popcll(m1);
-    if (lane == 0) s_wcnt[wave] = wtot;
-    __syncthreads();
-    int woff = 0;
-    for (int w = 0; w < wave; ++w) woff += s_wcnt[w];
-    const int64_t out0 = (int64_t)b * 2 * rpb;            // bundle region
-    // Survivors are compacted into LDS first and streamed out by the whole workgroup: every store instruction
-    // then writes 64 consecutive elements (the per-lane scatter wrote every other slot and took 2 instructions
-    // per row of a wave — half-used cache lines, 2.4 TB/s).
-    __shared__ T s_ex[kTile], s_ey[kTile], s_rh[kTile], s_th[kTile];
+    const int64_t j0 = (int64_t)chunk * kTile;
+    if (j0 >= a.m) { if (tid == 0) chunk_sq[blockIdx.x] = 0.0; return; }
+    const int64_t o0 = (int64_t)b * 2 * rpb;
     double sq = 0.0;
-    int k = woff + rank0;
-#pragma unroll
-    for (int r = 0; r < kRPT; ++r) {
-        if (keep[r]) {
-            s_ex[k] = e_x[r]; s_ey[k] = e_y[r]; s_th[k] = th[r];
-            s_rh[k] = rr[r] / (T)a.rmax;                                  // :142
-            const double dx1 = (double)e_x[r] - a.mux, dx2 = -(double)e_x[r] - a.mux;
-            const double dy = (double)e_y[r] - a.muy;
-            sq += (dx1 * dx1 + dx2 * dx2) + (dy * dy + dy * dy);
-            ++k;
-        }
-    }
-    __syncthreads();
-    if (ex) {                                                             // NULL outputs: statistics only
-        int cnt = 0;
-        for (int w = 0; w < kBlock / 64; ++w) cnt += s_wcnt[w];
-        const int64_t base = out0 + tile_off[blockIdx.x];
-        for (int j = tid; j < cnt; j += kBlock) {
-            const int64_t o = base + j;
-            const T vx = s_ex[j], vy = s_ey[j], vr = s_rh[j], vt = s_th[j];
-            ex[o] = vx;  ey[o] = vy;  rho[o] = vr;  theta[o] = vt;
-            ex[o + a.m] = -vx;                                            // :141
-            ey[o + a.m] = vy;                                             // :140
-            rho[o + a.m] = vr;                                            // :143
-            theta[o + a.m] = (T)3.141592653589793 - vt;                   // :144
-        }
+    for (int64_t j = j0 + tid; j < j0 + kTile && j < a.m; j += kBlock) {
+        const int64_t o = o0 + j;
+        const T vx = ex[o], vy = ey[o], vt = theta[o];
+        const T vr = rho[o] / (T)a.rmax;                                  // :142
+        rho[o] = vr;
+        ex[o + a.m] = -vx;                                                // :141
+        ey[o + a.m] = vy;                                                 // :140
+        rho[o + a.m] = vr;                                                // :143
+        theta[o + a.m] = (T)3.141592653589793 - vt;                       // :144
+        const double dx1 = (double)vx - a.mux, dx2 = -(double)vx - a.mux;
+        const double dy = (double)vy - a.muy;
+        sq += (dx1 * dx1 + dx2 * dx2) + (dy * dy + dy * dy);
     }
     for (int off = 32; off > 0; off >>= 1) sq += __shfl_down(sq, off);
     if (lane == 0) s_wsq[wave] = sq;
@@ -620,7 +636,7 @@ __global__ __launch_bounds__(kBlock) void k_ft_scatter(const T* __restrict__ w_e
     if (tid == 0) {
         double t = 0.0;
         for (int w = 0; w < kBlock / 64; ++w) t += s_wsq[w];
-        tile_sq[blockIdx.x] = t;
+        chunk_sq[blockIdx.x] = t;
     }
 }
 

@@ -2,8 +2,8 @@
 """Build-side guard for the hot loop of the FAST trace kernels (runs here, no GPU): compiles the library to
 gfx950 assembly and checks, for the history and the summary kernel,
   * the centre-form sphere arms (the blocks with exactly 4 v_rsq_f64 and no v_rcp_f64) carry no v_mov_b64,
-  * no other block of the surface loop is a pure copy block (>= 10 v_mov_b64 in <= 20 instructions),
-  * no scratch (spill) instruction anywhere in the kernel.
+  * no other block of the hot surface loop is a pure copy block (>= 10 v_mov_b64 in <= 20 instructions),
+  * no scratch (spill) instruction in the hot surface loop (the cold MATH_IEEE retrace may spill a few registers).
 The register coalescer's outcome is sensitive to the shape of the class dispatch in surface_step_n:
 run this after touching it.   python scripts/isa_lint.py"""
 import os, re, subprocess, sys, tempfile
@@ -21,25 +21,32 @@ with tempfile.TemporaryDirectory(dir=os.path.join(ROOT, "build") if os.path.isdi
 bad = 0
 for tag, name in KERNELS.items():
     i = txt.index(name + ":"); j = txt.index(".Lfunc_end", i)
-    blocks, cur, lab = [], [], "entry"
+    blocks, cur, lab, hdr = [], [], "entry", None
     for l in txt[i:j].split("\n"):
         t = l.strip()
-        m = re.match(r"^(\.LBB\d+_\d+):", t)
+        m = re.match(r"^(\.LBB\d+_\d+):(.*)", t)
         if m:
-            blocks.append((lab, cur)); cur = []; lab = m.group(1)
+            blocks.append((lab, hdr, cur)); cur = []; lab = m.group(1)
+            h = re.search(r"Header=BB(\d+_\d+)", m.group(2))      # LLVM's loop annotation of the block
+            hdr = ".LBB" + h.group(1) if h else (lab if "Loop Header" in m.group(2) else None)
         elif t and not t.startswith((".", ";")):
             cur.append(t.split(";")[0].strip())
-    blocks.append((lab, cur))
-    n_inst = sum(len(b) for _, b in blocks)
-    scratch = sum(1 for _, b in blocks for x in b if "scratch_" in x)
-    arms = [(lab, b) for lab, b in blocks if sum(x.startswith("v_rsq_f64") for x in b) == 4 and not any(x.startswith("v_rcp_f64") for x in b)]
-    arm_movs = [sum(x.startswith("v_mov_b64") for x in b) for _, b in arms]
-    arm_valu = [sum(x.startswith("v_") for x in b) for _, b in arms]
-    copy_blocks = [lab for lab, b in blocks if len(b) <= 20 and sum(x.startswith("v_mov_b64") for x in b) >= 10]
+    blocks.append((lab, hdr, cur))
+    n_inst = sum(len(b) for _, _, b in blocks)
+    arms = [(lab, h, b) for lab, h, b in blocks if sum(x.startswith("v_rsq_f64") for x in b) == 4 and not any(x.startswith("v_rcp_f64") for x in b)]
+    hot = arms[0][1] if arms else None                     # header of the loop the fast arms sit in = the hot surface loop
+    hot_blocks = [(lab, b) for lab, h, b in blocks if h == hot]
+    scratch_hot = sum(1 for _, b in hot_blocks for x in b if "scratch_" in x)
+    scratch_all = sum(1 for _, _, b in blocks for x in b if "scratch_" in x)
+    arm_movs = [sum(x.startswith("v_mov_b64") for x in b) for _, _, b in arms]
+    arm_valu = [sum(x.startswith("v_") for x in b) for _, _, b in arms]
+    copy_blocks = [lab for lab, b in hot_blocks if len(b) <= 20 and sum(x.startswith("v_mov_b64") for x in b) >= 10]
     # the general (grouped) arm keeps its own merge copies; they must not sit on the sphere / flat path:
-    # heuristically, at most one pure copy block may remain per copy of the surface loop (hot pass + far-cap retrace)
-    ok = scratch == 0 and len(arms) >= 2 and all(m == 0 for m in arm_movs[:2]) and len(copy_blocks) <= 2
-    print(f"{tag}: {n_inst} instructions, scratch {scratch}, sphere arms VALU {arm_valu[:2]} with v_mov_b64 {arm_movs[:2]}, "
-          f"pure copy blocks {copy_blocks} -> {'ok' if ok else 'REGRESSION'}")
+    # heuristically, at most one pure copy block may remain in the hot loop.  Spills are tolerated only outside it
+    # (the MATH_IEEE retrace of a wave that left the fast forms' domain is cold code).
+    ok = scratch_hot == 0 and len(arms) >= 2 and all(m == 0 for m in arm_movs[:2]) and len(copy_blocks) <= 1
+    print(f"{tag}: {n_inst} instructions ({sum(len(b) for _, b in hot_blocks)} in the hot loop), scratch in the hot loop {scratch_hot} "
+          f"(kernel {scratch_all}), sphere arms VALU {arm_valu[:2]} with v_mov_b64 {arm_movs[:2]}, pure copy blocks {copy_blocks} "
+          f"-> {'ok' if ok else 'REGRESSION'}")
     bad += not ok
 sys.exit(1 if bad else 0)

@@ -612,41 +612,56 @@ def _random_system(rng, rows, aspheric):
     return R, t, n, K, coef
 
 
-# FAST-policy attribution thresholds (tests below; measured tables: scripts/fast_attribution.py, profiles/).
-# A deviation of the FAST forms from the reference sequence is rounding-level (<= a few 1e-16 per operation)
-# amplified by the conditioning of the ray's path: 1 / sqrt(margin) at a square root whose normalised radicand
-# (sag discriminant, refraction discriminant, tilt radicand: oracle `skew_margins`) is `margin`.
-FAST_MARGIN = 1e-6        # rays whose smallest margin is above this must agree to FAST_TOL, status included
+# FAST-policy attribution (tests below; measured tables: scripts/fast_attribution.py, profiles/r02_fast_attribution*.log).
+# The FAST forms differ from the reference sequence by rounding only; wherever the reference's formulas stop being
+# the geometry (far-cap hits, backward directions, polynomial rows outside their conic) the kernel retraces the
+# wave with the reference sequence itself.  A rounding difference is amplified by the conditioning of the ray's
+# path, which the oracle measures on itself:
+#   margin = smallest normalised distance to a miss / TIR / equator boundary (oracle skew_margins),
+#   sens   = largest relative change of any coordinate under a 1e-13 relative perturbation of the launch data.
+FAST_FLIP_MARGIN = 1e-9   # a status flip is attributable only to a discriminant within 1e-9 (normalised) of zero
+FAST_MARGIN = 1e-6        # rays closer than this to a boundary are not value-compared (and must be rare)
 FAST_TOL = 1e-10          # BASELINE north_star: 1e-10 relative
+FAST_AMP = 100.0          # ... or 100 x the oracle's own response to the 1e-13 perturbation, whichever is larger
 
 
-def _fast_attribution(fast, oracle_engine, pres, y, x, u, v, rows, tag):
-    """One prescription: FAST vs oracle, every ray classified by the oracle's conditioning probe.  Returns
-    (rays, ill-conditioned rays, far-cap rays).  Asserts: status identical and coordinates within FAST_TOL on
-    every ray whose smallest margin exceeds FAST_MARGIN — far-cap hits, post-TIR paths and huge coordinates
-    included; every deviating ray is therefore attributed to a discriminant within FAST_MARGIN of zero."""
+def _deviation(ax, ay, bx, by):
+    s = np.maximum(1.0, np.maximum(np.nanmax(np.abs(bx), axis=0, initial=0.0), np.nanmax(np.abs(by), axis=0, initial=0.0)))
+    d = np.maximum(np.nanmax(np.abs(ax - bx), axis=0, initial=0.0), np.nanmax(np.abs(ay - by), axis=0, initial=0.0)) / s
+    pat = (np.isnan(ax) != np.isnan(bx)).any(axis=0) | (np.isnan(ay) != np.isnan(by)).any(axis=0)
+    return np.where(pat, np.inf, d)
+
+
+def _fast_attribution(fast, oracle_engine, pres, y, x, u, v, tag):
+    """One prescription: FAST vs oracle, every ray classified by the oracle.  Asserts (1) a status flip only
+    within FAST_FLIP_MARGIN of a branch boundary, (2) NaN patterns identical and coordinates within
+    max(FAST_TOL, FAST_AMP * sens) on every other ray farther than FAST_MARGIN from a boundary — far-cap hits,
+    post-TIR paths and huge coordinates included.  Returns (rays, rays within FAST_MARGIN, far-cap rays, flips)."""
     ox, oy, os_ = oracle_engine.skew(pres, y, x, u, v, slopes=True, want_status=True)
+    d = 1e-13
+    px, py = oracle_engine.skew(pres, y * (1 + d), x * (1 - d), u * (1 + d), v * (1 - d), slopes=True)
+    sens = _deviation(px, py, ox, oy)
     fx, fy, fs = fast.skew(pres, y, x, u, v, slopes=True, want_status=True)
     mg = oracle_engine.skew_margins(pres, y, x, u, v)
     cond = np.min(np.abs(mg[:, :3]), axis=1)
-    well = cond > FAST_MARGIN
-    scale = np.maximum(1.0, np.maximum(np.nanmax(np.abs(ox), axis=0, initial=0.0), np.nanmax(np.abs(oy), axis=0, initial=0.0)))
-    err = np.maximum(np.nanmax(np.abs(fx - ox), axis=0, initial=0.0), np.nanmax(np.abs(fy - oy), axis=0, initial=0.0)) / scale
-    nanpat = (np.isnan(fx) != np.isnan(ox)).any(axis=0) | (np.isnan(fy) != np.isnan(oy)).any(axis=0)
-    bad = well & ((fs != os_) | nanpat | (err > FAST_TOL))
-    assert not bad.any(), (tag, int(bad.sum()), float(err[bad].max()), float(cond[bad].min()), int((mg[bad, 3] > 0).sum()))
-    return y.size, int((~well).sum()), int((mg[:, 3] > 0).sum())
+    err = _deviation(fx, fy, ox, oy)
+    flip = fs != os_
+    bad_flip = flip & (cond > FAST_FLIP_MARGIN)
+    assert not bad_flip.any(), (tag, "status", int(bad_flip.sum()), float(cond[bad_flip].min()), mg[bad_flip][:3])
+    bad = ~flip & (cond > FAST_MARGIN) & ~(err <= np.maximum(FAST_TOL, FAST_AMP * sens))
+    assert not bad.any(), (tag, "coordinates", int(bad.sum()), float(err[bad].max()), float(sens[bad].max()), float(cond[bad].min()),
+                           int((mg[bad, 3] > 0).sum()))
+    return y.size, int((cond <= FAST_MARGIN).sum()), int((mg[:, 3] > 0).sum()), int(flip.sum())
 
 
 def test_random_systems_property(hip_engine, oracle_engine):
     """120 random prescriptions (2-14 rows; flat rows, both curvature signs, conics, polynomial
     terms, glass/air sequences that TIR and miss) x 1500 random skew rays each: the IEEE policy is
-    BIT-IDENTICAL to the oracle on every ray incl. NaN patterns and status; the FAST policy agrees to
-    1e-10 with identical status on EVERY ray that is not within 1e-6 (normalised) of a miss / TIR /
-    equator boundary, and those rays are rare (attribution, not a blanket tolerance)."""
+    BIT-IDENTICAL to the oracle on every ray incl. NaN patterns and status; every deviation of the FAST
+    policy is attributed ray by ray (see _fast_attribution): no blanket tolerance."""
     rng = np.random.default_rng(2024)
     fast = ort.HipEngine(0, fast_math=True)
-    ntot = nill = nfar = 0
+    ntot = nill = nfar = nflip = 0
     for case in range(120):
         rows = int(rng.integers(2, 15))
         aspheric = case % 3 == 0
@@ -662,19 +677,19 @@ def test_random_systems_property(hip_engine, oracle_engine):
             assert cm.rel_err(gx, ox, 1.0).max() <= 1e-11 and cm.rel_err(gy, oy, 1.0).max() <= 1e-11, case
         else:
             assert np.array_equal(gx, ox, equal_nan=True) and np.array_equal(gy, oy, equal_nan=True), case
-        a, b, c = _fast_attribution(fast, oracle_engine, pres, y, x, u, v, rows, case)
-        ntot += a; nill += b; nfar += c
-    assert nill <= 1e-4 * ntot, (nill, ntot)
+        a, b, c, f = _fast_attribution(fast, oracle_engine, pres, y, x, u, v, case)
+        ntot += a; nill += b; nfar += c; nflip += f
+    assert nill <= 1e-4 * ntot and nflip <= 1e-5 * ntot, (nill, nflip, ntot)
 
 
 def test_fast_policy_far_cap_and_wide_bundles(oracle_engine):
     """The FAST policy on what a lens designer never traces but the reference defines: strongly curved rows
     (|R| 6.5-30 mm) under +-14 mm, +-0.2 rad bundles — thousands of FAR-CAP hits (beyond a sphere's equator,
     where the reference refracts with the vertex-side normal, src/PupilSampling.jl:16-19), TIR and miss
-    sequences.  Same attribution assert: every ray outside the 1e-6 margin agrees to 1e-10, status included."""
+    sequences, directions refracted backward.  Same ray-by-ray attribution."""
     rng = np.random.default_rng(31337)
     fast = ort.HipEngine(0, fast_math=True)
-    ntot = nill = nfar = 0
+    ntot = nill = nfar = nflip = 0
     for case in range(60):
         rows = int(rng.integers(3, 15))
         aspheric = case % 3 == 0
@@ -684,10 +699,10 @@ def test_fast_policy_far_cap_and_wide_bundles(oracle_engine):
         m = 2000
         y = rng.uniform(-14, 14, m); x = rng.uniform(-14, 14, m)
         u = np.tan(rng.uniform(-0.2, 0.2, m)); v = np.tan(rng.uniform(-0.2, 0.2, m))
-        a, b, c = _fast_attribution(fast, oracle_engine, pres, y, x, u, v, rows, case)
-        ntot += a; nill += b; nfar += c
+        a, b, c, f = _fast_attribution(fast, oracle_engine, pres, y, x, u, v, case)
+        ntot += a; nill += b; nfar += c; nflip += f
     assert nfar >= 1000, nfar                      # the far-cap rule is exercised, not vacuous
-    assert nill <= 2e-3 * ntot, (nill, ntot)
+    assert nill <= 2e-3 * ntot and nflip <= 1e-4 * ntot, (nill, nflip, ntot)
 
 
 def test_random_systems_meridional_and_paraxial(hip_engine, oracle_engine):
