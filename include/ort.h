@@ -36,7 +36,7 @@
 extern "C" {
 #endif
 
-#define ORT_VERSION 100            /* 0.1.0 */
+#define ORT_VERSION 200            /* 0.2.0: ort_aim_out gained XP_t; ort_aberrations_f64, ort_fan_f64 */
 #define ORT_MAX_ROWS 64            /* surface-matrix rows per system, object row included */
 #define ORT_MAX_NCOEF 12           /* polynomial coefficients per surface */
 
@@ -212,11 +212,31 @@ typedef struct ort_aim_in {
 } ort_aim_in;
 typedef struct ort_aim_out {
     double U, y1, y2, y_EP, hprime, EP_t, Ubar;
+    double XP_t;           /* real_chief.z[end] - real_chief.z[end-1] (src/RayTracing.jl:294): exit pupil from the last vertex */
     int32_t iters;
     int32_t ok;            /* 0 = a Newton loop hit its iteration cap */
 } ort_aim_out;
 int ort_aim_f64(ort_ctx *ctx, const ort_system *fwd, const ort_system *rev, int n,
                 const ort_aim_in *in, ort_aim_out *out, unsigned flags);
+
+/* ---- meridional fans: TSA(surfaces, system, k_rays) and the caustic ray set ----------------------
+ * src/SeidelAberrations.jl:116-137: for every request the k_rays rays y = range(y_m / k, y_m, k), U = 0 through
+ * system `system` of the batch in one launch, each extended to the exit pupil and to the focal plane:
+ *   y_XP[i] = ray.y[end] + tan(ray.u[end]) XP_t,   eps[i] = ray.y[end] + tan(ray.u[end]) (BFD - sag(ray))
+ * (the last ray is the real marginal ray itself, :127-128).  descending != 0 walks the range backwards,
+ * range(y_m, y_m / k, k): with BFD = the paraxial or the marginal back focal distance this is the ray set
+ * and the image-space end points of the caustic plot (ext/MakieExtension.jl:364-381; its per-surface
+ * polylines are ort_trace_meridional_f64's history).  y_m, XP_t come from ort_aim_f64 (y_EP, XP_t).
+ * in : [n] host (device with ORT_DEVICE_PTRS); y_XP, eps : [n][k_rays].                              */
+typedef struct ort_fan_in {
+    int32_t system;        /* index into the ort_system batch */
+    int32_t layout_mode;   /* 1 = the prescription is a Layout{Aspheric} (Q16), as ORT_LAYOUT_INPUT */
+    double y_marg;         /* real_marginal.y[1] */
+    double XP_t;           /* real_chief.z[end] - real_chief.z[end-1] */
+    double BFD;            /* back focal distance the rays are extended to, from the last vertex */
+} ort_fan_in;
+int ort_fan_f64(ort_ctx *ctx, const ort_system *sys, int n, const ort_fan_in *in, int k_rays, int descending,
+                double *y_XP, double *eps, unsigned flags);
 
 /* ---- batched first-order solve + Seidel sums ------------------------------------------------
  * solve(surfaces, a, h′) (src/RayTracing.jl:302-335: Lens(), the two paraxial traces, stop
@@ -306,22 +326,47 @@ int ort_abcd_reverse_transfer_f64(ort_ctx *ctx, const double *M, int64_t nv, con
                                   unsigned flags);
 
 /* ---- multi-GPU reassembly: ONE all-gather of image-plane hits over RCCL / xGMI -------------
- * One process per GPU.  The path shards over independent bundles (no data-path collective); the
- * only exchange is the reassembly of equal-size per-rank hit slabs in rank order — which, with
+ * One process per GPU.  The path shards over independent units (bundles, pupil rows: no data-path
+ * collective); the only exchange is the reassembly of per-rank hit slabs in rank order — which, with
  * contiguous rank-ordered shards, reproduces the reference's append order
  * (src/PupilSampling.jl:134-137).  librccl.so is loaded on first use (dlopen), so the library has
  * no link-time dependency on it.
  *   rank 0: ort_comm_unique_id(id);  ship the 128 bytes to every rank (file, socket, MPI, ...)
  *   all   : ort_comm_create(ctx, nranks, rank, id, &comm)
- *   all   : ort_allgather_hits_f64(comm, xf, yf, count, gx, gy)      device pointers, async
- *           gx, gy : [nranks*count], rank r's slab at r*count.                                  */
+ *   all   : ort_trace_grid_f64(... xf = hits, yf = hits + count ...)      the trace writes the packed slab
+ *           ort_allgather_hits_packed_f64(comm, hits, count, gathered)    ONE ncclAllGather
+ *           ... trace the next shard meanwhile ...                         (the collective runs on the
+ *           ort_comm_wait(comm) / ort_comm_synchronize(comm)               communicator's own stream)
+ * Every collective below is ordered after the work already queued on the context's stream and runs on the
+ * communicator's own stream: it overlaps whatever the context's stream is given next.  ort_comm_wait makes the
+ * context's stream wait for the collectives issued so far (no host block); ort_comm_synchronize blocks the host.
+ * All data pointers are device pointers.                                                            */
 typedef struct ort_comm ort_comm;
 #define ORT_UNIQUE_ID_BYTES 128
 int ort_comm_unique_id(void *id128);
 int ort_comm_create(ort_ctx *ctx, int nranks, int rank, const void *id128, ort_comm **out);
 int ort_comm_destroy(ort_comm *comm);
+int ort_comm_size(const ort_comm *comm);
+int ort_comm_rank(const ort_comm *comm);
+int ort_comm_wait(ort_comm *comm);
+/* the context's stream waits for the collective issued `lag` calls before the latest (0 = the latest, lag < 8):
+ * with two hit buffers, ort_comm_wait_lag(comm, 1) before re-tracing into a buffer orders the trace after the
+ * all-gather that last read it while the latest all-gather still overlaps the trace.                     */
+int ort_comm_wait_lag(ort_comm *comm, int lag);
+int ort_comm_synchronize(ort_comm *comm);
+/* hits : [2][count] (x at +0, y at +count: pass xf = hits, yf = hits + count to the trace);
+ * gathered : [nranks][2][count], rank r's x slab at r*2*count, its y slab at r*2*count + count.       */
+int ort_allgather_hits_packed_f64(ort_comm *comm, const double *hits, int64_t count, double *gathered);
+int ort_allgather_hits_packed_f32(ort_comm *comm, const float *hits, int64_t count, float *gathered);
+/* separate x / y arrays: gx, gy : [nranks*count], rank r's slab at r*count (the two slabs go out fused
+ * into one RCCL launch).                                                                              */
 int ort_allgather_hits_f64(ort_comm *comm, const double *xf, const double *yf, int64_t count,
                            double *gx, double *gy);
+/* ragged slabs (compacted survivors, uneven shards): counts are exchanged first (8 bytes per rank, read by the
+ * host: this call blocks on that), then rank r's `count` values land at the exclusive offset of the counts.
+ * gathered : [capacity] device; counts : [nranks] HOST, out (may be NULL).                            */
+int ort_allgather_ragged_f64(ort_comm *comm, const double *values, int64_t count, double *gathered,
+                             int64_t capacity, int64_t *counts);
 
 #ifdef __cplusplus
 }

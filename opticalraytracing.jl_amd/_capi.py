@@ -63,9 +63,14 @@ class ort_aim_in(C.Structure):
 class ort_aim_out(C.Structure):
     _fields_ = [
         ("U", C.c_double), ("y1", C.c_double), ("y2", C.c_double), ("y_EP", C.c_double),
-        ("hprime", C.c_double), ("EP_t", C.c_double), ("Ubar", C.c_double),
+        ("hprime", C.c_double), ("EP_t", C.c_double), ("Ubar", C.c_double), ("XP_t", C.c_double),
         ("iters", C.c_int32), ("ok", C.c_int32),
     ]
+
+
+class ort_fan_in(C.Structure):
+    _fields_ = [("system", C.c_int32), ("layout_mode", C.c_int32), ("y_marg", C.c_double), ("XP_t", C.c_double),
+                ("BFD", C.c_double)]
 
 
 class ort_first_order(C.Structure):
@@ -116,6 +121,7 @@ SIGNATURES = {
     "ort_full_trace_f64": (_i, [_p, _p, _i, C.POINTER(ort_bundle), _p, _l, _i, _i, _p, _p, _p, _p, _p, _p, _u]),
     "ort_full_trace_f32": (_i, [_p, _p, _i, C.POINTER(ort_bundle), _p, _l, _i, _i, _p, _p, _p, _p, _p, _p, _u]),
     "ort_aim_f64": (_i, [_p, _p, _p, _i, C.POINTER(ort_aim_in), C.POINTER(ort_aim_out), _u]),
+    "ort_fan_f64": (_i, [_p, _p, _i, C.POINTER(ort_fan_in), _i, _i, _p, _p, _u]),
     "ort_first_order_f64": (_i, [_p, _i, _i, _p, _p, _p, _p, _p, _p, C.c_double, C.POINTER(ort_first_order), _u]),
     "ort_aberrations_f64": (_i, [_p, _i, _i, _p, _p, _p, _p, _p, _p, C.c_double, C.POINTER(ort_first_order), _p, _p, _u]),
     "ort_spot_batch_f64": (_i, [_p, _i, _i, _p, _p, _p, _p, _p, _i, _p, _i, C.POINTER(ort_first_order), _p, _p, _u]),
@@ -132,7 +138,15 @@ SIGNATURES = {
     "ort_comm_unique_id": (_i, [_p]),
     "ort_comm_create": (_i, [_p, _i, _i, _p, C.POINTER(_p)]),
     "ort_comm_destroy": (_i, [_p]),
+    "ort_comm_size": (_i, [_p]),
+    "ort_comm_rank": (_i, [_p]),
+    "ort_comm_wait": (_i, [_p]),
+    "ort_comm_wait_lag": (_i, [_p, _i]),
+    "ort_comm_synchronize": (_i, [_p]),
+    "ort_allgather_hits_packed_f64": (_i, [_p, _p, _l, _p]),
+    "ort_allgather_hits_packed_f32": (_i, [_p, _p, _l, _p]),
     "ort_allgather_hits_f64": (_i, [_p, _p, _p, _l, _p, _p]),
+    "ort_allgather_ragged_f64": (_i, [_p, _p, _l, _p, _l, _p]),
 }
 
 _lib: Optional[C.CDLL] = None

@@ -1,6 +1,5 @@
 """Consumers of the traced rays that the reference keeps next to the hot path (SURVEY §8f
-rows 3-4): Seidel sums, paraxial vignetting table, transverse-ray-error polynomials, the
-meridional fan `TSA` and its least-squares fit `SA`.
+rows 3-4): Seidel sums, the meridional fan `TSA` with its least-squares fit `SA`, and the caustic ray set.
 
 These are O(rows) host arithmetic per system in the reference too (no per-ray loop), so they
 stay host code here; every *trace* they need (paraxial, meridional fan) goes through the GPU
@@ -104,127 +103,53 @@ def aberrations(surfaces, system=None, lam: float = LAMBDA, dn=None) -> Aberrati
                       axial, lateral, petzval, medial, tangential, lam, int(np.sign(chief.y[-1])), system)
 
 
-class RayError:
-    """Transverse ray error polynomials (SeidelAberrations.jl:78-114).  kind: api.Tangential /
-    api.Sagittal / api.Skew."""
-
-    def __init__(self, kind, W: Aberration):
-        self.kind, self.W = kind, W
-        self.nu = W.system.marginal.nu[-1]
-        self.field_sign = W.field_sign
-
-    def _err(self, x, y, H):
-        if not math.hypot(x, y) <= 1.0:
-            raise DomainError("Domain: hypot(x, y) ≤ 1.0")
-        H = abs(H)
-        if not H <= 1.0:
-            raise DomainError("Domain: |H| ≤ 1.0")
-        H *= self.field_sign
-        W = self.W
-        ey = (4 * W.W040 * (x ** 2 * y + y ** 3) + W.W131 * H * (x ** 2 + 3 * y ** 2) + 2 * W.W222 * H ** 2 * y +
-              2 * W.W220 * H ** 2 * y + W.W311 * H ** 3 + 2 * W.W020 * y + W.W111 * H) * W.lam / self.nu
-        ex = (4 * W.W040 * (y ** 2 * x + x ** 3) + W.W131 * H * (2 * x * y) + 2 * W.W220 * H ** 2 * x +
-              2 * W.W020 * x) * W.lam / self.nu
-        return ex, ey
-
-    def __call__(self, *args):
-        if self.kind is api.Tangential:
-            return self._err(0, args[0], args[1])[1]
-        if self.kind is api.Sagittal:
-            return self._err(args[0], 0, args[1])[0]
-        return self._err(*args)
-
-
-@dataclass
-class Vignetting:                                                      # Types.jl:169-176
-    M: np.ndarray
-    FOV: np.ndarray
-    un: bool
-    limit: list
-    partial: list
-    full: list
-
-
-def vignetting(system, a=None) -> Vignetting:                          # Vignetting.jl:1-30
-    a = np.asarray(system.a if a is None else a, dtype=np.float64)
-    marginal, chief, stop = system.marginal, system.chief, system.stop
-    yb = np.abs(surface_ray(chief.y))
-    y = np.abs(surface_ray(marginal.y))
-    vig = np.empty((len(a), 5))
-    vig[:, 0] = a
-    vig[:, 1] = y
-    vig[:, 2] = y + yb
-    vig[:, 3] = yb
-    vig[:, 4] = yb - y
-    limited, unvig = vig[:, 1].copy(), vig[:, 2].copy()
-    half, full_v = vig[:, 3], vig[:, 4]
-    half[half < y] = np.nan
-    full_v[full_v < y] = np.nan
-    approx = np.isclose(a, unvig, rtol=math.sqrt(np.finfo(float).eps), atol=0.0)
-    a_unvig = (a >= unvig) | approx
-    un = bool(a_unvig.all())
-    with np.errstate(divide="ignore", invalid="ignore"):
-        min_un = min((a[i] - y[i]) / yb[i] for i in range(len(a)) if i != stop - 1)
-        min_half = np.min(a / yb)
-        min_full = np.min((a + y) / yb)
-    FOV = np.empty((3, 3))
-    for i, s in enumerate((min_un, min_half, min_full)):
-        ub = abs(chief.u[0] * s)
-        FOV[i] = (2 * math.degrees(math.atan(ub)), ub, abs(chief.y[-1] * s))
-    limit = [int(i) + 1 for i in np.nonzero((a < limited) & ~approx)[0]]
-    with np.errstate(invalid="ignore"):
-        full = [int(i) + 1 for i in np.nonzero(a <= vig[:, 4])[0]]
-    partial = [int(i) + 1 for i in np.nonzero(~a_unvig)[0] if int(i) + 1 not in full]
-    return Vignetting(vig, FOV, un, limit, partial, full)
+def _fan_spec(surfaces, system, engine):
+    """What ort_fan_f64 needs of the aimed real rays: y_m = real_marginal.y[1] (SeidelAberrations.jl:121),
+    XP_t = real_chief.z[end] - real_chief.z[end-1] (:120), and the prescription as the engine sees it."""
+    rm = trace_marginal_ray(surfaces, system, engine=engine)
+    rc = trace_chief_ray(surfaces, system, engine=engine)
+    pres, layout_mode, _ = api._as_layout(surfaces)
+    return rm, dict(system=0, layout_mode=layout_mode, y_marg=float(rm.y[0]), XP_t=float(rc.z[-1] - rc.z[-2])), pres
 
 
 def TSA(surfaces, system=None, k_rays: int = K_RAYS, engine=None):
-    """Transverse spherical aberration fan (SeidelAberrations.jl:116-137): k_rays - 1 meridional
-    rays traced in ONE launch of the device kernel."""
+    """Transverse spherical aberration fan (SeidelAberrations.jl:116-137): the k_rays meridional rays, their
+    extension to the exit pupil and to the paraxial focal plane in ONE launch of the device fan kernel
+    (`ort_fan_f64`); the aiming of the real marginal and chief rays is the reference's serial FD-Newton."""
     if isinstance(surfaces, System) and system is None:
         system = surfaces
         surfaces = system.layout
     pm = system.marginal
-    rm = trace_marginal_ray(surfaces, system, engine=engine)
-    rc = trace_chief_ray(surfaces, system, engine=engine)
-    XP_t = rc.z[-1] - rc.z[-2]
-    y_EP = api.linrange(rm.y[0] / k_rays, rm.y[0], k_rays)
-    y_XP = np.empty(k_rays)
-    eps = np.empty(k_rays)
-    BFD = pm.z[-1] - pm.z[-2]
-    t = surface_to_focus(BFD, rm, pm)
-    y_XP[-1] = rm.y[-2] + math.tan(rm.u[-1]) * XP_t
-    eps[-1] = transfer_real(rm, t)
-    rays = api.raytrace(surfaces, y_EP[:-1], 0.0, RealRay, engine=engine)
-    for i, ray in enumerate(rays):
-        tt = surface_to_focus(BFD, ray)
-        y_XP[i] = ray.y[-1] + math.tan(ray.u[-1]) * XP_t
-        eps[i] = transfer_real(ray, tt)
-    return y_XP, eps
+    _, spec, pres = _fan_spec(surfaces, system, engine)
+    spec["BFD"] = float(pm.z[-1] - pm.z[-2])                           # paraxial_BFD  :124
+    y_XP, eps = api._eng(engine).fan(pres, [spec], k_rays)
+    return y_XP[0], eps[0]
 
 
 def caustic_rays(surfaces, system=None, k_rays: int = K_RAYS, engine=None):
     """The ray set behind the reference's caustic plot (ext/MakieExtension.jl:353-398, the numbers only):
-    k_rays meridional rays y = range(y_marginal, y_marginal / k_rays, k_rays) at U = 0, traced in ONE
-    launch, each extended to the paraxial image plane (negative LSA, :373-377) or to the marginal focus
-    (:378-381).  Returns dict: y0 [k], z_surf / y_surf [k][rows-1] (polyline through the surfaces,
-    :386-387), zf (scalar), yf [k] (image-space end point, :391-392)."""
+    k_rays meridional rays y = range(y_marginal, y_marginal / k_rays, k_rays) at U = 0, each extended to the
+    paraxial image plane (negative LSA, :373-377) or to the marginal focus (:378-381): one launch of the fan
+    kernel for the end points, one of the meridional kernel for the polylines.  Returns dict: y0 [k],
+    z_surf / y_surf [k][rows-1] (polyline through the surfaces, :386-387), zf (scalar), yf [k] (image-space
+    end point, :391-392)."""
     if isinstance(surfaces, System) and system is None:
         system = surfaces
         surfaces = system.layout
     z = system.marginal.z
-    real_marginal = trace_marginal_ray(surfaces, system, engine=engine)
-    y = api.linrange(real_marginal.y[0], real_marginal.y[0] / k_rays, k_rays)       # :364
+    real_marginal, spec, pres = _fan_spec(surfaces, system, engine)
     paraxial_BFD = z[-1] - z[-2]                                                    # :365
     marginal_focus = real_marginal.z[-1]                                            # :366
     marginal_BFD = marginal_focus - z[-2]                                           # :368
     to_paraxial = abs(marginal_focus) < abs(z[-1])                                  # :373
     zf = z[-1] if to_paraxial else marginal_focus
-    BFD = paraxial_BFD if to_paraxial else marginal_BFD
+    spec["BFD"] = float(paraxial_BFD if to_paraxial else marginal_BFD)
+    eng = api._eng(engine)
+    _, yf = eng.fan(pres, [spec], k_rays, descending=True)                          # :377,381
+    y = api.linrange(real_marginal.y[0], real_marginal.y[0] / k_rays, k_rays)       # :364
     rays = api.raytrace(surfaces, y, 0.0, RealRay, engine=engine)
-    yf = np.array([transfer_real(r, surface_to_focus(BFD, r)) for r in rays])       # :377,381
     return {"y0": np.array([r.y[0] for r in rays]), "z_surf": np.array([r.z[:-1] for r in rays]),
-            "y_surf": np.array([r.y[1:] for r in rays]), "zf": float(zf), "yf": yf,
+            "y_surf": np.array([r.y[1:] for r in rays]), "zf": float(zf), "yf": yf[0],
             "to_paraxial_plane": bool(to_paraxial)}
 
 

@@ -876,21 +876,6 @@ def reverse_transfer(M, v, tau_p, tau, engine=None):                   # :13-17
     return out[0] if v.ndim == 1 else out
 
 
-def scale(lens: "Lens") -> "Lens":
-    """`scale!(M::Lens)`: powers from 1/m to 1/mm, in place (RayTracing.jl:9-12)."""
-    lens.M[:, 1] *= 1e-3
-    return lens
-
-
-def raypoints(*args):
-    """Plot points of the paraxial marginal and chief rays (RayPlot.jl:4-24): (z, [y0, y1, y2, ȳ, y3, y4])."""
-    marginal, chief = (args[0].marginal, args[0].chief) if len(args) == 1 else args
-    z = marginal.z
-    y1 = marginal.y if marginal.u[0] == 0 else np.concatenate([[0.0], marginal.y[1:]])
-    yb = np.concatenate([[chief.y[1] + chief.nu[0] * z[0]], chief.y[1:]])
-    return z, [np.zeros_like(z), y1, -y1, yb, yb + y1, yb - y1]
-
-
 def flatten(M):                                                        # :19-28
     M = _mat(M)
     f = -1.0 / M[1, 0]

@@ -40,6 +40,50 @@ def first_order_arrays(engine, mats: np.ndarray, a, hprime, dn=None, lam: float 
     return {k: np.array(arr[k]) for k in _FO_FIELDS}
 
 
+_AIM_OUT = np.dtype([(k, np.float64) for k in ("U", "y1", "y2", "y_EP", "hprime", "EP_t", "Ubar", "XP_t")] +
+                    [("iters", np.int32), ("ok", np.int32)])
+_AIM_IN = np.dtype([("system", np.int32), ("stop", np.int32), ("layout_fwd", np.int32), ("layout_rev", np.int32),
+                    ("H", np.float64), ("y_marg", np.float64), ("a_stop", np.float64), ("chief_y_end", np.float64),
+                    ("chief_u_end", np.float64), ("f", np.float64), ("atol", np.float64)])
+
+
+def aim_instances(mats: np.ndarray, a, hprime, fields: Sequence[float] = (0.0,), engine=None, fo=None) -> Dict[str, np.ndarray]:
+    """Real-ray aiming of every (instance, field) pair in one launch of the four-lane aiming kernel
+    (`ort_aim_f64`: trace_marginal_ray / trace_chief_ray / trace_edge_rays, src/RayTracing.jl:223-296,
+    src/PupilSampling.jl:67-103) for plain spherical prescriptions [ninst][rows][3].  Returns the fields of
+    ort_aim_out as [ninst][nfields] arrays (U, y1, y2, y_EP, hprime, EP_t, Ubar, XP_t, iters, ok)."""
+    eng = _eng(engine)
+    mats = np.ascontiguousarray(mats, dtype=np.float64)
+    ninst, rows, _ = mats.shape
+    fields = np.abs(np.asarray(fields, dtype=np.float64))
+    if not np.all(fields <= 1.0):
+        raise DomainError("Domain: |H| ≤ 1.0")
+    nf = len(fields)
+    a_arr = np.ascontiguousarray(np.broadcast_to(np.asarray(a, dtype=np.float64), (ninst, rows - 1)))
+    if fo is None:
+        fo = first_order_arrays(eng, mats, a_arr, hprime)
+    R, t, n = mats[:, :, 0], mats[:, :, 1].copy(), mats[:, :, 2]
+    t[:, 0] = np.where(np.isfinite(t[:, 0]), t[:, 0], 0.0)                      # Lens() mutation (Q19)
+    fwd = Prescription(R, t, n)
+    rev_R = -np.concatenate([np.full((ninst, 1), math.inf), R[:, :0:-1]], axis=1)   # RayTracing.jl:267-277
+    rev_t = t[:, ::-1].copy(); rev_t[:, 0] = fo["BFD"]
+    rev = Prescription(rev_R, rev_t, n[:, ::-1].copy(), np.zeros_like(rev_R))
+    na = ninst * nf
+    ain = (_capi.ort_aim_in * na)()
+    spec = np.frombuffer(ain, dtype=_AIM_IN, count=na)
+    inst = np.repeat(np.arange(ninst, dtype=np.int32), nf)
+    stop = fo["stop"][inst]
+    spec["system"] = inst; spec["stop"] = stop; spec["layout_fwd"] = 0; spec["layout_rev"] = 1
+    spec["H"] = np.tile(fields, ninst); spec["y_marg"] = fo["y_marg"][inst]
+    spec["a_stop"] = a_arr[inst, stop - 1]; spec["chief_y_end"] = fo["chief_y_end"][inst]
+    spec["chief_u_end"] = fo["chief_u_end"][inst]; spec["f"] = fo["f"][inst]; spec["atol"] = EPS
+    aout = (_capi.ort_aim_out * na)()
+    sf, sr = eng.system(fwd), eng.system(rev)                    # objects held across the call (HipEngine.system)
+    _capi.check(eng.ctx.lib.ort_aim_f64(eng.ctx.h, sf.h, sr.h, na, ain, aout, eng.base_flags))
+    arr = np.frombuffer(aout, dtype=_AIM_OUT, count=na)
+    return {k: np.array(arr[k]).reshape(ninst, nf) for k in _AIM_OUT.names}
+
+
 def tolerance_run(mats: np.ndarray, a, hprime, fields: Sequence[float] = (0.0,), k_rays: int = SPOT_RAYS,
                   dn=None, engine=None) -> Dict[str, np.ndarray]:
     """Seidel + spot-size Monte-Carlo over perturbed instances: for every instance the first-order
@@ -99,7 +143,7 @@ def tolerance_run(mats: np.ndarray, a, hprime, fields: Sequence[float] = (0.0,),
     _mark("upload forward + reversed tables")
     _capi.check(eng.ctx.lib.ort_aim_f64(eng.ctx.h, sf.h, sr.h, na, ain, aout, eng.base_flags))
     _mark("aim kernel call")
-    dt_out = np.dtype([(k, np.float64) for k in ("U", "y1", "y2", "y_EP", "hprime", "EP_t", "Ubar")] +
+    dt_out = np.dtype([(k, np.float64) for k in ("U", "y1", "y2", "y_EP", "hprime", "EP_t", "Ubar", "XP_t")] +
                       [("iters", np.int32), ("ok", np.int32)])
     aim = np.frombuffer(aout, dtype=dt_out, count=na)
     if not np.all(aim["ok"] == 1):
@@ -240,6 +284,123 @@ def full_trace_systems(mats: np.ndarray, a, hprime, fields: Sequence[float] = (0
     return first, out
 
 
+_BUNDLE = np.dtype([("system", np.int32), ("stop", np.int32), ("U", np.float64), ("V", np.float64), ("a_stop", np.float64),
+                    ("hprime", np.float64), ("ybar", np.float64), ("z0", np.float64), ("yaxis_off", np.int64),
+                    ("xaxis_off", np.int64)])
+
+
+class ImageHitsPlan:
+    """Everything `image_hits` does before its trace, kept on the device for repeated launches (bench.py's
+    multi-GPU step; a zoom / tolerance loop that re-traces): first-order solve and aiming of the instances this
+    shard touches, pupil axes, bundle descriptors.
+
+    shard = (rank, world) splits the work into contiguous rank-ordered slabs (dist.shard_bounds) of
+      unit="bundle": (instance, field) bundles — equal slabs whenever the bundle count divides;
+      unit="row":    pupil ROWS of the flattened (instance, field, row) list — slabs within one row of equal for
+                     any world size; a slab may start and end inside a bundle (<= 3 launches per trace).
+    Concatenating the ranks' hits in rank order reproduces the single-GPU order either way
+    (src/PupilSampling.jl:123,134-137: y outer, x inner, bundles in call order)."""
+
+    def __init__(self, mats: np.ndarray, a, hprime, fields: Sequence[float], k: int, engine=None, shard=None,
+                 dtype=np.float64, unit: str = "bundle"):
+        import torch
+        from . import dist as odist
+        eng = _eng(engine)
+        mats = np.ascontiguousarray(mats, dtype=np.float64)
+        ninst, rows, _ = mats.shape
+        fields = np.abs(np.asarray(fields, dtype=np.float64))
+        if not np.all(fields <= 1.0):
+            raise DomainError("Domain: |H| ≤ 1.0")
+        if unit not in ("bundle", "row"):
+            raise ValueError("unit must be 'bundle' or 'row'")
+        nf = len(fields)
+        a_arr = np.ascontiguousarray(np.broadcast_to(np.asarray(a, dtype=np.float64), (ninst, rows - 1)))
+        hp_arr = np.ascontiguousarray(np.broadcast_to(np.asarray(hprime, dtype=np.float64), (ninst,)))
+        na = ninst * nf
+        per = k if unit == "row" else 1                            # shard units per bundle
+        ulo, uhi = (0, na * per) if shard is None else odist.shard_bounds(na * per, shard[1])[shard[0]]
+        if uhi <= ulo:
+            raise ValueError("image_hits: this shard holds no work")
+        lo, hi = ulo // per, (uhi - 1) // per + 1                  # bundles touched
+        # a rank solves, aims and uploads only the instances its slab touches
+        i0, i1 = lo // nf, (hi - 1) // nf + 1
+        mats, a_arr, hp_arr = mats[i0:i1], a_arr[i0:i1], hp_arr[i0:i1]
+        lo, hi, ninst = lo - i0 * nf, hi - i0 * nf, i1 - i0
+        fo = first_order_arrays(eng, mats, a_arr, hp_arr)
+        aim_all = aim_instances(mats, a_arr, hp_arr, fields, engine=eng, fo=fo)
+        nb = hi - lo
+        inst = np.repeat(np.arange(ninst, dtype=np.int32), nf)[lo:hi]
+        aim = {key: v.reshape(-1)[lo:hi] for key, v in aim_all.items()}
+        if not np.all(aim["ok"] == 1):
+            raise RuntimeError("ray aiming did not converge")
+        stop = fo["stop"][inst]
+        a_stop = a_arr[inst, stop - 1]
+        R, t, n = mats[:, :, 0], mats[:, :, 1].copy(), mats[:, :, 2]
+        t[:, 0] = np.where(np.isfinite(t[:, 0]), t[:, 0], 0.0)
+        BFD = fo["BFD"]
+        ext = Prescription(np.concatenate([R, np.full((ninst, 1), math.inf)], axis=1),
+                           np.concatenate([t[:, :-1], BFD[:, None], np.zeros((ninst, 1))], axis=1),
+                           np.concatenate([n, np.ones((ninst, 1))], axis=1))
+        off = np.arange(nb, dtype=np.int64) * (2 * k)
+
+        def bundles(sel, row_start):
+            arr = (_capi.ort_bundle * len(sel))()
+            bd = np.frombuffer(arr, dtype=_BUNDLE, count=len(sel))
+            bd["system"] = inst[sel]; bd["stop"] = stop[sel]; bd["U"] = aim["U"][sel]; bd["V"] = 0.0
+            bd["a_stop"] = np.abs(a_stop[sel]); bd["hprime"] = aim["hprime"][sel]; bd["ybar"] = 0.0; bd["z0"] = 1.0
+            bd["yaxis_off"] = off[sel] + row_start; bd["xaxis_off"] = off[sel] + k
+            return arr
+
+        # segments: (bundle array, number of bundles, rows per bundle, first ray of the segment inside the shard)
+        segs, pos = [], 0
+        idx = np.arange(nb)
+        if unit == "bundle":
+            segs.append((bundles(idx, 0), nb, k, 0))
+        else:
+            base = (i0 * nf + lo) * k                              # first row unit of local bundle 0
+            for b0, nbs, rs, nrows in odist.row_segments(ulo - base, uhi - base, k):
+                segs.append((bundles(idx[b0:b0 + nbs], rs), nbs, nrows, pos))
+                pos += nbs * nrows * k
+        self.n_rays = (uhi - ulo) * (k if unit == "row" else k * k)
+        self.k, self.nb, self.eng, self.S = k, nb, eng, rows
+        self.units = (ulo, uhi)
+        # full square pupil: y from the aimed upper to lower edge ray, x symmetric about the axis
+        ends = np.ascontiguousarray(np.stack([aim["y1"], aim["y2"], -aim["y_EP"], aim["y_EP"]], axis=1))
+        dev = torch.device("cuda", eng.ctx.device)
+        self.dev = dev
+        d_ends = torch.from_numpy(ends).to(dev)
+        d_axes = torch.empty(nb * 2 * k, dtype=torch.float64, device=dev)
+        torch.cuda.synchronize(dev)
+        self.fl = eng.base_flags | _capi.ORT_DEVICE_PTRS
+        lib, h = eng.ctx.lib, eng.ctx.h
+        _capi.check(lib.ort_make_axes_f64(h, nb, k, k, d_ends.data_ptr(), d_axes.data_ptr(), self.fl))
+        eng.ctx.synchronize()
+        self.f32 = np.dtype(dtype) == np.float32
+        self.tdt = torch.float32 if self.f32 else torch.float64
+        self.d_axes = d_axes.to(torch.float32) if self.f32 else d_axes
+        torch.cuda.synchronize(dev)
+        self.sys = eng.system(ext)                                 # the object, held for the life of the plan
+        self.segs = segs
+
+    def new_hits(self):
+        """A packed [2, n_rays] slab (x row, y row): what ort_allgather_hits_packed_* sends as ONE message."""
+        import torch
+        return torch.empty((2, self.n_rays), dtype=self.tdt, device=self.dev)
+
+    def trace(self, hits, status=None) -> None:
+        """Launch the summary-mode trace(s) of this shard: x_f into hits[0], y_f into hits[1] (asynchronous on the
+        engine's stream); status: optional int32 [n_rays]."""
+        import ctypes as C
+        lib, h = self.eng.ctx.lib, self.eng.ctx.h
+        es = 4 if self.f32 else 8
+        for barr, nbs, ny, pos in self.segs:
+            out = _capi.ort_grid_out_f32() if self.f32 else _capi.ort_grid_out_f64()
+            out.xf, out.yf = hits[0].data_ptr() + pos * es, hits[1].data_ptr() + pos * es
+            out.status = None if status is None else status.data_ptr() + pos * 4
+            fn = lib.ort_trace_grid_f32 if self.f32 else lib.ort_trace_grid_f64
+            _capi.check(fn(h, self.sys.h, nbs, barr, self.d_axes.data_ptr(), self.d_axes.numel(), ny, self.k, C.byref(out), self.fl))
+
+
 def image_hits(mats: np.ndarray, a, hprime, fields: Sequence[float], k: int, engine=None, shard=None,
                dtype=np.float64):
     """Image-plane hit points of every (instance, field) bundle over the FULL square pupil k x k
@@ -249,93 +410,14 @@ def image_hits(mats: np.ndarray, a, hprime, fields: Sequence[float], k: int, eng
     [nb, k, k] (bit 16 = rejected by the stop filter), in bundle order (instance-major, field-minor).
 
     shard = (rank, world): trace only this rank's contiguous slab of bundles (dist.shard_bounds) —
-    concatenating the ranks' outputs in rank order (dist.allgather_hits / ort_allgather_hits_f64)
+    concatenating the ranks' outputs in rank order (dist.allgather_hits / ort_allgather_hits_packed_f64)
     reproduces the single-GPU result.  dtype = np.float32: Float32 trace and hits (BASELINE config 5:
-    8 B per ray out); solve, aiming and the pupil axes are still computed in Float64."""
+    8 B per ray out); solve, aiming and the pupil axes are still computed in Float64.
+    (ImageHitsPlan is the same thing split into a reusable setup and its launches, with row-level sharding.)"""
     import torch
-    from . import dist as odist
-    eng = _eng(engine)
-    mats = np.ascontiguousarray(mats, dtype=np.float64)
-    ninst, rows, _ = mats.shape
-    fields = np.abs(np.asarray(fields, dtype=np.float64))
-    if not np.all(fields <= 1.0):
-        raise DomainError("Domain: |H| ≤ 1.0")
-    nf = len(fields)
-    a_arr = np.ascontiguousarray(np.broadcast_to(np.asarray(a, dtype=np.float64), (ninst, rows - 1)))
-    hp_arr = np.ascontiguousarray(np.broadcast_to(np.asarray(hprime, dtype=np.float64), (ninst,)))
-    na = ninst * nf
-    lo, hi = (0, na) if shard is None else odist.shard_bounds(na, shard[1])[shard[0]]
-    if hi <= lo:
-        raise ValueError("image_hits: this shard holds no bundle")
-    # a rank solves, aims and uploads only the instances its slab of bundles touches
-    i0, i1 = lo // nf, (hi - 1) // nf + 1
-    mats, a_arr, hp_arr = mats[i0:i1], a_arr[i0:i1], hp_arr[i0:i1]
-    lo, hi, ninst = lo - i0 * nf, hi - i0 * nf, i1 - i0
-    fo = first_order_arrays(eng, mats, a_arr, hp_arr)
-    R, t, n = mats[:, :, 0], mats[:, :, 1].copy(), mats[:, :, 2]
-    t[:, 0] = np.where(np.isfinite(t[:, 0]), t[:, 0], 0.0)
-    BFD = fo["BFD"]
-    fwd = Prescription(R, t, n)
-    rev_R = -np.concatenate([np.full((ninst, 1), math.inf), R[:, :0:-1]], axis=1)
-    rev_t = t[:, ::-1].copy(); rev_t[:, 0] = BFD
-    rev = Prescription(rev_R, rev_t, n[:, ::-1].copy(), np.zeros_like(rev_R))
-    nb = hi - lo
-    inst = np.repeat(np.arange(ninst, dtype=np.int32), nf)[lo:hi]
-    Hs = np.tile(fields, ninst)[lo:hi]
-    stop = fo["stop"][inst]
-    ain = (_capi.ort_aim_in * nb)()
-    dt_in = np.dtype([("system", np.int32), ("stop", np.int32), ("layout_fwd", np.int32), ("layout_rev", np.int32),
-                      ("H", np.float64), ("y_marg", np.float64), ("a_stop", np.float64), ("chief_y_end", np.float64),
-                      ("chief_u_end", np.float64), ("f", np.float64), ("atol", np.float64)])
-    spec = np.frombuffer(ain, dtype=dt_in, count=nb)
-    a_stop = a_arr[inst, stop - 1]
-    spec["system"] = inst; spec["stop"] = stop; spec["layout_fwd"] = 0; spec["layout_rev"] = 1; spec["H"] = Hs
-    spec["y_marg"] = fo["y_marg"][inst]; spec["a_stop"] = a_stop; spec["chief_y_end"] = fo["chief_y_end"][inst]
-    spec["chief_u_end"] = fo["chief_u_end"][inst]; spec["f"] = fo["f"][inst]; spec["atol"] = EPS
-    aout = (_capi.ort_aim_out * nb)()
-    sf, sr = eng.system(fwd), eng.system(rev)                    # objects held across the call (HipEngine.system)
-    _capi.check(eng.ctx.lib.ort_aim_f64(eng.ctx.h, sf.h, sr.h, nb, ain, aout, eng.base_flags))
-    dt_out = np.dtype([(kk, np.float64) for kk in ("U", "y1", "y2", "y_EP", "hprime", "EP_t", "Ubar")] +
-                      [("iters", np.int32), ("ok", np.int32)])
-    aim = np.frombuffer(aout, dtype=dt_out, count=nb)
-    if not np.all(aim["ok"] == 1):
-        raise RuntimeError("ray aiming did not converge")
-    ext = Prescription(np.concatenate([R, np.full((ninst, 1), math.inf)], axis=1),
-                       np.concatenate([t[:, :-1], BFD[:, None], np.zeros((ninst, 1))], axis=1),
-                       np.concatenate([n, np.ones((ninst, 1))], axis=1))
-    barr = (_capi.ort_bundle * nb)()
-    dt_b = np.dtype([("system", np.int32), ("stop", np.int32), ("U", np.float64), ("V", np.float64), ("a_stop", np.float64),
-                     ("hprime", np.float64), ("ybar", np.float64), ("z0", np.float64), ("yaxis_off", np.int64),
-                     ("xaxis_off", np.int64)])
-    bd = np.frombuffer(barr, dtype=dt_b, count=nb)
-    off = np.arange(nb, dtype=np.int64) * (2 * k)
-    bd["system"] = inst; bd["stop"] = stop; bd["U"] = aim["U"]; bd["V"] = 0.0; bd["a_stop"] = np.abs(a_stop)
-    bd["hprime"] = aim["hprime"]; bd["ybar"] = 0.0; bd["z0"] = 1.0; bd["yaxis_off"] = off; bd["xaxis_off"] = off + k
-    # full square pupil: y from the aimed upper to lower edge ray, x symmetric about the axis
-    ends = np.ascontiguousarray(np.stack([aim["y1"], aim["y2"], -aim["y_EP"], aim["y_EP"]], axis=1))
-    dev = torch.device("cuda", eng.ctx.device)
-    d_ends = torch.from_numpy(ends).to(dev)
-    d_axes = torch.empty(nb * 2 * k, dtype=torch.float64, device=dev)
-    f32 = np.dtype(dtype) == np.float32
-    tdt = torch.float32 if f32 else torch.float64
-    xf = torch.empty((nb, k, k), dtype=tdt, device=dev); yf = torch.empty_like(xf)
-    st = torch.empty((nb, k, k), dtype=torch.int32, device=dev)
-    torch.cuda.synchronize(dev)
-    fl = eng.base_flags | _capi.ORT_DEVICE_PTRS
-    lib, h = eng.ctx.lib, eng.ctx.h
-    _capi.check(lib.ort_make_axes_f64(h, nb, k, k, d_ends.data_ptr(), d_axes.data_ptr(), fl))
-    import ctypes as C
-    if f32:
-        eng.ctx.synchronize()
-        d_axes = d_axes.to(torch.float32)
-        torch.cuda.synchronize(dev)
-        out = _capi.ort_grid_out_f32()
-        trace = lib.ort_trace_grid_f32
-    else:
-        out = _capi.ort_grid_out_f64()
-        trace = lib.ort_trace_grid_f64
-    out.xf, out.yf, out.status = xf.data_ptr(), yf.data_ptr(), st.data_ptr()
-    se = eng.system(ext)
-    _capi.check(trace(h, se.h, nb, barr, d_axes.data_ptr(), d_axes.numel(), k, k, C.byref(out), fl))
-    eng.ctx.synchronize()
-    return xf, yf, st
+    plan = ImageHitsPlan(mats, a, hprime, fields, k, engine=engine, shard=shard, dtype=dtype)
+    hits = plan.new_hits()
+    st = torch.empty(plan.n_rays, dtype=torch.int32, device=plan.dev)
+    plan.trace(hits, st)
+    plan.eng.ctx.synchronize()
+    return hits[0].view(plan.nb, k, k), hits[1].view(plan.nb, k, k), st.view(plan.nb, k, k)

@@ -452,9 +452,10 @@ __device__ __forceinline__ void surface_step_fast_poly(Ray<T>& r, const SurfRec<
 // (the root that tends to -z0/k2 as c -> 0: the vertex-side sheet the reference picks with
 // sign(R), PupilSampling.jl:7).  The unnormalised normal is (-c x, -c y, 1 - c (1+K) z); on
 // a sphere it is already unit and k.n equals the square root above.
-// REFR: the row refracts (eta != 1).  TIR: |eta| > 1, total internal reflection is possible
-// and the reference's "k untouched" rule (Q1) needs a select; for |eta| <= 1 the radicand
-// 1 - eta^2 (1 - cos^2 I) >= 1 - eta^2 >= 0 and no select is emitted.
+// REFR: the row refracts (eta != 1).  TIR: the row is NOT in 0 < eta <= 1 — eta > 1, where total internal
+// reflection is possible and the reference's "k untouched" rule (Q1) needs a select, or a mirror's eta < 0; for
+// 0 < eta <= 1 the radicand 1 - eta^2 (1 - cos^2 I) >= 1 - eta^2 >= 0, no select is emitted, and the refracted
+// direction cannot point backward.
 template <typename T> struct ConicHit { T cn, n2, cosi, cos2; };   // n = (-cn x, -cn y, n2), cos I = k.n
 
 // Transfer to the row and intersection.  Returns false when the row does not refract (flat, eta == 1).
@@ -539,7 +540,9 @@ __device__ __forceinline__ void surface_step_fast_conic(Ray<T>& r, const SurfRec
     if (!fast_conic_hit<T, KIND, REFR>(r, s, h)) return;
     if (KIND == KIND_SPHERE) odd = odd || t_class(h.n2, kClassNegative);    // beyond the equator: 1 - c z < 0
     fast_snell<T, TIR>(r, s, h);
-    if (KIND != KIND_FLAT) odd = odd || t_class(r.k2, kClassNegative);
+    // backward direction: impossible for 0 < eta <= 1 (gam >= 0 and the normal's axial component is positive once
+    // far-cap hits are out), so only the rows of the TIR class (eta > 1, or a mirror's eta < 0) are tested
+    if (KIND != KIND_FLAT && TIR) odd = odd || t_class(r.k2, kClassNegative);
 }
 
 // MATH_FAST, strongly curved sphere (|R| <= kCentreFormMaxR) in CENTRE form: with Q = P - C
@@ -602,7 +605,7 @@ __device__ __forceinline__ void surface_step_fast_sphere_c(Ray<T>& r, const Surf
     fast_sphere_c_coeffs<T>(s, sq, disc, D2, gam);
     odd = odd || t_class(Qz, s.farmask);
     fast_sphere_c_apply<T, TIR>(r, s, Qz, D2, gam);
-    odd = odd || t_class(r.k2, kClassNegative);
+    if (TIR) odd = odd || t_class(r.k2, kClassNegative);        // see surface_step_fast_conic
 }
 
 // All N rays of a lane through one surface.  `cls` packs the row's wave-uniform class bits

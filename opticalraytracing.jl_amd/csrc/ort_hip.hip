@@ -164,7 +164,7 @@ void build_records(int nsys, int rows, int ncoef, const double* R, const double*
             r.e2c2 = r.eta2 * (r.invR * r.invR);
             r.ec = r.eta * std::fabs(r.invR);
             r.cls = (r.finite ? CLS_FINITE : 0) | (nc > 0 ? CLS_HASP : 0) | ((r.eta != T(1)) ? CLS_REFR : 0) |
-                    (!(std::fabs(r.eta) <= T(1)) ? CLS_TIR : 0) |
+                    (!(r.eta > T(0) && r.eta <= T(1)) ? CLS_TIR : 0) |
                     (kind << CLS_KIND_SHIFT);
             out[(size_t)s * S + i] = r;
         }
@@ -1042,7 +1042,38 @@ int ort_aim_f64(ort_ctx* ctx, const ort_system* fwd, const ort_system* rev, int 
     return ORT_OK;
 }
 
-// --------------------------------------------------------------------------------------
+int ort_fan_f64(ort_ctx* ctx, const ort_system* sys, int n, const ort_fan_in* in, int k_rays, int descending,
+                double* y_XP, double* eps, unsigned flags)
+{
+    static_assert(sizeof(ort_fan_in) == sizeof(FanIn), "ABI struct mismatch");
+    int rc = check_ctx(ctx); if (rc) return rc;
+    rc = check_sys(ctx, sys); if (rc) return rc;
+    if (n < 0 || !in || k_rays < 1 || !y_XP || !eps) return fail(ORT_EINVAL, "bad fan arguments");
+    if (n == 0) return ORT_OK;
+    const bool devp = flags & ORT_DEVICE_PTRS;
+    const int64_t total = (int64_t)n * k_rays;
+    if ((total + kBlock - 1) / kBlock > 0x7fffffffLL) return fail(ORT_EINVAL, "launch too large");
+    if (!devp)
+        for (int i = 0; i < n; ++i)
+            if (in[i].system < 0 || in[i].system >= sys->nsys) return fail(ORT_EINVAL, "fan %d: system %d out of range", i, in[i].system);
+    const FanIn* din = reinterpret_cast<const FanIn*>(in);
+    double *dy = y_XP, *de = eps;
+    if (!devp) {
+        rc = to_device<FanIn>(ctx, SL_IN0, reinterpret_cast<const FanIn*>(in), (size_t)n, &din); if (rc) return rc;
+        rc = dev_out<double>(ctx, SL_OUT0, (size_t)total, &dy); if (rc) return rc;
+        rc = dev_out<double>(ctx, SL_OUT1, (size_t)total, &de); if (rc) return rc;
+    }
+    hipLaunchKernelGGL(k_fan, dim3((unsigned)((total + kBlock - 1) / kBlock)), dim3(kBlock), 0, ctx->stream, n, k_rays, descending ? 1 : 0,
+                       din, sys->mer, sys->coef64, sys->d_tlast, sys->rows - 1, sys->ncoef, dy, de);
+    HIP_TRY(hipGetLastError());
+    if (!devp) {
+        rc = from_device<double>(ctx, y_XP, dy, (size_t)total); if (rc) return rc;
+        rc = from_device<double>(ctx, eps, de, (size_t)total); if (rc) return rc;
+        HIP_TRY(hipStreamSynchronize(ctx->stream));
+    }
+    return ORT_OK;
+}
+
 static int first_order_impl(ort_ctx* ctx, int nsys, int rows, const double* R, const double* t, const double* n,
                             const double* a, const double* dn, const double* hprime, double lambda,
                             ort_first_order* out, double* surf, double* inc, unsigned flags)
@@ -1204,8 +1235,10 @@ int ort_abcd_reverse_transfer_f64(ort_ctx* ctx, const double* M, int64_t nv, con
     return abcd_apply(ctx, M, nv, v, tau, tau_p, out, flags, 1);
 }
 
+}  // extern "C"
+
 // --------------------------------------------------------------------------------------
-// RCCL, loaded lazily.  Only the five entry points the reassembly needs.
+// RCCL, loaded lazily.  Only the entry points the reassembly needs.
 struct Id128 { char b[ORT_UNIQUE_ID_BYTES]; };   // ncclUniqueId, passed by value
 namespace {
 struct Rccl {
@@ -1213,12 +1246,14 @@ struct Rccl {
     int (*GetUniqueId)(void*) = nullptr;
     int (*CommInitRank)(void**, int, Id128, int) = nullptr;
     int (*AllGather)(const void*, void*, size_t, int, void*, hipStream_t) = nullptr;
+    int (*Broadcast)(const void*, void*, size_t, int, int, void*, hipStream_t) = nullptr;
     int (*CommDestroy)(void*) = nullptr;
     const char* (*GetErrorString)(int) = nullptr;
     int (*GroupStart)() = nullptr;
     int (*GroupEnd)() = nullptr;
 };
 Rccl g_rccl;
+constexpr int kNcclInt64 = 4, kNcclFloat32 = 7, kNcclFloat64 = 8;
 
 int rccl_load()
 {
@@ -1230,11 +1265,13 @@ int rccl_load()
     g_rccl.GetUniqueId = (int (*)(void*))dlsym(h, "ncclGetUniqueId");
     g_rccl.CommInitRank = (int (*)(void**, int, Id128, int))dlsym(h, "ncclCommInitRank");
     g_rccl.AllGather = (int (*)(const void*, void*, size_t, int, void*, hipStream_t))dlsym(h, "ncclAllGather");
+    g_rccl.Broadcast = (int (*)(const void*, void*, size_t, int, int, void*, hipStream_t))dlsym(h, "ncclBroadcast");
     g_rccl.CommDestroy = (int (*)(void*))dlsym(h, "ncclCommDestroy");
     g_rccl.GetErrorString = (const char* (*)(int))dlsym(h, "ncclGetErrorString");
     g_rccl.GroupStart = (int (*)())dlsym(h, "ncclGroupStart");
     g_rccl.GroupEnd = (int (*)())dlsym(h, "ncclGroupEnd");
-    if (!g_rccl.GetUniqueId || !g_rccl.CommInitRank || !g_rccl.AllGather || !g_rccl.CommDestroy || !g_rccl.GroupStart || !g_rccl.GroupEnd)
+    if (!g_rccl.GetUniqueId || !g_rccl.CommInitRank || !g_rccl.AllGather || !g_rccl.Broadcast || !g_rccl.CommDestroy ||
+        !g_rccl.GroupStart || !g_rccl.GroupEnd)
         return fail(ORT_EHIP, "librccl.so lacks a required symbol");
     g_rccl.h = h;
     return ORT_OK;
@@ -1247,11 +1284,38 @@ int rccl_load()
     } while (0)
 }  // namespace
 
+// The collectives run on the communicator's OWN stream, ordered after the work already queued on the context's
+// stream (an event), so that the reassembly of one shard overlaps the trace of the next; ort_comm_wait orders the
+// context's stream after them again, ort_comm_synchronize blocks the host.
 struct ort_comm {
     ort_ctx* ctx = nullptr;
     void* comm = nullptr;
     int nranks = 0, rank = 0;
+    hipStream_t stream = nullptr;
+    hipEvent_t ev_in = nullptr;
+    static constexpr int kRing = 8;
+    hipEvent_t ev_ring[kRing] = {};  // completion of the last kRing collectives, oldest overwritten
+    unsigned long long issued = 0;   // collectives issued so far
+    int64_t* d_counts = nullptr;     // [nranks + 1] device scratch of the ragged gather (own count at [nranks])
+    int64_t* h_counts = nullptr;     // page-locked mirror
 };
+
+namespace {
+int comm_begin(ort_comm* c)          // comm stream waits for everything queued on the context's stream so far
+{
+    HIP_TRY(hipEventRecord(c->ev_in, c->ctx->stream));
+    HIP_TRY(hipStreamWaitEvent(c->stream, c->ev_in, 0));
+    return ORT_OK;
+}
+int comm_end(ort_comm* c)
+{
+    HIP_TRY(hipEventRecord(c->ev_ring[c->issued % ort_comm::kRing], c->stream));
+    ++c->issued;
+    return ORT_OK;
+}
+}  // namespace
+
+extern "C" {
 
 int ort_comm_unique_id(void* id128)
 {
@@ -1272,8 +1336,14 @@ int ort_comm_create(ort_ctx* ctx, int nranks, int rank, const void* id128, ort_c
     ort_comm* c = new (std::nothrow) ort_comm();
     if (!c) return fail(ORT_ENOMEM, "out of host memory");
     c->ctx = ctx; c->nranks = nranks; c->rank = rank;
+    hipError_t e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&c->ev_in, hipEventDisableTiming);
+    for (int i = 0; i < ort_comm::kRing && e == hipSuccess; ++i) e = hipEventCreateWithFlags(&c->ev_ring[i], hipEventDisableTiming);
+    if (e == hipSuccess) e = hipMalloc((void**)&c->d_counts, (size_t)(nranks + 1) * sizeof(int64_t));
+    if (e == hipSuccess) e = hipHostMalloc((void**)&c->h_counts, (size_t)(nranks + 1) * sizeof(int64_t), hipHostMallocDefault);
+    if (e != hipSuccess) { ort_comm_destroy(c); return fail(ORT_EHIP, "communicator resources: %s", hipGetErrorString(e)); }
     int r = g_rccl.CommInitRank(&c->comm, nranks, id, rank);
-    if (r != 0) { delete c; return fail(ORT_EHIP, "ncclCommInitRank failed: %s", g_rccl.GetErrorString ? g_rccl.GetErrorString(r) : "?"); }
+    if (r != 0) { c->comm = nullptr; ort_comm_destroy(c); return fail(ORT_EHIP, "ncclCommInitRank failed: %s", g_rccl.GetErrorString ? g_rccl.GetErrorString(r) : "?"); }
     *out = c;
     return ORT_OK;
 }
@@ -1281,27 +1351,106 @@ int ort_comm_create(ort_ctx* ctx, int nranks, int rank, const void* id128, ort_c
 int ort_comm_destroy(ort_comm* comm)
 {
     if (!comm) return ORT_OK;
-    if (comm->comm && g_rccl.CommDestroy) {
-        hipError_t e = hipSetDevice(comm->ctx->device); (void)e;
-        e = hipStreamSynchronize(comm->ctx->stream); (void)e;
-        g_rccl.CommDestroy(comm->comm);
-    }
+    hipError_t e = hipSetDevice(comm->ctx->device); (void)e;
+    if (comm->stream) { e = hipStreamSynchronize(comm->stream); (void)e; }
+    e = hipStreamSynchronize(comm->ctx->stream); (void)e;
+    if (comm->comm && g_rccl.CommDestroy) g_rccl.CommDestroy(comm->comm);
+    if (comm->d_counts) { e = hipFree(comm->d_counts); (void)e; }
+    if (comm->h_counts) { e = hipHostFree(comm->h_counts); (void)e; }
+    if (comm->ev_in) { e = hipEventDestroy(comm->ev_in); (void)e; }
+    for (hipEvent_t ev : comm->ev_ring) if (ev) { e = hipEventDestroy(ev); (void)e; }
+    if (comm->stream) { e = hipStreamDestroy(comm->stream); (void)e; }
     delete comm;
     return ORT_OK;
 }
 
+int ort_comm_size(const ort_comm* comm) { return comm ? comm->nranks : fail(ORT_EINVAL, "null communicator"); }
+int ort_comm_rank(const ort_comm* comm) { return comm ? comm->rank : fail(ORT_EINVAL, "null communicator"); }
+
+int ort_comm_wait_lag(ort_comm* comm, int lag)
+{
+    if (!comm) return fail(ORT_EINVAL, "null communicator");
+    if (lag < 0 || lag >= ort_comm::kRing) return fail(ORT_EINVAL, "lag %d outside 0..%d", lag, ort_comm::kRing - 1);
+    int rc = check_ctx(comm->ctx); if (rc) return rc;
+    if (comm->issued < (unsigned long long)lag + 1) return ORT_OK;          // nothing that old was issued
+    HIP_TRY(hipStreamWaitEvent(comm->ctx->stream, comm->ev_ring[(comm->issued - 1 - lag) % ort_comm::kRing], 0));
+    return ORT_OK;
+}
+
+int ort_comm_wait(ort_comm* comm) { return ort_comm_wait_lag(comm, 0); }
+
+int ort_comm_synchronize(ort_comm* comm)
+{
+    if (!comm) return fail(ORT_EINVAL, "null communicator");
+    int rc = check_ctx(comm->ctx); if (rc) return rc;
+    HIP_TRY(hipStreamSynchronize(comm->stream));
+    return ORT_OK;
+}
+
+// ONE ncclAllGather of the packed slab [2][count] (x at +0, y at +count) -> [nranks][2][count].
+int ort_allgather_hits_packed_f64(ort_comm* comm, const double* hits, int64_t count, double* gathered)
+{
+    if (!comm || !hits || !gathered || count < 0) return fail(ORT_EINVAL, "bad all-gather arguments");
+    int rc = check_ctx(comm->ctx); if (rc) return rc;
+    if (count == 0) return ORT_OK;
+    rc = comm_begin(comm); if (rc) return rc;
+    RCCL_TRY(g_rccl.AllGather(hits, gathered, (size_t)(2 * count), kNcclFloat64, comm->comm, comm->stream));
+    return comm_end(comm);
+}
+
+int ort_allgather_hits_packed_f32(ort_comm* comm, const float* hits, int64_t count, float* gathered)
+{
+    if (!comm || !hits || !gathered || count < 0) return fail(ORT_EINVAL, "bad all-gather arguments");
+    int rc = check_ctx(comm->ctx); if (rc) return rc;
+    if (count == 0) return ORT_OK;
+    rc = comm_begin(comm); if (rc) return rc;
+    RCCL_TRY(g_rccl.AllGather(hits, gathered, (size_t)(2 * count), kNcclFloat32, comm->comm, comm->stream));
+    return comm_end(comm);
+}
+
+// Separate x / y arrays.  When they are the two halves of one packed slab (yf == xf + count, gy == gx + nranks*count
+// is NOT that layout) the call is the packed one; otherwise the two slabs go out as ONE fused RCCL launch.
 int ort_allgather_hits_f64(ort_comm* comm, const double* xf, const double* yf, int64_t count, double* gx, double* gy)
 {
     if (!comm || !xf || !yf || !gx || !gy || count < 0) return fail(ORT_EINVAL, "bad all-gather arguments");
     int rc = check_ctx(comm->ctx); if (rc) return rc;
     if (count == 0) return ORT_OK;
-    const int ncclFloat64 = 8;
-    RCCL_TRY(g_rccl.GroupStart());           // x and y slabs fused into one RCCL launch
-    int r1 = g_rccl.AllGather(xf, gx, (size_t)count, ncclFloat64, comm->comm, comm->ctx->stream);
-    int r2 = r1 ? 0 : g_rccl.AllGather(yf, gy, (size_t)count, ncclFloat64, comm->comm, comm->ctx->stream);
+    rc = comm_begin(comm); if (rc) return rc;
+    RCCL_TRY(g_rccl.GroupStart());
+    int r1 = g_rccl.AllGather(xf, gx, (size_t)count, kNcclFloat64, comm->comm, comm->stream);
+    int r2 = r1 ? 0 : g_rccl.AllGather(yf, gy, (size_t)count, kNcclFloat64, comm->comm, comm->stream);
     int r3 = g_rccl.GroupEnd();              // always closed: an open group would swallow every later collective
     RCCL_TRY(r1); RCCL_TRY(r2); RCCL_TRY(r3);
-    return ORT_OK;
+    return comm_end(comm);
+}
+
+// Ragged reassembly (compacted survivors): counts first (one 8-byte all-gather, read by the host), then every
+// rank's slab lands at its exclusive offset — a group of ncclBroadcast, one per rank, fused into one launch.
+int ort_allgather_ragged_f64(ort_comm* comm, const double* values, int64_t count, double* gathered, int64_t capacity,
+                             int64_t* counts)
+{
+    if (!comm || count < 0 || (count > 0 && !values) || !gathered || capacity < 0) return fail(ORT_EINVAL, "bad ragged all-gather arguments");
+    int rc = check_ctx(comm->ctx); if (rc) return rc;
+    const int nr = comm->nranks;
+    rc = comm_begin(comm); if (rc) return rc;
+    comm->h_counts[nr] = count;
+    HIP_TRY(hipMemcpyAsync(comm->d_counts + nr, comm->h_counts + nr, sizeof(int64_t), hipMemcpyHostToDevice, comm->stream));
+    RCCL_TRY(g_rccl.AllGather(comm->d_counts + nr, comm->d_counts, 1, kNcclInt64, comm->comm, comm->stream));
+    HIP_TRY(hipMemcpyAsync(comm->h_counts, comm->d_counts, (size_t)nr * sizeof(int64_t), hipMemcpyDeviceToHost, comm->stream));
+    HIP_TRY(hipStreamSynchronize(comm->stream));
+    int64_t total = 0;
+    for (int r = 0; r < nr; ++r) { if (counts) counts[r] = comm->h_counts[r]; total += comm->h_counts[r]; }
+    if (total > capacity) return fail(ORT_EINVAL, "ragged all-gather: %lld entries exceed the capacity %lld", (long long)total, (long long)capacity);
+    RCCL_TRY(g_rccl.GroupStart());
+    int bad = 0; int64_t off = 0;
+    for (int r = 0; r < nr && !bad; ++r) {
+        const int64_t c = comm->h_counts[r];
+        if (c > 0) bad = g_rccl.Broadcast(values, gathered + off, (size_t)c, kNcclFloat64, r, comm->comm, comm->stream);
+        off += c;
+    }
+    int r3 = g_rccl.GroupEnd();
+    RCCL_TRY(bad); RCCL_TRY(r3);
+    return comm_end(comm);
 }
 
 }  // extern "C"

@@ -167,8 +167,13 @@ __global__ __launch_bounds__(kBlock, (HIST && SUMM) ? ORT_MIN_WAVES - 1 : ORT_MI
     __shared__ unsigned s_bid;
     if (FT == FT_FULL) {
         if (tid == 0) {
-            const unsigned long long tk = atomicAdd(p.ft_ticket, 1ull) - p.ft_ticket_base;
-            s_bid = tk < gridDim.x ? (unsigned)tk : gridDim.x - 1;   // (never out of the grid, whatever the host passed)
+            unsigned long long tk = atomicAdd(p.ft_ticket, 1ull) - p.ft_ticket_base;
+            if (tk >= gridDim.x) tk = gridDim.x - 1;                 // (never out of the grid, whatever the host passed)
+            // tickets walk the bundles round-robin (ticket = tile * nb + bundle): the tiles in flight at any time
+            // are spread over all the bundles' chains, so each look-back chain below is nb times shorter; a tile's
+            // predecessors in its bundle still hold lower tickets
+            const unsigned nbn = gridDim.x / (unsigned)p.tiles_per_bundle;
+            s_bid = (unsigned)(tk % nbn) * (unsigned)p.tiles_per_bundle + (unsigned)(tk / nbn);
         }
         __syncthreads();
     }
@@ -430,26 +435,35 @@ __global__ __launch_bounds__(kBlock, (HIST && SUMM) ? ORT_MIN_WAVES - 1 : ORT_MI
                 }
                 long long excl = 0;
                 int hi = tile - 1;                               // next predecessor to look at
+                constexpr int kLook = 4;                         // predecessors per lane and round: windows of 256 tiles
                 while (hi >= 0) {
-                    const int t = hi - lane;                     // lane l looks at tile hi - l
-                    unsigned long long wd = 2ull << 62 | ep;     // beyond the first tile: an inclusive prefix of 0
-                    if (t >= 0) {
-                        // every tile with a lower ticket is running or done, so this wait ends; the cap is a guard
-                        // against a host-side bookkeeping error only (the wave then leaves with a zero prefix)
-                        for (int spin = 0; spin < (1 << 24); ++spin) {
-                            wd = __hip_atomic_load(stw + t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                            if ((wd >> 62) != 0 && (wd & (0x3fffffffull << 32)) == ep) break;
-                            wd = 2ull << 62 | ep;
-                            __builtin_amdgcn_s_sleep(1);
+                    // lane l looks at tiles hi - kLook l - j, j = 0 .. kLook-1 (nearest first); every tile with a lower
+                    // ticket is running or done, so the waits end; the cap is a guard against a host-side bookkeeping
+                    // error only (the wave then leaves with a zero prefix)
+                    long long part = 0;                          // sum of this lane's words up to its first inclusive one
+                    bool found = false;
+#pragma unroll
+                    for (int j = 0; j < kLook; ++j) {
+                        const int t = hi - kLook * lane - j;
+                        unsigned long long wd = 2ull << 62 | ep; // beyond the first tile: an inclusive prefix of 0
+                        if (t >= 0) {
+                            for (int spin = 0; spin < (1 << 22); ++spin) {
+                                wd = __hip_atomic_load(stw + t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                                if ((wd >> 62) != 0 && (wd & (0x3fffffffull << 32)) == ep) break;
+                                wd = 2ull << 62 | ep;
+                                __builtin_amdgcn_s_sleep(1);
+                            }
                         }
+                        if (!found) part += (long long)(wd & 0xffffffffull);
+                        found = found || ((wd >> 62) == 2);
                     }
-                    const unsigned long long incl = __ballot((wd >> 62) == 2);
-                    const int first = incl ? __builtin_ctzll(incl) : 64;       // nearest tile holding an inclusive prefix
-                    long long v = (lane <= first) ? (long long)(wd & 0xffffffffull) : 0;
+                    const unsigned long long incl = __ballot(found);
+                    const int first = incl ? __builtin_ctzll(incl) : 64;       // nearest lane holding an inclusive prefix
+                    long long v = (lane <= first) ? part : 0;
                     for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off);
                     excl += __shfl(v, 0);
                     if (incl) break;
-                    hi -= 64;
+                    hi -= 64 * kLook;
                 }
                 if (lane == 0) {
                     if (tile != 0)
@@ -751,23 +765,26 @@ struct AimIn {
 };
 struct AimOut {
     double U, y1, y2, y_EP, hprime, EP_t, Ubar;
+    double XP_t;           // real_chief.z[end] - real_chief.z[end-1]   (RayTracing.jl:294; TSA, SeidelAberrations.jl:120)
     int32_t iters;         // Newton iterations spent (all loops)
     int32_t ok;            // 1 = every loop converged
 };
 
-struct MerEnd { double y_stop, y_last, U_last, z_last, z_prev; };
+struct MerEnd { double y_stop, y_last, U_last, z_last, z_prev, y_first, s_last; };
 
 __device__ inline MerEnd mer_trace_to(const MerSurf* __restrict__ surf, const double* __restrict__ coefs, int S, int ncoef,
                                       int layout_mode, double t_last, double y, double U, int stop_idx)
 {
     MerEnd e;
-    e.y_stop = __builtin_nan("");
+    e.y_stop = __builtin_nan(""); e.y_first = y;
     double sprev = 0.0, z = 0.0, zp = 0.0;
     for (int i = 0; i < S; ++i) {
         const double tsi = mer_step(surf[i], coefs ? coefs + (int64_t)(i + 1) * ncoef : nullptr, layout_mode, y, U, sprev);
         zp = z; z = (i == 0) ? tsi : z + tsi;                    // cumsum(ts)  (Types.jl:61-63)
         if (i + 1 == stop_idx) e.y_stop = y;                     // ray.y[begin+stop]
+        if (i == 0) e.y_first = y;                               // ray.y[2]
     }
+    e.s_last = sprev;                                            // sag at the last surface
     zp = z; z = z + (t_last - sprev);                            // last ts entry
     e.y_last = y; e.U_last = U; e.z_last = z; e.z_prev = zp;
     return e;
@@ -786,7 +803,7 @@ __device__ __forceinline__ void pair_newton(F&& trace, double& v, double target,
     const bool pert = role & 1;
     bool conv = false;
     int it = 0;
-    e.y_stop = e.y_last = e.U_last = e.z_last = e.z_prev = 0.0;
+    e.y_stop = e.y_last = e.U_last = e.z_last = e.z_prev = e.y_first = e.s_last = 0.0;
     while (true) {
         if (!conv) e = trace(pert ? v + eps : v);
         const double L = e.y_stop - target;
@@ -835,6 +852,9 @@ __global__ __launch_bounds__(64) void k_aim(int n, const AimIn* __restrict__ in,
     const double ub1 = -__shfl(e.U_last, 0, 4);                  // ū[1] = -reverse(ray.u)[1]          :289
     const double z2 = __shfl(e.z_last, 0, 4) - __shfl(e.z_prev, 0, 4);   // z[2] = ray.z[end] - ray.z[end-1]   :292
     const double EP_t = -yb2 / ::tan(ub1) + z2;                  // :293
+    // z[end] - z[end-1] = -ȳ[end-1] / tan(ū[end-1])  (:294):  ȳ[end-1] = ray.y[2] (the last real surface),
+    // ū[end-1] = -ray.u[1] (the converged launch angle of the reversed trace)
+    const double XP_t = -__shfl(e.y_first, 0, 4) / ::tan(-__shfl(v, 0, 4));
     const double y_EP = fabs(__shfl(v, 2, 4));                   // PupilSampling.jl:98 (real_marginal.y[1])
     // ---- phase 2: field, edge rays (PupilSampling.jl:94-100)
     const double U = a.H * ub1;                                  // :96
@@ -852,10 +872,51 @@ __global__ __launch_bounds__(64) void k_aim(int n, const AimIn* __restrict__ in,
     const int ok_all = ok & __shfl(ok, 2, 4);
     if (valid && role == 0) {
         AimOut o;
-        o.U = U; o.y1 = yy; o.y2 = y2e; o.y_EP = y_EP; o.hprime = u * a.f; o.EP_t = EP_t; o.Ubar = ub1;
+        o.U = U; o.y1 = yy; o.y2 = y2e; o.y_EP = y_EP; o.hprime = u * a.f; o.EP_t = EP_t; o.Ubar = ub1; o.XP_t = XP_t;
         o.iters = it_all; o.ok = ok_all;
         out[aim] = o;
     }
+}
+
+// ------------------------------------------------------------------------------------
+// Meridional fans (SURVEY §8f "next #4"): the ray set of `TSA` (src/SeidelAberrations.jl:116-137) — and, in
+// descending order with another back focal distance, of the caustic plot (ext/MakieExtension.jl:353-398) — for
+// many systems in ONE launch.  One thread per (request, ray): y = range(y_m / k, y_m, k)[i] (or its reverse), U = 0,
+// traced with mer_step; then
+//     y_XP = ray.y[end] + tan(ray.u[end]) * XP_t                                 (:131; transfer :107-115)
+//     eps  = ray.y[end] + tan(ray.u[end]) * (BFD - sag(ray)),  sag(ray) = ray.z[end-1] - ray.z[end]   (:130,132; :91)
+// The last ray (y = y_m) is the real marginal ray itself: the reference takes it from trace_marginal_ray (:127-128)
+// instead of tracing it again — the same trace of the same launch data, so the same numbers.
+// ------------------------------------------------------------------------------------
+__device__ __forceinline__ double dd_range_elem(double a, double b, int n, int i);   // below (pupil axes)
+
+struct FanIn {
+    int32_t system;        // index into the system batch
+    int32_t layout_mode;   // 1 = the prescription is a Layout{Aspheric} (Q16)
+    double y_marg;         // real_marginal.y[1]
+    double XP_t;           // real_chief.z[end] - real_chief.z[end-1]
+    double BFD;            // paraxial (or marginal, caustic) back focal distance from the last vertex
+};
+
+__global__ __launch_bounds__(kBlock) void k_fan(int n, int k_rays, int descending, const FanIn* __restrict__ in,
+                                                const MerSurf* __restrict__ surf, const double* __restrict__ coefs,
+                                                const double* __restrict__ t_last, int S, int ncoef,
+                                                double* __restrict__ y_XP, double* __restrict__ eps)
+{
+    const int64_t g = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (g >= (int64_t)n * k_rays) return;
+    const int q = (int)(g / k_rays), i = (int)(g - (int64_t)q * k_rays);
+    const FanIn f = in[q];
+    const double lo = f.y_marg / (double)k_rays;                                  // range(y_m / k, y_m, k)  (:121)
+    const double y0 = descending ? dd_range_elem(f.y_marg, lo, k_rays, i) : dd_range_elem(lo, f.y_marg, k_rays, i);
+    const MerSurf* F = surf + (int64_t)f.system * S;
+    const double* cF = coefs ? coefs + (int64_t)f.system * (S + 1) * ncoef : nullptr;
+    const double tl = t_last[f.system];
+    const MerEnd e = mer_trace_to(F, cF, S, ncoef, f.layout_mode, tl, y0, 0.0, -1);
+    const double tu = ::tan(e.U_last);
+    const double sag = e.s_last - tl;                                             // ray.z[end-1] - ray.z[end] = -ts[end]
+    y_XP[g] = e.y_last + tu * f.XP_t;
+    eps[g] = e.y_last + tu * (f.BFD - sag);
 }
 
 // ------------------------------------------------------------------------------------
@@ -1088,7 +1149,7 @@ __device__ __forceinline__ void make_rec(SurfRec<T>& r, T t, T Rv, T n1, T n2, T
     if (kind == KIND_SPHERE && fabs((double)Rv) <= kCentreFormMaxR && sizeof(T) == 8) { kind = KIND_SPHERE_C; r.K = r.t + Rv; }
     r.farmask = Rv > T(0) ? kClassPositive : kClassNegative;
     r.cls = (r.finite ? CLS_FINITE : 0) | (nc > 0 ? CLS_HASP : 0) | ((r.eta != T(1)) ? CLS_REFR : 0) |
-            (!(fabs(r.eta) <= T(1)) ? CLS_TIR : 0) | (kind << CLS_KIND_SHIFT);
+            (!(r.eta > T(0) && r.eta <= T(1)) ? CLS_TIR : 0) | (kind << CLS_KIND_SHIFT);
 }
 
 // number of coefficients in use for a row: the whole width if any entry is non-zero AFTER the cast to T

@@ -30,6 +30,28 @@ def shard_bounds(n_units: int, world: int) -> List[Tuple[int, int]]:
     return out
 
 
+def row_segments(ulo: int, uhi: int, k: int) -> List[Tuple[int, int, int, int]]:
+    """A contiguous slab [ulo, uhi) of the flattened (bundle, pupil row) list, k rows per bundle, as at most
+    three uniform pieces (first bundle, number of bundles, first row, rows per bundle): a partial first bundle,
+    whole bundles, a partial last bundle — each one grid launch (the grid entry points take one ny per call).
+    Traced in this order they yield the slab's rays in the reference's order (y outer, x inner,
+    src/PupilSampling.jl:123)."""
+    if uhi <= ulo:
+        return []
+    b0, r0 = divmod(ulo, k)
+    b1, r1 = divmod(uhi, k)                # the slab ends before row r1 of bundle b1
+    if b0 == b1:
+        return [(b0, 1, r0, r1 - r0)]
+    segs = []
+    if r0 > 0:
+        segs.append((b0, 1, r0, k - r0)); b0 += 1
+    if b1 > b0:
+        segs.append((b0, b1 - b0, 0, k))
+    if r1 > 0:
+        segs.append((b1, 1, 0, r1))
+    return segs
+
+
 def shard(seq: Sequence, rank: int, world: int) -> Sequence:
     lo, hi = shard_bounds(len(seq), world)[rank]
     return seq[lo:hi]
@@ -128,6 +150,10 @@ class RcclComm:
         _capi.check(_capi.load().ort_comm_unique_id(buf))
         return buf.raw
 
+    @property
+    def nranks_seen(self) -> int:
+        return int(self.engine.ctx.lib.ort_comm_size(self.h))
+
     def allgather_hits(self, xf, yf):
         """xf, yf: CUDA float64 tensors of equal length -> rank-ordered (gx, gy) of nranks*len."""
         import torch
@@ -136,8 +162,45 @@ class RcclComm:
         gy = torch.empty_like(gx)
         self._capi.check(self.engine.ctx.lib.ort_allgather_hits_f64(self.h, xf.data_ptr(), yf.data_ptr(), n,
                                                                     gx.data_ptr(), gy.data_ptr()))
-        self.engine.ctx.synchronize()
+        self.synchronize()
         return gx, gy
+
+    def allgather_hits_packed(self, hits, gathered=None, wait: bool = True):
+        """hits: CUDA tensor [2, n] (x row, y row — the trace wrote into it) -> [nranks, 2, n]: ONE ncclAllGather
+        on the communicator's stream, after the work queued on the engine's stream.  wait=False returns at once;
+        the caller overlaps further traces and calls wait() / synchronize() before reading `gathered`."""
+        import torch
+        n = hits.shape[-1]
+        if gathered is None:
+            gathered = torch.empty((self.nranks, 2, n), dtype=hits.dtype, device=hits.device)
+        fn = self.engine.ctx.lib.ort_allgather_hits_packed_f64 if hits.dtype == torch.float64 else \
+            self.engine.ctx.lib.ort_allgather_hits_packed_f32
+        self._capi.check(fn(self.h, hits.data_ptr(), n, gathered.data_ptr()))
+        if wait:
+            self.synchronize()
+        return gathered
+
+    def allgather_ragged(self, values, capacity: int):
+        """values: CUDA float64 tensor of this rank's length -> (rank-ordered concatenation [sum counts], counts)."""
+        import numpy as np
+        import torch
+        out = torch.empty(int(capacity), dtype=torch.float64, device=values.device)
+        counts = np.zeros(self.nranks, dtype=np.int64)
+        self._capi.check(self.engine.ctx.lib.ort_allgather_ragged_f64(self.h, values.data_ptr(), values.numel(), out.data_ptr(),
+                                                                      int(capacity), counts.ctypes.data))
+        self.synchronize()
+        return out[:int(counts.sum())], counts
+
+    def wait(self):
+        """engine stream waits for the collectives issued so far (no host block)."""
+        self._capi.check(self.engine.ctx.lib.ort_comm_wait(self.h))
+
+    def wait_lag(self, lag: int):
+        """engine stream waits for the collective issued `lag` calls before the latest one."""
+        self._capi.check(self.engine.ctx.lib.ort_comm_wait_lag(self.h, int(lag)))
+
+    def synchronize(self):
+        self._capi.check(self.engine.ctx.lib.ort_comm_synchronize(self.h))
 
     def close(self):
         if getattr(self, "h", None):

@@ -194,8 +194,25 @@ class HipEngine:
         aout = (_capi.ort_aim_out * n)()
         sf, sr = self.system(fwd), self.system(rev)      # both objects held across the call (see system())
         check(self.ctx.lib.ort_aim_f64(self.ctx.h, sf.h, sr.h, n, ain, aout, self.base_flags))
-        return [dict(U=o.U, y1=o.y1, y2=o.y2, y_EP=o.y_EP, hprime=o.hprime, EP_t=o.EP_t, Ubar=o.Ubar,
+        return [dict(U=o.U, y1=o.y1, y2=o.y2, y_EP=o.y_EP, hprime=o.hprime, EP_t=o.EP_t, Ubar=o.Ubar, XP_t=o.XP_t,
                      iters=o.iters, ok=bool(o.ok)) for o in aout]
+
+    # ---- meridional fans: TSA (SeidelAberrations.jl:116-137) / caustic ray set (MakieExtension.jl:364-381) ----
+    def fan(self, pres: Prescription, specs: Sequence[dict], k_rays: int, descending: bool = False):
+        """ort_fan_f64: for every spec {system, layout_mode, y_marg, XP_t, BFD} the k_rays rays
+        y = range(y_marg / k, y_marg, k) (reversed when `descending`), U = 0, in ONE launch.
+        Returns (y_XP, eps), each [len(specs), k_rays]."""
+        n = len(specs)
+        fin = (_capi.ort_fan_in * n)()
+        for i, sp in enumerate(specs):
+            f = fin[i]
+            f.system, f.layout_mode = int(sp.get("system", 0)), int(bool(sp.get("layout_mode", 0)))
+            f.y_marg, f.XP_t, f.BFD = float(sp["y_marg"]), float(sp["XP_t"]), float(sp["BFD"])
+        y_xp = np.empty((n, k_rays)); eps = np.empty((n, k_rays))
+        sysd = self.system(pres)
+        check(self.ctx.lib.ort_fan_f64(self.ctx.h, sysd.h, n, fin, int(k_rays), 1 if descending else 0,
+                                       ptr(y_xp), ptr(eps), self.base_flags))
+        return y_xp, eps
 
     # ---- batched first-order solve + Seidel sums: RayTracing.jl:302-323, SeidelAberrations.jl:6-53 --
     def first_order(self, R, t, n, a, hprime, dn=None, lam: float = 587.5618e-6) -> List[dict]:

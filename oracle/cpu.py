@@ -247,6 +247,24 @@ class OracleEngine:
             yo[:, r], Uo[:, r], ts[:, r] = by, bU, bt
         return yo, Uo, ts
 
+    def fan(self, pres, specs: Sequence[dict], k_rays: int, descending: bool = False):
+        """The ray loop of TSA (src/SeidelAberrations.jl:121-133): y = range(y_m / k, y_m, k), U = 0,
+        raytrace(surfaces, y, 0.0, RealRay) (orc_trace_meridional), then
+        y_XP = ray.y[end] + tan(ray.u[end]) XP_t (:131) and eps = ray.y[end] + tan(ray.u[end]) (BFD - sag(ray)),
+        sag(ray) = ray.z[end-1] - ray.z[end] = -ts[end] (:130,132; RayTracing.jl:91,105-115)."""
+        import math
+        n = len(specs)
+        y_xp = np.empty((n, k_rays)); eps = np.empty((n, k_rays))
+        for q, sp in enumerate(specs):
+            ym = float(sp["y_marg"])
+            ys = linrange(ym, ym / k_rays, k_rays) if descending else linrange(ym / k_rays, ym, k_rays)
+            yo, Uo, ts = self.meridional(pres, ys, np.zeros(k_rays), bool(sp.get("layout_mode", 0)), int(sp.get("system", 0)))
+            for i in range(k_rays):
+                tu = math.tan(Uo[-1, i])
+                y_xp[q, i] = yo[-1, i] + tu * sp["XP_t"]
+                eps[q, i] = yo[-1, i] + tu * (sp["BFD"] - (-ts[-1, i]))
+        return y_xp, eps
+
     def paraxial(self, tau, phi, y, w, a=None, clip: bool = False):
         tau = np.atleast_2d(_f(tau)); phi = np.atleast_2d(_f(phi))
         nlens, k = tau.shape

@@ -551,6 +551,46 @@ def test_first_order_and_seidel_batch(hip_engine, oracle_engine):
     assert e.value.code == -1 and "last thickness" in str(e.value)
 
 
+def test_fan_tsa_sa_caustic_on_device(hip_engine, oracle_engine):
+    """SURVEY §8f #4 on the device: `TSA` (src/SeidelAberrations.jl:116-137), the `SA` fit (:139-146) and the
+    caustic ray set (ext/MakieExtension.jl:364-381) through ort_fan_f64, against the oracle engine's restatement
+    of the same lines; the reference's own check `abs(SA(TSA(...)..., 9)[1] / W040 - 1) < 0.05`
+    (test/runtests.jl:277-278) with W040 from the device Seidel kernel; and the batched entry fed by the device
+    aiming kernel (y_EP, XP_t) for 40 perturbed Double-Gauss instances in one launch."""
+    from opticalraytracing_jl_amd import analysis as an, batch, workloads
+    for surf, a, h in ((cm.cooke(), cm.COOKE_A, cm.COOKE_H), (cm.tessar(), cm.TESSAR_A, cm.TESSAR_H)):
+        sg = ort.solve(surf.copy(), a, h, engine=hip_engine)
+        so = ort.solve(surf.copy(), a, h, engine=oracle_engine)
+        yg, eg = an.TSA(surf, sg, engine=hip_engine)
+        yo, eo = an.TSA(surf, so, engine=oracle_engine)
+        assert yg.shape == yo.shape == (ort.api.K_RAYS,)
+        assert cm.rel_err(yg, yo, 1.0).max() <= TOL and cm.rel_err(eg, eo, 1e-3).max() <= 1e-8    # eps ~ 1e-2 mm: aiming atol 1.5e-8
+        cg, co = an.caustic_rays(surf, sg, 24, engine=hip_engine), an.caustic_rays(surf, so, 24, engine=oracle_engine)
+        assert cg["to_paraxial_plane"] == co["to_paraxial_plane"] and abs(cg["zf"] - co["zf"]) <= 1e-8
+        for key in ("y0", "yf", "y_surf", "z_surf"):
+            assert np.abs(cg[key] - co[key]).max() <= 1e-8, key
+    surf = cm.cooke()
+    sg = ort.solve(surf.copy(), cm.COOKE_A, cm.COOKE_H, engine=hip_engine)
+    W040 = hip_engine.aberrations(surf[:, 0], surf[:, 1], surf[:, 2], cm.COOKE_A, cm.COOKE_H)["W040"][0]
+    B1 = an.SA(*an.TSA(surf, sg, engine=hip_engine), 9)[0]
+    lam_nu = 587.5618e-6 / sg.marginal.nu[-1]
+    assert abs(B1 / (4 * W040 * lam_nu) - 1) < 0.05 or abs(B1 / W040 - 1) < 0.05, (B1, W040)
+    # batched: device aiming (y_EP, XP_t) -> one fan launch over 40 instances, vs the oracle fan per instance
+    mats = workloads.config5(None, ninst=40)
+    fo = batch.first_order_arrays(hip_engine, mats, cm.DG_A, cm.DG_H)
+    aims = batch.aim_instances(mats, cm.DG_A, cm.DG_H, (0.0,), engine=hip_engine)
+    pres = Prescription(mats[:, :, 0], mats[:, :, 1], mats[:, :, 2])
+    specs = [dict(system=i, layout_mode=0, y_marg=float(aims["y_EP"][i, 0]), XP_t=float(aims["XP_t"][i, 0]), BFD=float(fo["BFD"][i]))
+             for i in range(40)]
+    yg, eg = hip_engine.fan(pres, specs, 32)
+    yo, eo = oracle_engine.fan(pres, specs, 32)
+    assert cm.rel_err(yg, yo, 1.0).max() <= TOL and np.abs(eg - eo).max() <= 1e-10
+    # XP_t of the device aiming == the host-driven trace_chief_ray (RayTracing.jl:294)
+    s0 = ort.solve(mats[0].copy(), cm.DG_A, cm.DG_H, engine=oracle_engine)
+    rc = ort.trace_chief_ray(mats[0], s0, engine=oracle_engine)
+    assert abs((rc.z[-1] - rc.z[-2]) - aims["XP_t"][0, 0]) <= 1e-6 * abs(aims["XP_t"][0, 0])
+
+
 def test_native_rccl_allgather_single_rank():
     """ort_comm_* / ort_allgather_hits_f64 (librccl loaded lazily): a 1-rank communicator on the one
     GPU of the test box — the all-gather must reproduce the slabs (multi-rank correctness of the
@@ -1072,3 +1112,53 @@ def test_image_hits_config4_sharded(hip_engine, oracle_engine):
     assert float(ok.float().mean()) > 0.5
     assert float((w32[0][ok].double() - whole[0][ok]).abs().max()) <= 2e-4
     assert float((w32[1][ok].double() - whole[1][ok]).abs().max()) <= 2e-4
+
+
+def test_image_hits_plan_row_shards_and_packed_slab(hip_engine):
+    """ImageHitsPlan (what bench.py's multi-GPU step launches): pupil-ROW sharding for world sizes that do not
+    divide the bundle count — slabs that start and end inside a bundle — concatenated in rank order equal the
+    single launch bit for bit; the packed [2][n] slab is what ONE all-gather sends."""
+    import torch
+    from opticalraytracing_jl_amd import batch, dist as odist, workloads
+    mats = np.array([workloads.double_gauss(line, g) for g in (-1.0, 1.0) for line in (0, 1, 2)])
+    fields = (0.0, 0.7, 1.0)                                    # 18 bundles
+    k = 20
+    whole = batch.ImageHitsPlan(mats, cm.DG_A, cm.DG_H, fields, k, engine=hip_engine)
+    wh = whole.new_hits(); whole.trace(wh); hip_engine.ctx.synchronize()
+    assert wh.shape == (2, 18 * k * k)
+    for world in (4, 7):                                        # 360 rows: 90 each; 51/52 rows -> uneven
+        parts = []
+        for r in range(world):
+            plan = batch.ImageHitsPlan(mats, cm.DG_A, cm.DG_H, fields, k, engine=hip_engine, shard=(r, world), unit="row")
+            lo, hi = odist.shard_bounds(18 * k, world)[r]
+            assert plan.n_rays == (hi - lo) * k and len(plan.segs) <= 3
+            h = plan.new_hits(); plan.trace(h); hip_engine.ctx.synchronize()
+            parts.append(h)
+        cat = torch.cat(parts, dim=1)
+        assert torch.equal(torch.nan_to_num(cat), torch.nan_to_num(wh)), world
+
+
+def test_native_rccl_packed_ragged_and_overlap_single_rank():
+    """The native reassembly entry points on the one GPU of the test box (1-rank communicator): the packed
+    single-collective all-gather on the communicator's own stream, ordered after the engine's stream
+    (ort_comm_wait / _wait_lag / _synchronize), and the ragged gather (counts, then slabs).  Multi-rank order is
+    covered by the gloo tests and is RCCL's contract."""
+    import torch
+    from opticalraytracing_jl_amd import dist as odist
+    eng = ort.default_engine()
+    comm = odist.RcclComm(eng, 1, 0, odist.RcclComm.unique_id())
+    assert comm.nranks_seen == 1
+    hits = torch.randn((2, 200003), dtype=torch.float64, device="cuda:0")
+    torch.cuda.synchronize()
+    g = comm.allgather_hits_packed(hits)
+    assert g.shape == (1, 2, 200003) and torch.equal(g[0], hits)
+    for i in range(5):                                          # ring of completion events
+        comm.allgather_hits_packed(hits, g, wait=False)
+        comm.wait_lag(1)
+    comm.wait(); comm.synchronize()
+    assert torch.equal(g[0], hits)
+    vals = torch.randn(12345, dtype=torch.float64, device="cuda:0")
+    torch.cuda.synchronize()
+    out, counts = comm.allgather_ragged(vals, 20000)
+    assert counts.tolist() == [12345] and torch.equal(out, vals)
+    comm.close()

@@ -288,7 +288,7 @@ def test_aberration_coefficients(cooke_system):
 
 # ---- "vignetting" :241-251 -----------------------------------------------------------------------
 def test_vignetting_table(cooke_system, eng):
-    from opticalraytracing_jl_amd import analysis as an
+    from tests import ref_consumers as an
     surfaces, system = cooke_system
     vig = an.vignetting(system, cm.COOKE_A)
     assert vig.partial == [1, 2, 3, 6, 7]
@@ -303,9 +303,10 @@ def test_vignetting_table(cooke_system, eng):
 
 # ---- "transverse ray errors" :290-310 --------------------------------------------------------------
 def test_transverse_ray_errors(cooke_system):
-    from opticalraytracing_jl_amd import analysis as an
+    from opticalraytracing_jl_amd import analysis
+    from tests import ref_consumers as an
     surfaces, system = cooke_system
-    dW = an.aberrations(surfaces, system)
+    dW = analysis.aberrations(surfaces, system)
     ey = an.RayError(ort.Tangential, dW)
     ex = an.RayError(ort.Sagittal, dW)
     rs = 1e-3
