@@ -30,6 +30,7 @@
 #ifndef ORT_H
 #define ORT_H
 
+#include <stddef.h>
 #include <stdint.h>
 
 #ifdef __cplusplus
@@ -79,6 +80,16 @@ int ort_ctx_timer_stop(ort_ctx *ctx, float *ms);
 /* device properties the bench reports (name, CU count, clock MHz, total bytes) */
 int ort_ctx_device_info(ort_ctx *ctx, char *name, int name_len, int *cus, int *clock_mhz,
                         int64_t *mem_bytes);
+
+/* ---- device buffers ---------------------------------------------------------------- 
+ * For hosts without a GPU array library of their own (the Julia shim, a plain C caller): allocate on the
+ * context's GPU, pass the pointers with ORT_DEVICE_PTRS, download only what is read on the host — a config-2
+ * history is 1.8 GB, 30 ms over PCIe against 0.3 ms of kernel.  upload / download block until the copy is
+ * done; free waits for the context's stream first.                                                      */
+int ort_device_malloc(ort_ctx *ctx, size_t bytes, void **out);
+int ort_device_free(ort_ctx *ctx, void *p);
+int ort_device_upload(ort_ctx *ctx, void *dst_device, const void *src_host, size_t bytes);
+int ort_device_download(ort_ctx *ctx, void *dst_host, const void *src_device, size_t bytes);
 
 /* ---- systems ---------------------------------------------------------------------- */
 /* Upload nsys prescriptions of `rows` rows each (host pointers, always).
@@ -189,6 +200,12 @@ int ort_trace_meridional_f64(ort_ctx *ctx, const ort_system *sys, int isys, int6
                              const double *y, const double *U,
                              double *y_out, double *U_out, double *ts_out, int64_t ld,
                              unsigned flags);
+/* Base.asin's DomainError (src/RayTracing.jl:162: asin(y / R) with |y / R| > 1, reachable only by rounding at a
+ * sphere's equator): the reference's raytrace of THAT ray throws.  The batch form traces every ray — the
+ * offending ones are NaN from that surface on — and reports it: with host pointers the call returns ORT_EDOMAIN
+ * (outputs written, message names the first ray and surface); with ORT_DEVICE_PTRS query the last launch of
+ * the context after it has run: ray = -1 when there was none (blocks on the context's stream).             */
+int ort_ctx_domain_error(ort_ctx *ctx, int64_t *ray, int *surface, int64_t *count);
 
 /* ---- batched real-ray aiming: trace_chief_ray / trace_marginal_ray / trace_edge_rays -----
  * One (system, field) pair per entry: the FD-Newton drivers of src/RayTracing.jl:223-240 (real

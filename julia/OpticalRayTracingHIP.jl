@@ -3,7 +3,8 @@
 # Adds BATCH methods with the reference's names and argument order to OpticalRayTracing.jl,
 # and a `full_trace` that replaces only the grid stage (src/PupilSampling.jl:115-146), taking
 # the aiming scalars from the unmodified reference code.  Not exercised in the build container
-# (no Julia runtime there); the same C ABI is exercised through ctypes by the Python mirror.
+# (no Julia runtime there); the same C ABI is exercised through ctypes by the Python mirror
+# (the device-resident calls below: tests/test_gpu_parity.py::test_device_buffers_through_the_c_abi).
 #
 #   ENV["ORT_HIP_LIB"] = "/path/to/libort_hip.so";  include("OpticalRayTracingHIP.jl")
 module OpticalRayTracingHIP
@@ -13,6 +14,7 @@ import OpticalRayTracing: raytrace, full_trace, Layout, System, RealRay, RealRay
 
 const LIB = get(ENV, "ORT_HIP_LIB", joinpath(@__DIR__, "..", "opticalraytracing.jl_amd", "csrc", "libort_hip.so"))
 
+const ORT_DEVICE_PTRS = UInt32(1) << 0
 const ORT_FAST_MATH = UInt32(1) << 5
 const ORT_CLIP = UInt32(1) << 4
 const ORT_LAYOUT_INPUT = UInt32(1) << 3
@@ -36,6 +38,91 @@ mutable struct Context
 end
 const CTX = Ref{Context}()
 ctx() = (isassigned(CTX) || (CTX[] = Context()); CTX[])
+
+# ---- device-resident results ------------------------------------------------------------------------
+# A host-pointer call brings every ray-sized output back over PCIe (config 2's history: 1.8 GB, ~30 ms against
+# 0.3 ms of kernel).  DeviceArray keeps results on the GPU (ort_device_malloc + ORT_DEVICE_PTRS); `download`
+# copies back only what the host reads — a row of the history, the image-plane hits, a strided sample.
+mutable struct DeviceArray{T}
+    p::Ptr{T}; len::Int
+    function DeviceArray{T}(len::Integer) where T
+        r = Ref{Ptr{Cvoid}}(C_NULL)
+        check(ccall((:ort_device_malloc, LIB), Cint, (Ptr{Cvoid}, Csize_t, Ref{Ptr{Cvoid}}), ctx().h, len * sizeof(T), r))
+        finalizer(a -> ccall((:ort_device_free, LIB), Cint, (Ptr{Cvoid}, Ptr{Cvoid}), ctx().h, a.p), new{T}(Ptr{T}(r[]), len))
+    end
+end
+function DeviceArray(v::Vector{T}) where T
+    d = DeviceArray{T}(length(v))
+    GC.@preserve v check(ccall((:ort_device_upload, LIB), Cint, (Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Csize_t), ctx().h, d.p, pointer(v), sizeof(v)))
+    return d
+end
+"download(d, first, n): elements first .. first+n-1 (1-based) of a device array"
+function download(d::DeviceArray{T}, first::Integer = 1, n::Integer = d.len - first + 1) where T
+    v = Vector{T}(undef, n)
+    GC.@preserve v check(ccall((:ort_device_download, LIB), Cint, (Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Csize_t),
+                               ctx().h, pointer(v), d.p + (first - 1) * sizeof(T), n * sizeof(T)))
+    return v
+end
+synchronize() = check(ccall((:ort_ctx_synchronize, LIB), Cint, (Ptr{Cvoid},), ctx().h))
+
+struct GridOut64            # == ort_grid_out_f64
+    xv::Ptr{Float64}; yv::Ptr{Float64}; ld::Int64
+    xf::Ptr{Float64}; yf::Ptr{Float64}; xs::Ptr{Float64}; ys::Ptr{Float64}; status::Ptr{Int32}
+end
+
+"""
+    trace_grid_device(sys, bundles, axes, ny, nx; history = true, flags = 0) -> NamedTuple of DeviceArrays
+
+The hot loop of `full_trace` (src/PupilSampling.jl:121-138) for many bundles with every output LEFT ON THE GPU:
+`xv`, `yv` ((rows-1) x N, surface-major: surface s of ray r at s*N + r) when `history`, else the summary
+`xf`, `yf`, `status`.  `sys` comes from `upload`, `bundles :: Vector{OrtBundle}`, `axes :: Vector{Float64}` (the
+exact Julia `range`s, collected).  The call is asynchronous; `download` / `synchronize()` wait for it.
+"""
+function trace_grid_device(sys, rows::Integer, bundles::Vector{OrtBundle}, axes::Vector{Float64}, ny::Integer, nx::Integer;
+                           history::Bool = true, flags::UInt32 = UInt32(0))
+    N = length(bundles) * ny * nx; S = rows - 1
+    dax = DeviceArray(axes)
+    if history
+        xv = DeviceArray{Float64}(S * N); yv = DeviceArray{Float64}(S * N)
+        out = Ref(GridOut64(xv.p, yv.p, N, C_NULL, C_NULL, C_NULL, C_NULL, C_NULL)); res = (xv = xv, yv = yv, N = N, S = S)
+    else
+        xf = DeviceArray{Float64}(N); yf = DeviceArray{Float64}(N); st = DeviceArray{Int32}(N)
+        out = Ref(GridOut64(C_NULL, C_NULL, 0, xf.p, yf.p, C_NULL, C_NULL, st.p)); res = (xf = xf, yf = yf, status = st, N = N)
+    end
+    GC.@preserve bundles out dax check(ccall((:ort_trace_grid_f64, LIB), Cint,
+        (Ptr{Cvoid}, Ptr{Cvoid}, Cint, Ptr{OrtBundle}, Ptr{Float64}, Int64, Cint, Cint, Ref{GridOut64}, UInt32),
+        ctx().h, sys, length(bundles), bundles, dax.p, length(axes), ny, nx, out, flags | ORT_DEVICE_PTRS))
+    synchronize()                                   # `dax` may be collected after this
+    return res
+end
+
+"""
+    full_trace_rms(surfaces::Layout, system, H, k_rays, focus) -> (count, RMS)
+
+`full_trace(...).RMS` and the ray count with NOTHING ray-sized crossing PCIe: the statistics-only route of
+`ort_full_trace_f64` (NULL error vectors) — aiming by the unmodified reference, grid stage, stop filter, mirrored
+centroid and σ on the GPU; 96 doubles of axes in, 16 bytes out.
+"""
+function full_trace_rms(surfaces::Layout, system::System, H::Float64, k_rays::Int = 64,
+                        focus = system.marginal.z[end] - system.marginal.z[end-1]; coef = nothing, flags::UInt32 = UInt32(0))
+    H = abs(H); H ≤ 1.0 || throw(DomainError(H, "Domain: |H| ≤ 1.0"))
+    stop = system.stop; a_stop = abs(system.a[stop])
+    real_chief = trace_chief_ray(surfaces, system); real_marginal = trace_marginal_ray(surfaces, system)
+    EP_t = real_chief.z[1]; U = H * real_chief.u[1]; u = tan(U); y_EP = abs(real_marginal.y[1])
+    y1, y2 = OpticalRayTracing.trace_edge_rays(surfaces, y_EP - u * EP_t, -y_EP - u * EP_t, U, stop, a_stop)
+    R = [surfaces[:, 1]; Inf]; t = [surfaces[:, 2]; 0.0]; n = [surfaces[:, 3]; 1.0]; t[end-1] = focus
+    sys = upload(R, t, n, [surfaces.K; 0.0], coef === nothing ? nothing : [coef; zeros(1, size(coef, 2))])
+    k2 = div(k_rays, 2)
+    axes = [collect(range(y1, y2, k_rays)); collect(range(0.0, y_EP, k2))]
+    b = [OrtBundle(0, stop, U, 0.0, a_stop, u * system.f, 0.0, 1.0, 0, k_rays)]
+    cnt = Ref{Int64}(0); rms = Ref{Float64}(0.0)
+    GC.@preserve axes b check(ccall((:ort_full_trace_f64, LIB), Cint,
+        (Ptr{Cvoid}, Ptr{Cvoid}, Cint, Ptr{OrtBundle}, Ptr{Float64}, Int64, Cint, Cint,
+         Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ref{Int64}, Ref{Float64}, UInt32),
+        ctx().h, sys, 1, b, axes, length(axes), k_rays, k2, C_NULL, C_NULL, C_NULL, C_NULL, cnt, rms, flags))
+    release(sys)
+    return cnt[], rms[]
+end
 
 "Power-series coefficients of a row's polynomial; the closure handed to the CPU path is built from the same vector."
 poly(c::Vector{Float64}) = OpticalRayTracing.Polynomial(y -> evalpoly(y, c))

@@ -108,6 +108,10 @@ SIGNATURES = {
     "ort_ctx_timer_start": (_i, [_p]),
     "ort_ctx_timer_stop": (_i, [_p, C.POINTER(C.c_float)]),
     "ort_ctx_device_info": (_i, [_p, C.c_char_p, _i, C.POINTER(_i), C.POINTER(_i), C.POINTER(_l)]),
+    "ort_device_malloc": (_i, [_p, C.c_size_t, C.POINTER(_p)]),
+    "ort_device_free": (_i, [_p, _p]),
+    "ort_device_upload": (_i, [_p, _p, _p, C.c_size_t]),
+    "ort_device_download": (_i, [_p, _p, _p, C.c_size_t]),
     "ort_system_create": (_i, [_p, _i, _i, _p, _p, _p, _p, _p, _i, C.POINTER(_p)]),
     "ort_system_destroy": (_i, [_p]),
     "ort_system_set_apertures": (_i, [_p, _p]),
@@ -131,6 +135,7 @@ SIGNATURES = {
                                              C.POINTER(ort_first_order), _p, _p, _p, _p, _p, _p, _u]),
     "ort_spot_batch_f32": (_i, [_p, _i, _i, _p, _p, _p, _p, _p, _i, _p, _i, C.POINTER(ort_first_order), _p, _p, _u]),
     "ort_trace_meridional_f64": (_i, [_p, _p, _i, _l, _p, _p, _p, _p, _p, _l, _u]),
+    "ort_ctx_domain_error": (_i, [_p, C.POINTER(_l), C.POINTER(_i), C.POINTER(_l)]),
     "ort_trace_paraxial_f64": (_i, [_p, _i, _i, _p, _p, _p, _l, _p, _p, _p, _p, _l, _u]),
     "ort_abcd_f64": (_i, [_p, _i, _i, _p, _p, _p, _u]),
     "ort_abcd_transfer_f64": (_i, [_p, _p, _l, _p, _p, _p, _p, _u]),

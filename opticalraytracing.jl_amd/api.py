@@ -398,7 +398,10 @@ def _raytrace_real(surfaces, y, U, K=None, p=None, engine=None):      # RayTraci
         ncol = pres.n[0]
     else:
         pres, layout_mode, ncol = _as_layout(surfaces)
-    yo, Uo, ts = _eng(engine).meridional(pres, y, U, layout_mode)
+    eng = _eng(engine)
+    yo, Uo, ts = eng.meridional(pres, y, U, layout_mode)
+    if getattr(eng, "last_domain_error", None):                        # Base.asin's DomainError, :162
+        raise DomainError(eng.last_domain_error)
     if np.ndim(y) == 0 and np.ndim(U) == 0:
         return RealRayT.from_trace(Tangential, np.column_stack([yo[:, 0], Uo[:, 0]]), ts[:, 0], ncol)
     return [RealRayT.from_trace(Tangential, np.column_stack([yo[:, j], Uo[:, j]]), ts[:, j], ncol)

@@ -251,7 +251,7 @@ __device__ __forceinline__ void ieee_div2(double a1, double a2, double b, double
 __device__ __forceinline__ void ieee_div2(float a1, float a2, float b, float& q1, float& q2) { q1 = a1 / b; q2 = a2 / b; }
 __device__ __forceinline__ double ieee_div(double a, double b) { return ieee_div_with(a, b, ieee_rcp_refined(b)); }
 __device__ __forceinline__ float ieee_div(float a, float b) { return a / b; }
-__device__ __forceinline__ double ieee_sqrt(double x)
+__device__ __forceinline__ double ieee_sqrt_any(double x)      // every IEEE special case: +-0 and +inf return x, x < 0 -> NaN
 {
     const double y = __builtin_amdgcn_rsq(x);
     double g = x * y;
@@ -263,7 +263,28 @@ __device__ __forceinline__ double ieee_sqrt(double x)
     g = __builtin_fma(d, h, g);
     d = __builtin_fma(-g, g, x);
     g = __builtin_fma(d, h, g);
-    return __builtin_amdgcn_class(x, 0x260) ? x : g;          // +-0 and +inf return x; x < 0 -> NaN through rsq
+    return __builtin_amdgcn_class(x, 0x260) ? x : g;
+}
+__device__ __forceinline__ float ieee_sqrt_any(float x) { return __builtin_sqrtf(x); }
+// The same for a FINITE radicand (the sag and refraction discriminants, :5,24):
+__device__ __forceinline__ double ieee_sqrt(double x)
+{
+    // x = 0: the seed of rsq(0) is +inf and 0 * inf = NaN; seeding from x + 1e-300 instead (one add where a class
+    // test and two selects would be) gives 0 * 1e150 = 0 and every later step keeps the 0 exactly.  x + 1e-300 == x
+    // for every x > 1e-284, and a non-zero radicand of this loop (a sum / difference of doubles of the size of 1 or
+    // R^2, never a product of tiny factors) is far above that; x < 0 is still NaN through rsq.  +inf would give NaN
+    // instead of +inf: the one radicand that can be infinite (the tilt's, on a flat row with a polynomial) uses ieee_sqrt_any.
+    const double y = __builtin_amdgcn_rsq(x + 1e-300);
+    double g = x * y;
+    double h = y * 0.5;
+    const double r = __builtin_fma(-h, g, 0.5);
+    g = __builtin_fma(g, r, g);
+    h = __builtin_fma(h, r, h);
+    double d = __builtin_fma(-g, g, x);
+    g = __builtin_fma(d, h, g);
+    d = __builtin_fma(-g, g, x);
+    g = __builtin_fma(d, h, g);
+    return g;
 }
 __device__ __forceinline__ float ieee_sqrt(float x) { return __builtin_sqrtf(x); }
 
@@ -343,7 +364,7 @@ __device__ __forceinline__ void surface_step_ieee(Ray<T>& r, const SurfRec<T>& s
         const double si = (double)s.sgn * inv;                   // exact: (sign(R) t) inv == t (sign(R) inv)
         m0 = (T)(tx * si); m1 = (T)(ty * si); m2 = (T)(-inv);
     } else {
-        const T sq = ieee_sqrt(Dt);
+        const T sq = ieee_sqrt_any(Dt);                          // inf on a flat row (with a polynomial)
         T tx, ty;
         ieee_div2(s.sgn * r.x, s.sgn * r.y, sq, tx, ty);         // one refined reciprocal, two quotients
         if (HASP) {

@@ -68,7 +68,7 @@ enum { SL_IN0 = 0, SL_IN1, SL_IN2, SL_IN3, SL_OUT0, SL_OUT1, SL_OUT2, SL_OUT3, S
        SL_BUNDLES, SL_AXES, SL_WEX, SL_WEY, SL_WR, SL_WTH, SL_TCNT, SL_TSX, SL_TSY, SL_TRM,
        SL_TOFF, SL_TSQ, SL_AGG, SL_RES0, SL_RES1, SL_TAB0, SL_TAB1, SL_TAB2, SL_TAB3,
        SL_SB_FO, SL_SB_REC, SL_SB_MF, SL_SB_MR, SL_SB_TLF, SL_SB_TLR, SL_SB_AIN, SL_SB_AOUT, SL_SB_ENDS, SL_SB_FLAG,
-       SL_SB_FIELDS, SL_SB_A, SL_SB_HP, SL_SB_PACK, SL_SB_CEXT, SL_SB_CREV, SL_FTSTATE, SL_FTTICKET, SL_COUNT };
+       SL_SB_FIELDS, SL_SB_A, SL_SB_HP, SL_SB_PACK, SL_SB_CEXT, SL_SB_CREV, SL_FTSTATE, SL_FTTICKET, SL_DOMAIN, SL_COUNT };
 
 }  // namespace
 
@@ -753,6 +753,49 @@ int ort_ctx_device_info(ort_ctx* ctx, char* name, int name_len, int* cus, int* c
 }
 
 // --------------------------------------------------------------------------------------
+// Device buffers for hosts without a GPU array library of their own (the Julia shim): with these and
+// ORT_DEVICE_PTRS a caller keeps ray-sized results on the device and downloads only what it reads.
+int ort_device_malloc(ort_ctx* ctx, size_t bytes, void** out)
+{
+    int rc = check_ctx(ctx); if (rc) return rc;
+    if (!out) return fail(ORT_EINVAL, "null out");
+    *out = nullptr;
+    if (bytes == 0) return ORT_OK;
+    hipError_t e = hipMalloc(out, bytes);
+    if (e != hipSuccess) { *out = nullptr; return fail(ORT_ENOMEM, "hipMalloc(%zu) failed: %s", bytes, hipGetErrorString(e)); }
+    return ORT_OK;
+}
+
+int ort_device_free(ort_ctx* ctx, void* p)
+{
+    int rc = check_ctx(ctx); if (rc) return rc;
+    if (!p) return ORT_OK;
+    HIP_TRY(hipStreamSynchronize(ctx->stream));                 // no launch of this context may still use it
+    HIP_TRY(hipFree(p));
+    return ORT_OK;
+}
+
+int ort_device_upload(ort_ctx* ctx, void* dst, const void* src, size_t bytes)
+{
+    int rc = check_ctx(ctx); if (rc) return rc;
+    if (bytes == 0) return ORT_OK;
+    if (!dst || !src) return fail(ORT_EINVAL, "null pointer");
+    HIP_TRY(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    return ORT_OK;
+}
+
+int ort_device_download(ort_ctx* ctx, void* dst, const void* src, size_t bytes)
+{
+    int rc = check_ctx(ctx); if (rc) return rc;
+    if (bytes == 0) return ORT_OK;
+    if (!dst || !src) return fail(ORT_EINVAL, "null pointer");
+    HIP_TRY(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    return ORT_OK;
+}
+
+// --------------------------------------------------------------------------------------
 int ort_system_create(ort_ctx* ctx, int nsys, int rows, const double* R, const double* t, const double* n,
                       const double* K, const double* coef, int ncoef, ort_system** out)
 {
@@ -981,9 +1024,14 @@ int ort_trace_meridional_f64(ort_ctx* ctx, const ort_system* sys, int isys, int6
     const int layout = (flags & ORT_LAYOUT_INPUT) ? 1 : 0;
     const int64_t blocks = (nrays + kBlock - 1) / kBlock;
     const double t_last = sys->t_last[(size_t)isys];
+    // DomainError record of this launch: [0] = min over (ray << 8 | surface), [1] = count
+    unsigned long long* ddom;
+    rc = dev_out<unsigned long long>(ctx, SL_DOMAIN, 2, &ddom); if (rc) return rc;
+    HIP_TRY(hipMemsetAsync(ddom, 0xff, sizeof(unsigned long long), ctx->stream));
+    HIP_TRY(hipMemsetAsync(ddom + 1, 0, sizeof(unsigned long long), ctx->stream));
     if (flags & ORT_DEVICE_PTRS) {
         hipLaunchKernelGGL(k_trace_meridional, dim3((unsigned)blocks), dim3(kBlock), 0, ctx->stream,
-                           surf, coefs, S, sys->ncoef, layout, t_last, nrays, y, U, y_out, U_out, ts_out, ld);
+                           surf, coefs, S, sys->ncoef, layout, t_last, nrays, y, U, y_out, U_out, ts_out, ld, ddom);
         HIP_TRY(hipGetLastError());
         return ORT_OK;
     }
@@ -994,13 +1042,36 @@ int ort_trace_meridional_f64(ort_ctx* ctx, const ort_system* sys, int isys, int6
     rc = dev_out<double>(ctx, SL_OUT1, (size_t)rows * nrays, &oU); if (rc) return rc;
     if (ts_out) { rc = dev_out<double>(ctx, SL_OUT2, (size_t)rows * nrays, &ots); if (rc) return rc; }
     hipLaunchKernelGGL(k_trace_meridional, dim3((unsigned)blocks), dim3(kBlock), 0, ctx->stream,
-                       surf, coefs, S, sys->ncoef, layout, t_last, nrays, dy, dU, oy, oU, ots, nrays);
+                       surf, coefs, S, sys->ncoef, layout, t_last, nrays, dy, dU, oy, oU, ots, nrays, ddom);
     HIP_TRY(hipGetLastError());
     const size_t w = (size_t)nrays * sizeof(double);
     HIP_TRY(hipMemcpy2DAsync(y_out, ld * sizeof(double), oy, w, w, rows, hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(hipMemcpy2DAsync(U_out, ld * sizeof(double), oU, w, w, rows, hipMemcpyDeviceToHost, ctx->stream));
     if (ts_out) HIP_TRY(hipMemcpy2DAsync(ts_out, ld * sizeof(double), ots, w, w, rows, hipMemcpyDeviceToHost, ctx->stream));
+    unsigned long long hdom[2] = {~0ull, 0ull};
+    HIP_TRY(hipMemcpyAsync(hdom, ddom, sizeof hdom, hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(hipStreamSynchronize(ctx->stream));
+    if (hdom[0] != ~0ull)
+        return fail(ORT_EDOMAIN, "DomainError: asin(x) is not defined for |x| > 1 (y / R at a spherical surface, src/RayTracing.jl:162): "
+                                 "ray %llu at surface row %u, %llu ray-surface(s) in all; those rays are NaN from there on, every other output is valid",
+                    hdom[0] >> 8, (unsigned)(hdom[0] & 0xff), hdom[1]);
+    return ORT_OK;
+}
+
+int ort_ctx_domain_error(ort_ctx* ctx, int64_t* ray, int* surface, int64_t* count)
+{
+    int rc = check_ctx(ctx); if (rc) return rc;
+    if (ray) *ray = -1;
+    if (surface) *surface = 0;
+    if (count) *count = 0;
+    if (!ctx->slot[SL_DOMAIN].p) return ORT_OK;
+    unsigned long long hdom[2];
+    HIP_TRY(hipMemcpyAsync(hdom, ctx->slot[SL_DOMAIN].p, sizeof hdom, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    if (hdom[0] == ~0ull) return ORT_OK;
+    if (ray) *ray = (int64_t)(hdom[0] >> 8);
+    if (surface) *surface = (int)(hdom[0] & 0xff);
+    if (count) *count = (int64_t)hdom[1];
     return ORT_OK;
 }
 

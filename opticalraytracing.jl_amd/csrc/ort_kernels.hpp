@@ -33,10 +33,16 @@ namespace ort {
 #ifndef ORT_APERTURES
 #define ORT_APERTURES 1   // 0 compiles the clear-aperture extension out (A/B builds)
 #endif
+#ifndef ORT_FT_DEBUG
+#define ORT_FT_DEBUG 0
+#endif
 #ifndef ORT_MIN_WAVES
 #define ORT_MIN_WAVES 5      // __launch_bounds__ 2nd argument (waves per SIMD): 96 VGPRs, no spill in the fast history kernel
 #endif
-constexpr int kBlock = 256;
+#ifndef ORT_BLOCK
+#define ORT_BLOCK 256          // threads per workgroup (A/B builds: 128 halves the tile and the end-of-launch tail)
+#endif
+constexpr int kBlock = ORT_BLOCK;
 constexpr int kRPT = ORT_RPT;
 constexpr int kTile = kBlock * kRPT;
 constexpr int kMaxRows = 64;
@@ -167,7 +173,11 @@ __global__ __launch_bounds__(kBlock, (HIST && SUMM) ? ORT_MIN_WAVES - 1 : ORT_MI
     __shared__ unsigned s_bid;
     if (FT == FT_FULL) {
         if (tid == 0) {
+#if ORT_FT_DEBUG & 2            /* A/B only: blockIdx order instead of tickets (no progress guarantee) */
+            unsigned long long tk = blockIdx.x;
+#else
             unsigned long long tk = atomicAdd(p.ft_ticket, 1ull) - p.ft_ticket_base;
+#endif
             if (tk >= gridDim.x) tk = gridDim.x - 1;                 // (never out of the grid, whatever the host passed)
             // tickets walk the bundles round-robin (ticket = tile * nb + bundle): the tiles in flight at any time
             // are spread over all the bundles' chains, so each look-back chain below is nb times shorter; a tile's
@@ -434,7 +444,11 @@ __global__ __launch_bounds__(kBlock, (HIST && SUMM) ? ORT_MIN_WAVES - 1 : ORT_MI
                                        __HIP_MEMORY_SCOPE_AGENT);
                 }
                 long long excl = 0;
+#if ORT_FT_DEBUG & 1            /* A/B only: no look-back, every tile writes at its dense position (wrong offsets, same traffic) */
+                int hi = -1; excl = (long long)tile * kTile * 3 / 4;
+#else
                 int hi = tile - 1;                               // next predecessor to look at
+#endif
                 constexpr int kLook = 4;                         // predecessors per lane and round: windows of 256 tiles
                 while (hi >= 0) {
                     // lane l looks at tiles hi - kLook l - j, j = 0 .. kLook-1 (nearest first); every tile with a lower
@@ -687,7 +701,7 @@ struct MerSurf {   // row i+1 of the prescription as seen by loop iteration i
 
 // One loop iteration of src/RayTracing.jl:151-167.  Returns ts[i] (after :160).
 __device__ __forceinline__ double mer_step(const MerSurf& s, const double* __restrict__ c, int layout_mode,
-                                           double& y, double& U, double& sprev)
+                                           double& y, double& U, double& sprev, bool& domain)
 {
     const double tcur = s.t - sprev;                              // ts[i] after :161
     const double tU = ::tan(U);
@@ -706,7 +720,9 @@ __device__ __forceinline__ double mer_step(const MerSurf& s, const double* __res
     sprev = sg;
     double theta;
     if (s.K == 0.0 && !layout_mode && s.ncoef == 0) {
-        theta = ::asin(y / s.R);                                  // :162, tilt(y, R) = y / R (:101)
+        const double q = y / s.R;                                 // tilt(y, R) = y / R (:101)
+        domain = domain || (fabs(q) > 1.0);                       // Base.asin throws DomainError there (:162); NaN here + the flag
+        theta = ::asin(q);                                        // :162
     } else {
         double tl = s.sgn * y / __builtin_sqrt(s.R * s.R - y * y * (1.0 + s.K));   // :98
         tl = tl + (s.ncoef > 0 ? poly_deriv<double>(c, s.ncoef, y) : 0.0);
@@ -722,7 +738,8 @@ __global__ __launch_bounds__(kBlock) void k_trace_meridional(const MerSurf* __re
                                                              int64_t nrays, const double* __restrict__ y_in,
                                                              const double* __restrict__ U_in,
                                                              double* __restrict__ y_out, double* __restrict__ U_out,
-                                                             double* __restrict__ ts_out, int64_t ld)
+                                                             double* __restrict__ ts_out, int64_t ld,
+                                                             unsigned long long* __restrict__ dom)
 {
     __shared__ MerSurf s_s[kMaxRows];
     __shared__ double s_c[kMaxRows * kMaxCoef];
@@ -735,7 +752,11 @@ __global__ __launch_bounds__(kBlock) void k_trace_meridional(const MerSurf* __re
     y_out[g] = y; U_out[g] = U;                                   // :150
     double sprev = 0.0;
     for (int i = 0; i < S; ++i) {
-        const double tsi = mer_step(s_s[i], s_c + i * ncoef, layout_mode, y, U, sprev);
+        bool domain = false;
+        const double tsi = mer_step(s_s[i], s_c + i * ncoef, layout_mode, y, U, sprev, domain);
+        // the reference's raytrace(...) of THIS ray would throw a DomainError here (asin of |y / R| > 1, :162): the
+        // first such (ray, surface) of the launch is recorded for the caller, the ray continues as NaN
+        if (domain && dom) { atomicMin(dom, ((unsigned long long)g << 8) | (unsigned)(i + 1)); atomicAdd(dom + 1, 1ull); }
         if (ts_out) ts_out[(int64_t)i * ld + g] = tsi;
         y_out[(int64_t)(i + 1) * ld + g] = y;                     // :165
         U_out[(int64_t)(i + 1) * ld + g] = U;                     // :166
@@ -778,8 +799,9 @@ __device__ inline MerEnd mer_trace_to(const MerSurf* __restrict__ surf, const do
     MerEnd e;
     e.y_stop = __builtin_nan(""); e.y_first = y;
     double sprev = 0.0, z = 0.0, zp = 0.0;
+    bool domain = false;                                         // (aiming traces: a NaN loss ends the Newton loop)
     for (int i = 0; i < S; ++i) {
-        const double tsi = mer_step(surf[i], coefs ? coefs + (int64_t)(i + 1) * ncoef : nullptr, layout_mode, y, U, sprev);
+        const double tsi = mer_step(surf[i], coefs ? coefs + (int64_t)(i + 1) * ncoef : nullptr, layout_mode, y, U, sprev, domain);
         zp = z; z = (i == 0) ? tsi : z + tsi;                    // cumsum(ts)  (Types.jl:61-63)
         if (i + 1 == stop_idx) e.y_stop = y;                     // ray.y[begin+stop]
         if (i == 0) e.y_first = y;                               // ray.y[2]

@@ -74,6 +74,7 @@ class HipEngine:
         self.ctx = Context(device, stream)
         self.base_flags = (_capi.ORT_FAST_MATH if fast_math else 0) | (0 if use_lds else _capi.ORT_NO_LDS)
         self._systems = OrderedDict()
+        self.last_domain_error = None
         self.cache_size = 32
 
     # ---- systems ---------------------------------------------------------------------
@@ -176,8 +177,15 @@ class HipEngine:
         yo = np.empty((rows, N)); Uo = np.empty((rows, N)); ts = np.empty((rows, N))
         flags = self.base_flags | (_capi.ORT_LAYOUT_INPUT if layout_mode else 0)
         sysd = self.system(pres)
-        check(self.ctx.lib.ort_trace_meridional_f64(self.ctx.h, sysd.h, isys, N, ptr(y), ptr(U),
-                                                    ptr(yo), ptr(Uo), ptr(ts), N, flags))
+        rc = self.ctx.lib.ort_trace_meridional_f64(self.ctx.h, sysd.h, isys, N, ptr(y), ptr(U),
+                                                   ptr(yo), ptr(Uo), ptr(ts), N, flags)
+        # ORT_EDOMAIN: Base.asin would have thrown for some ray (RayTracing.jl:162); the arrays are complete (those
+        # rays NaN): the message is kept for the host mirror, which raises the reference's DomainError
+        self.last_domain_error = None
+        if rc == _capi.ORT_EDOMAIN:
+            self.last_domain_error = self.ctx.lib.ort_last_error().decode("utf-8", "replace")
+        else:
+            check(rc)
         return yo, Uo, ts
 
     # ---- batched aiming: RayTracing.jl:223-296 + PupilSampling.jl:67-83,94-103 ------------

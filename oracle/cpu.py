@@ -51,6 +51,7 @@ def lib():
                                           _fp, _fp, _l, _ip, _i]
     L.orc_trace_skew_grid_f32.restype = _l
     L.orc_trace_meridional.argtypes = [_i, _dp, _dp, _dp, _dp, _dp, _i, _i, _d, _d, _dp, _dp, _dp]
+    L.orc_trace_meridional.restype = _i
     L.orc_lens_from_surfaces.argtypes = [_i, _dp, _dp, _dp, _dp, _dp]; L.orc_lens_from_surfaces.restype = _i
     L.orc_trace_paraxial.argtypes = [_i, _dp, _dp, _d, _d, _dp, _i, _dp, _dp]
     L.orc_abcd.argtypes = [_i, _dp, _dp, _dp]
@@ -146,6 +147,7 @@ class OracleEngine:
     def __init__(self, nthreads: int = 1):
         self.L = lib()
         self.nthreads = nthreads
+        self.last_domain_error = None
 
     def skew(self, pres, y, x, U, V, isys: int = 0, slopes: bool = False, want_status: bool = False):
         s = _Sys(pres, isys)
@@ -241,9 +243,12 @@ class OracleEngine:
         N, rows = y.size, s.rows
         yo = np.empty((rows, N)); Uo = np.empty((rows, N)); ts = np.empty((rows, N))
         by = np.empty(rows); bU = np.empty(rows); bt = np.empty(rows)
+        self.last_domain_error = None
         for r in range(N):
-            self.L.orc_trace_meridional(*s.args(), 1 if layout_mode else 0, float(y[r]), float(U[r]),
-                                        _p(by), _p(bU), _p(bt))
+            dom = self.L.orc_trace_meridional(*s.args(), 1 if layout_mode else 0, float(y[r]), float(U[r]),
+                                              _p(by), _p(bU), _p(bt))
+            if dom and self.last_domain_error is None:
+                self.last_domain_error = f"DomainError: asin(x) is not defined for |x| > 1: ray {r} at surface row {dom}"
             yo[:, r], Uo[:, r], ts[:, r] = by, bU, bt
         return yo, Uo, ts
 

@@ -155,11 +155,12 @@ static double tilt2(double y, double R, double K, const double *c, int ncoef)
 }
 
 /* src/RayTracing.jl:145-169 */
-void orc_trace_meridional(int rows, const double *R, const double *t, const double *n,
-                          const double *K, const double *coef, int ncoef,
-                          int layout_mode, double y, double U,
-                          double *y_out, double *U_out, double *ts_out)
+int orc_trace_meridional(int rows, const double *R, const double *t, const double *n,
+                         const double *K, const double *coef, int ncoef,
+                         int layout_mode, double y, double U,
+                         double *y_out, double *U_out, double *ts_out)
 {
+    int domain = 0;   /* 1-based row of the first asin(x), |x| > 1: Base.asin throws a DomainError there (:162) */
     double ts[ORC_MAX_ROWS];
     for (int i = 0; i < rows; ++i) ts[i] = t[i];              /* :148 */
     y_out[0] = y; U_out[0] = U;                               /* :150 */
@@ -173,9 +174,9 @@ void orc_trace_meridional(int rows, const double *R, const double *t, const doub
         ts[i] += s;                                           /* :160 */
         ts[i + 1] -= s;                                       /* :161 */
         /* :162 — asin(y/R) iff K == 0 and p is the function `zero` itself (Q16).
-         * Base.asin throws DomainError for |arg| > 1; C returns NaN (not reproduced). */
+         * Base.asin throws DomainError for |arg| > 1; C returns NaN: the row is reported through the return value. */
         double theta;
-        if (Ks == 0.0 && !layout_mode && !ps) theta = asin(y / Rs);
+        if (Ks == 0.0 && !layout_mode && !ps) { if (fabs(y / Rs) > 1.0 && !domain) domain = i + 1; theta = asin(y / Rs); }
         else                                  theta = atan(tilt2(y, Rs, Ks, ps, ncoef));
         double sin_ip = n[i] * sin(U + theta) / n[i + 1];     /* :163 */
         U = fabs(sin_ip) <= 1.0 ? asin(sin_ip) - theta : NAN; /* :164 */
@@ -183,6 +184,7 @@ void orc_trace_meridional(int rows, const double *R, const double *t, const doub
         U_out[i + 1] = U;                                     /* :166 */
     }
     if (ts_out) for (int i = 0; i < rows; ++i) ts_out[i] = ts[i];
+    return domain;
 }
 
 /* ---- paraxial ----------------------------------------------------------------------- */

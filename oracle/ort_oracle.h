@@ -74,10 +74,12 @@ int64_t orc_trace_skew_grid(int rows, const double *R, const double *t, const do
 /* src/RayTracing.jl:145-169 — one meridional ray.  y_out, U_out, ts_out: rows entries
  * (row 0 = input ray; ts_out = per-ray distances, z = cumsum(ts) per Types.jl:61-63).
  * layout_mode != 0 reproduces Layout input (p never ≡ zero -> always atan, Q16).     */
-void orc_trace_meridional(int rows, const double *R, const double *t, const double *n,
-                          const double *K, const double *coef, int ncoef,
-                          int layout_mode, double y, double U,
-                          double *y_out, double *U_out, double *ts_out);
+/* Returns 0, or the 1-based row of the first asin(y / R) with |y / R| > 1, where Base.asin throws a DomainError
+ * (:162) and this restatement continues with NaN.                                                           */
+int orc_trace_meridional(int rows, const double *R, const double *t, const double *n,
+                         const double *K, const double *coef, int ncoef,
+                         int layout_mode, double y, double U,
+                         double *y_out, double *U_out, double *ts_out);
 
 /* src/RayTracing.jl:38-53 — Lens(surfaces).  MUTATES t[0] like the reference (Q19).
  * tau, phi need `rows` entries; returns k = number of lens rows kept.                */

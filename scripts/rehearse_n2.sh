@@ -1,11 +1,9 @@
 #!/bin/bash
-# GPU box (1 GPU): rehearsal of the N = 2 launch path with the gloo backend (both ranks on cuda:0).
+# GPU box (1 GPU): rehearsal of the N = 2 launch path of bench.py — BASELINE config 4 sharded over the ranks with the
+# all-gather inside the timed region — with the gloo backend (both ranks on cuda:0, the collective on CPU tensors), at
+# reduced size, including rank 0's bit-for-bit check of the gathered hits against its own single-rank trace.
 cd /root/repo
 export ORT_BENCH_BACKEND=gloo
-timeout -k 10 300 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29533 bench.py --gpus 2 --steps 5 --warmup 2 --pupil 512 > gpurun_out/rehearse_n2.log 2>&1
+timeout -k 10 400 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29533 bench.py --gpus 2 --steps 3 --warmup 1 --zoom 4 --pupil4 256 > gpurun_out/rehearse_n2.log 2>&1
 echo "rc=$?" >> gpurun_out/rehearse_n2.log
-tail -5 gpurun_out/rehearse_n2.log
-# config 4 driver, 2 ranks, gloo, reduced size, with the bit-for-bit check against the single-rank trace
-timeout -k 10 300 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29544 scripts/zoom_sweep_dist.py --pupil 128 --zoom 8 --check > gpurun_out/rehearse_zoom_n2.log 2>&1
-echo "rc=$?" >> gpurun_out/rehearse_zoom_n2.log
-tail -6 gpurun_out/rehearse_zoom_n2.log
+tail -c 2500 gpurun_out/rehearse_n2.log
