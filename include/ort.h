@@ -57,6 +57,10 @@ extern "C" {
 #define ORT_FAST_MATH     (1u << 5) /* fused/reciprocal arithmetic, |rel err| << 1e-10; default is
                                        the op-for-op IEEE sequence of the reference loop */
 #define ORT_NO_LDS        (1u << 6) /* read the surface table through scalar loads, not LDS */
+#define ORT_FT_LOOKBACK   (1u << 7) /* full_trace: the trace kernel writes the survivors' first half at its final place
+                                       (decoupled look-back over the bundle's tiles) instead of staging compacted tiles in
+                                       a workspace: 82 instead of 100 B/ray of HBM traffic, but tiles wait for their
+                                       predecessors' counts — slower whenever the trace is VALU-bound */
 
 #define ORT_STATUS_STOPPED (1 << 16)
 #define ORT_STATUS_VIGNETTED (1 << 17)                /* ort_system_set_apertures: outside a clear aperture */

@@ -462,34 +462,52 @@ int run_full_trace(ort_ctx* ctx, TraceParams<T>& p, int nb, T* ex, T* ey, T* rho
         rc = dev_out<T>(ctx, SL_OUT2, (size_t)2 * N, &drho); if (rc) return rc;
         rc = dev_out<T>(ctx, SL_OUT4, (size_t)2 * N, &dth); if (rc) return rc;
     }
-    // look-back state: one 8-byte word per tile + the ticket counter; zero-filled when (re)allocated only — the
-    // epoch tells the words of this launch from older ones, the base does the same for tickets
-    rc = dev_out<unsigned long long>(ctx, SL_FTSTATE, (size_t)tiles, &p.ft_state); if (rc) return rc;
-    if (ctx->slot[SL_FTSTATE].cap != ctx->ft_state_cap) {
-        HIP_TRY(hipMemsetAsync(p.ft_state, 0, ctx->slot[SL_FTSTATE].cap, ctx->stream));
-        ctx->ft_state_cap = ctx->slot[SL_FTSTATE].cap;
+    if (!(flags & ORT_FT_LOOKBACK)) {
+        // default route: tile-local compaction into a workspace | tile offsets + bundle aggregates | placement of the
+        // survivors in both halves + squared deviations | sigma.  No workgroup waits for another.
+        T *wex, *wey, *wr, *wth; int64_t* tile_off;
+        rc = dev_out<T>(ctx, SL_WEX, (size_t)N, &wex); if (rc) return rc;
+        rc = dev_out<T>(ctx, SL_WEY, (size_t)N, &wey); if (rc) return rc;
+        rc = dev_out<T>(ctx, SL_WR, (size_t)N, &wr); if (rc) return rc;
+        rc = dev_out<T>(ctx, SL_WTH, (size_t)N, &wth); if (rc) return rc;
+        rc = dev_out<int64_t>(ctx, SL_TOFF, (size_t)tiles, &tile_off); if (rc) return rc;
+        p.out_ex = wex; p.out_ey = wey; p.out_r = wr; p.out_th = wth;
+        rc = launch_trace<T, true, false, false, FT_FULL>(ctx, p, tiles, flags); if (rc) return rc;
+        hipLaunchKernelGGL(k_ft_scan, dim3((unsigned)nb), dim3(kBlock), 0, ctx->stream,
+                           p.tile_cnt, p.tile_sx, p.tile_sy, p.tile_rmax, p.tiles_per_bundle, tile_off, agg);
+        HIP_TRY(hipGetLastError());
+        hipLaunchKernelGGL((k_ft_place<T>), dim3((unsigned)tiles), dim3(kBlock), 0, ctx->stream,
+                           wex, wey, wr, wth, rpb, p.tiles_per_bundle, p.tile_cnt, tile_off, agg, dex, dey, drho, dth, chunk_sq);
+        HIP_TRY(hipGetLastError());
+    } else {
+        // ORT_FT_LOOKBACK: the trace kernel writes the first half itself.  Look-back state: one 8-byte word per tile +
+        // the ticket counter; zero-filled when (re)allocated only — the epoch tells the words of this launch from
+        // older ones, the base does the same for tickets
+        rc = dev_out<unsigned long long>(ctx, SL_FTSTATE, (size_t)tiles, &p.ft_state); if (rc) return rc;
+        if (ctx->slot[SL_FTSTATE].cap != ctx->ft_state_cap) {
+            HIP_TRY(hipMemsetAsync(p.ft_state, 0, ctx->slot[SL_FTSTATE].cap, ctx->stream));
+            ctx->ft_state_cap = ctx->slot[SL_FTSTATE].cap;
+        }
+        if (!ctx->slot[SL_FTTICKET].p) {
+            rc = dev_out<unsigned long long>(ctx, SL_FTTICKET, 1, &p.ft_ticket); if (rc) return rc;
+            HIP_TRY(hipMemsetAsync(p.ft_ticket, 0, sizeof(unsigned long long), ctx->stream));
+            ctx->ft_ticket_base = 0;
+        }
+        p.ft_ticket = static_cast<unsigned long long*>(ctx->slot[SL_FTTICKET].p);
+        ctx->ft_epoch = (ctx->ft_epoch + 1) & 0x3fffffffu;
+        if (ctx->ft_epoch == 0) ctx->ft_epoch = 1;
+        p.ft_epoch = ctx->ft_epoch;
+        p.ft_ticket_base = ctx->ft_ticket_base;
+        ctx->ft_ticket_base += (unsigned long long)tiles;
+        p.out_ex = dex; p.out_ey = dey; p.out_r = drho; p.out_th = dth;
+        rc = launch_trace<T, true, false, false, FT_LOOKBACK>(ctx, p, tiles, flags); if (rc) return rc;
+        hipLaunchKernelGGL(k_ft_scan, dim3((unsigned)nb), dim3(kBlock), 0, ctx->stream,
+                           p.tile_cnt, p.tile_sx, p.tile_sy, p.tile_rmax, p.tiles_per_bundle, (int64_t*)nullptr, agg);
+        HIP_TRY(hipGetLastError());
+        hipLaunchKernelGGL((k_ft_mirror<T>), dim3((unsigned)tiles), dim3(kBlock), 0, ctx->stream,
+                           rpb, p.tiles_per_bundle, agg, dex, dey, drho, dth, chunk_sq);
+        HIP_TRY(hipGetLastError());
     }
-    if (!ctx->slot[SL_FTTICKET].p) {
-        rc = dev_out<unsigned long long>(ctx, SL_FTTICKET, 1, &p.ft_ticket); if (rc) return rc;
-        HIP_TRY(hipMemsetAsync(p.ft_ticket, 0, sizeof(unsigned long long), ctx->stream));
-        ctx->ft_ticket_base = 0;
-    }
-    p.ft_ticket = static_cast<unsigned long long*>(ctx->slot[SL_FTTICKET].p);
-    ctx->ft_epoch = (ctx->ft_epoch + 1) & 0x3fffffffu;
-    if (ctx->ft_epoch == 0) ctx->ft_epoch = 1;
-    p.ft_epoch = ctx->ft_epoch;
-    p.ft_ticket_base = ctx->ft_ticket_base;
-    ctx->ft_ticket_base += (unsigned long long)tiles;
-    p.out_ex = dex; p.out_ey = dey; p.out_r = drho; p.out_th = dth;
-    // trace + stop filter + ordered compaction of the first half | bundle aggregates | rho, mirror half, squared
-    // deviations (survivors only) | sigma
-    rc = launch_trace<T, true, false, false, FT_FULL>(ctx, p, tiles, flags); if (rc) return rc;
-    hipLaunchKernelGGL(k_ft_scan, dim3((unsigned)nb), dim3(kBlock), 0, ctx->stream,
-                       p.tile_cnt, p.tile_sx, p.tile_sy, p.tile_rmax, p.tiles_per_bundle, agg);
-    HIP_TRY(hipGetLastError());
-    hipLaunchKernelGGL((k_ft_mirror<T>), dim3((unsigned)tiles), dim3(kBlock), 0, ctx->stream,
-                       rpb, p.tiles_per_bundle, agg, dex, dey, drho, dth, chunk_sq);
-    HIP_TRY(hipGetLastError());
     hipLaunchKernelGGL(k_ft_finalize, dim3((unsigned)nb), dim3(kBlock), 0, ctx->stream,
                        chunk_sq, p.tiles_per_bundle, agg, dcount, drms);
     HIP_TRY(hipGetLastError());

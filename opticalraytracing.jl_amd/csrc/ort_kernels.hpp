@@ -86,9 +86,9 @@ struct TraceParams {
     T* xv; T* yv; int64_t ld;
     T* xf; T* yf; T* xs; T* ys;
     int32_t* status;
-    // full_trace (FT_FULL): the first half of the error vectors is written by the trace kernel itself —
-    // out_* = caller's ex / ey / rho / theta, [nb][2*rpb]; rho holds the UN-normalised stop radius until
-    // k_ft_mirror divides it — at an offset found by a decoupled look-back over the bundle's tiles
+    // full_trace: where the trace kernel puts a tile's compacted survivors (ex, ey, UN-normalised stop radius, theta).
+    // FT_FULL: out_* = workspace [N], tile t of bundle b at b*rpb + t*kTile.  FT_LOOKBACK: out_* = the caller's
+    // ex / ey / rho / theta [nb][2*rpb], at the offset found by a decoupled look-back over the bundle's tiles
     T* out_ex; T* out_ey; T* out_r; T* out_th;
     unsigned long long* ft_state;       // [tiles] look-back words: state (2 bits) | epoch (30 bits) | prefix (32 bits)
     unsigned long long* ft_ticket;      // tiles are taken in ticket order: every predecessor of a tile has started
@@ -152,10 +152,16 @@ __device__ __forceinline__ void load_rec(SurfRec<T>& d, const __attribute__((add
 // ------------------------------------------------------------------------------------
 // The hot kernel.  GRID: rays generated from bundle axes; otherwise read from lists.
 // HIST: write per-surface history.  SUMM: write image/stop hits + status.
-// FT: full_trace epilogue.  FT_FULL = stop filter + dense workspace + tile aggregates (survivors are
-// compacted by k_ft_scatter); FT_STATS = stop filter + per-tile (count, mean, M2, max r) only —
-// nothing ray-sized is written: the statistics-only route of ort_full_trace_f64.
-enum { FT_NONE = 0, FT_FULL = 1, FT_STATS = 2 };
+// FT: full_trace epilogue.  The stop filter and an order-preserving compaction of the tile's survivors (wave
+// ballot + popcount prefix, wave offsets through LDS) run in this kernel; where the compacted tile goes is the mode:
+//   FT_FULL      to the tile's own slot of a workspace [N]; k_ft_scan turns the tile counts into offsets and
+//                k_ft_place moves the survivors (25 B/ray read) to both halves of the output — no workgroup waits
+//                for another (the default: fastest measured);
+//   FT_LOOKBACK  straight to its final position in the first half, found by a decoupled look-back over the
+//                bundle's earlier tiles (tiles taken in ticket order); k_ft_mirror adds the second half — least
+//                HBM traffic (82 vs 100 B/ray), but every tile waits for its predecessors' counts (ORT_FT_LOOKBACK);
+//   FT_STATS     per-tile (count, mean, M2, max r) only — nothing ray-sized is written: the statistics-only route.
+enum { FT_NONE = 0, FT_FULL = 1, FT_STATS = 2, FT_LOOKBACK = 3 };
 constexpr int kStatusVignetted = 1 << 17, kStatusVigShift = 20;
 // ------------------------------------------------------------------------------------
 template <typename T, int MATH, bool USE_LDS, bool GRID, bool HIST, bool SUMM, int FT>
@@ -168,10 +174,11 @@ __global__ __launch_bounds__(kBlock, (HIST && SUMM) ? ORT_MIN_WAVES - 1 : ORT_MI
 
     const int tid = threadIdx.x;
     const int S = p.S;
-    // FT_FULL: the tile index is a TICKET, not blockIdx — the look-back below waits on tiles with lower indices,
+    // FT_LOOKBACK: the tile index is a TICKET, not blockIdx — the look-back below waits on tiles with lower indices,
     // and a ticket order guarantees they are running or done whatever order the hardware dispatches blocks in
+    constexpr bool kCompact = FT == FT_FULL || FT == FT_LOOKBACK;
     __shared__ unsigned s_bid;
-    if (FT == FT_FULL) {
+    if (FT == FT_LOOKBACK) {
         if (tid == 0) {
 #if ORT_FT_DEBUG & 2            /* A/B only: blockIdx order instead of tickets (no progress guarantee) */
             unsigned long long tk = blockIdx.x;
@@ -187,7 +194,7 @@ __global__ __launch_bounds__(kBlock, (HIST && SUMM) ? ORT_MIN_WAVES - 1 : ORT_MI
         }
         __syncthreads();
     }
-    const unsigned bid = (FT == FT_FULL) ? s_bid : blockIdx.x;
+    const unsigned bid = (FT == FT_LOOKBACK) ? s_bid : blockIdx.x;
     int sysid, b = 0;
     int64_t j0;          // first ray of this thread inside its bundle / list
     int64_t gbase;       // global index of ray j0
@@ -396,7 +403,7 @@ __global__ __launch_bounds__(kBlock, (HIST && SUMM) ? ORT_MIN_WAVES - 1 : ORT_MI
             const bool drop = (ri > a_stop) || t_isnan(xf) || t_isnan(yf) || !live[r] ||   // :132
                               (st[r] & kStatusVignetted);
             keep[r] = !drop;
-            if (FT == FT_FULL) thv[r] = dev_atan2(ys_[r], xs_[r]);   // :133
+            if (kCompact) thv[r] = dev_atan2(ys_[r], xs_[r]);          // :133
             eyv[r] = yf - hprime;                                    // :134
             exv[r] = xf;                                             // :135
             rv[r] = drop ? T(-1) : ri;                               // :136, -1 marks a dropped ray
@@ -404,7 +411,7 @@ __global__ __launch_bounds__(kBlock, (HIST && SUMM) ? ORT_MIN_WAVES - 1 : ORT_MI
         }
         const int lane = tid & 63, wave = tid >> 6;
         int rank0 = 0;
-        if (FT == FT_FULL) {
+        if (kCompact) {
             const unsigned long long m0 = __ballot(keep[0]);
             const unsigned long long m1 = (kRPT > 1) ? __ballot(keep[kRPT - 1]) : 0ull;
             const unsigned long long lt = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
@@ -419,9 +426,8 @@ __global__ __launch_bounds__(kBlock, (HIST && SUMM) ? ORT_MIN_WAVES - 1 : ORT_MI
         }
         if (lane == 0) { s_wcnt[wave] = cnt; s_wsx[wave] = sx; s_wsy[wave] = sy; s_wmax[wave] = rmax; }
         __syncthreads();
-        if (FT == FT_FULL) {
-            __shared__ T s_cx[FT == FT_FULL ? kTile : 1], s_cy[FT == FT_FULL ? kTile : 1], s_cr[FT == FT_FULL ? kTile : 1],
-                         s_ct[FT == FT_FULL ? kTile : 1];
+        if (kCompact) {
+            __shared__ T s_cx[kCompact ? kTile : 1], s_cy[kCompact ? kTile : 1], s_cr[kCompact ? kTile : 1], s_ct[kCompact ? kTile : 1];
             __shared__ long long s_base;
             int woff = 0, c = 0;
             for (int w = 0; w < kBlock / 64; ++w) { woff += (w < wave) ? s_wcnt[w] : 0; c += s_wcnt[w]; }
@@ -430,7 +436,13 @@ __global__ __launch_bounds__(kBlock, (HIST && SUMM) ? ORT_MIN_WAVES - 1 : ORT_MI
             for (int r = 0; r < kRPT; ++r)
                 if (keep[r]) { s_cx[k] = exv[r]; s_cy[k] = eyv[r]; s_cr[k] = rv[r]; s_ct[k] = thv[r]; ++k; }
             const int tile = (int)(bid - (unsigned)b * (unsigned)p.tiles_per_bundle);
-            if (wave == 0) {
+            if (FT == FT_FULL) {
+                if (tid == 0) {
+                    double ax = 0.0, ay = 0.0, mx = -1.0;
+                    for (int w = 0; w < kBlock / 64; ++w) { ax += s_wsx[w]; ay += s_wsy[w]; mx = fmax(mx, s_wmax[w]); }
+                    p.tile_cnt[bid] = c; p.tile_sx[bid] = ax; p.tile_sy[bid] = ay; p.tile_rmax[bid] = mx;
+                }
+            } else if (wave == 0) {
                 // Exclusive offset of this tile among its bundle's survivors: decoupled look-back (Merrill & Garland) over
                 // the bundle's earlier tiles, 64 at a time.  One 8-byte word per tile carries everything, so relaxed
                 // agent-scope atomics suffice: state 1 = the tile's own count, state 2 = inclusive prefix.
@@ -487,7 +499,8 @@ __global__ __launch_bounds__(kBlock, (HIST && SUMM) ? ORT_MIN_WAVES - 1 : ORT_MI
                 }
             }
             __syncthreads();
-            const int64_t o0 = (int64_t)b * 2 * p.rpb + s_base;
+            // FT_FULL: the tile's slot of the workspace [N]; FT_LOOKBACK: its place in the bundle's output slab [2 rpb]
+            const int64_t o0 = (FT == FT_FULL) ? (int64_t)b * p.rpb + (int64_t)tile * kTile : (int64_t)b * 2 * p.rpb + s_base;
             for (int j = tid; j < c; j += kBlock) {
                 p.out_ex[o0 + j] = s_cx[j]; p.out_ey[o0 + j] = s_cy[j]; p.out_r[o0 + j] = s_cr[j]; p.out_th[o0 + j] = s_ct[j];
             }
@@ -576,8 +589,9 @@ __global__ __launch_bounds__(kBlock) void k_ft_stats_reduce(const int32_t* __res
 }
 
 // ------------------------------------------------------------------------------------
-// full_trace, stage B: per bundle, the aggregates of its tiles (count, centroid, max radius).
-// One workgroup per bundle; fixed-shape tree: bitwise reproducible.
+// full_trace, stage B: per bundle, exclusive scan of the tile survivor counts (tile_off, FT_FULL route; may be
+// null) and the bundle aggregates (count, centroid, max radius).  One workgroup per bundle; fixed shapes:
+// bitwise reproducible.
 // ------------------------------------------------------------------------------------
 struct FtBundleAgg {
     int64_t m;        // survivors (first half)
@@ -591,27 +605,46 @@ __global__ __launch_bounds__(kBlock) void k_ft_scan(const int32_t* __restrict__ 
                                                     const double* __restrict__ tile_sy,
                                                     const double* __restrict__ tile_rmax,
                                                     int tiles_per_bundle,
+                                                    int64_t* __restrict__ tile_off,
                                                     FtBundleAgg* __restrict__ agg)
 {
-    __shared__ long long s_rc[kBlock];
+    __shared__ int64_t s_w[kBlock / 64];
+    __shared__ int64_t s_carry;
     __shared__ double s_rx[kBlock], s_ry[kBlock], s_rm[kBlock];
-    const int b = blockIdx.x, tid = threadIdx.x;
+    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int64_t base = (int64_t)b * tiles_per_bundle;
-    long long ac = 0; double ax = 0.0, ay = 0.0, mx = -1.0;
-    for (int t = tid; t < tiles_per_bundle; t += kBlock) {
-        ac += tile_cnt[base + t]; ax += tile_sx[base + t]; ay += tile_sy[base + t]; mx = fmax(mx, tile_rmax[base + t]);
+    if (tid == 0) s_carry = 0;
+    double ax = 0.0, ay = 0.0, mx = -1.0;
+    __syncthreads();
+    for (int t0 = 0; t0 < tiles_per_bundle; t0 += kBlock) {
+        const int t = t0 + tid;
+        const int64_t c = (t < tiles_per_bundle) ? tile_cnt[base + t] : 0;
+        if (t < tiles_per_bundle) { ax += tile_sx[base + t]; ay += tile_sy[base + t]; mx = fmax(mx, tile_rmax[base + t]); }
+        // inclusive wave scan
+        int64_t v = c;
+        for (int off = 1; off < 64; off <<= 1) {
+            const int64_t nb = __shfl_up(v, off);
+            if (lane >= off) v += nb;
+        }
+        if (lane == 63) s_w[wave] = v;
+        __syncthreads();
+        int64_t woff = 0;
+        for (int w = 0; w < wave; ++w) woff += s_w[w];
+        const int64_t carry = s_carry;
+        if (tile_off && t < tiles_per_bundle) tile_off[base + t] = carry + woff + v - c;
+        __syncthreads();
+        if (tid == kBlock - 1) s_carry = carry + woff + v;
+        __syncthreads();
     }
-    s_rc[tid] = ac; s_rx[tid] = ax; s_ry[tid] = ay; s_rm[tid] = mx;
+    // deterministic tree over the 256 per-thread partials
+    s_rx[tid] = ax; s_ry[tid] = ay; s_rm[tid] = mx;
     __syncthreads();
     for (int off = kBlock / 2; off > 0; off >>= 1) {
-        if (tid < off) {
-            s_rc[tid] += s_rc[tid + off]; s_rx[tid] += s_rx[tid + off]; s_ry[tid] += s_ry[tid + off];
-            s_rm[tid] = fmax(s_rm[tid], s_rm[tid + off]);
-        }
+        if (tid < off) { s_rx[tid] += s_rx[tid + off]; s_ry[tid] += s_ry[tid + off]; s_rm[tid] = fmax(s_rm[tid], s_rm[tid + off]); }
         __syncthreads();
     }
     if (tid == 0) {
-        const int64_t m = s_rc[0];
+        const int64_t m = s_carry;
         FtBundleAgg a;
         a.m = m;
         // mean of [ex; -ex] and of [ey; ey] over n = 2m entries
@@ -624,7 +657,55 @@ __global__ __launch_bounds__(kBlock) void k_ft_scan(const int32_t* __restrict__ 
 }
 
 // ------------------------------------------------------------------------------------
-// full_trace, stage C: survivors only.  The first half (written by the trace kernel) is read once; rho is
+// full_trace, stage C of the FT_FULL route: one workgroup per tile moves the tile's compacted survivors from its
+// workspace slot to both halves of the bundle's output slab — first half at the tile's exclusive offset (ray
+// order, :134-137), mirror [-ex; ey; rho; pi - theta] at offset m (:139-144), rho = r / maximum(r) (:142) — and
+// sums the squared deviations about the centroid (two-pass sigma, :169-173).  25 B/ray read, 50 B/ray written.
+// ------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(kBlock) void k_ft_place(const T* __restrict__ w_ex, const T* __restrict__ w_ey,
+                                                     const T* __restrict__ w_r, const T* __restrict__ w_th,
+                                                     int64_t rpb, int tiles_per_bundle,
+                                                     const int32_t* __restrict__ tile_cnt, const int64_t* __restrict__ tile_off,
+                                                     const FtBundleAgg* __restrict__ agg,
+                                                     T* __restrict__ ex, T* __restrict__ ey,
+                                                     T* __restrict__ rho, T* __restrict__ theta,
+                                                     double* __restrict__ tile_sq)
+{
+    __shared__ double s_wsq[kBlock / 64];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int b = blockIdx.x / tiles_per_bundle;
+    const int tile = blockIdx.x - b * tiles_per_bundle;
+    const int c = tile_cnt[blockIdx.x];
+    const FtBundleAgg a = agg[b];
+    const int64_t src = (int64_t)b * rpb + (int64_t)tile * kTile;
+    const int64_t dst = (int64_t)b * 2 * rpb + tile_off[blockIdx.x];
+    double sq = 0.0;
+    for (int j = tid; j < c; j += kBlock) {
+        const T vx = w_ex[src + j], vy = w_ey[src + j], vt = w_th[src + j];
+        const T vr = w_r[src + j] / (T)a.rmax;                            // :142
+        const int64_t o = dst + j;
+        ex[o] = vx;  ey[o] = vy;  rho[o] = vr;  theta[o] = vt;
+        ex[o + a.m] = -vx;                                                // :141
+        ey[o + a.m] = vy;                                                 // :140
+        rho[o + a.m] = vr;                                                // :143
+        theta[o + a.m] = (T)3.141592653589793 - vt;                       // :144
+        const double dx1 = (double)vx - a.mux, dx2 = -(double)vx - a.mux;
+        const double dy = (double)vy - a.muy;
+        sq += (dx1 * dx1 + dx2 * dx2) + (dy * dy + dy * dy);
+    }
+    for (int off = 32; off > 0; off >>= 1) sq += __shfl_down(sq, off);
+    if (lane == 0) s_wsq[wave] = sq;
+    __syncthreads();
+    if (tid == 0) {
+        double t = 0.0;
+        for (int w = 0; w < kBlock / 64; ++w) t += s_wsq[w];
+        tile_sq[blockIdx.x] = t;
+    }
+}
+
+// ------------------------------------------------------------------------------------
+// full_trace, stage C of the FT_LOOKBACK route: survivors only.  The first half (written by the trace kernel) is read once; rho is
 // normalised in place (r ./ maximum(r), :142), the mirrored half [-ex; ey; rho; pi - theta] goes to offset m
 // (:139-144), and the squared deviations about the centroid are summed per chunk (two-pass sigma, :169-173).
 // Grid: nb * chunks_per_bundle blocks of kTile entries; chunks beyond the bundle's m survivors leave at once.

@@ -107,12 +107,13 @@ def test_grid_cooke_config1_bitexact(hip_engine, oracle_engine, H):
     for key in ("xv", "yv", "xf", "yf", "xs", "ys"):
         assert np.array_equal(g[key], o[key], equal_nan=True), key
     assert np.array_equal(g["status"], o["status"])
-    gf = hip_engine.full_trace_grid(pres, [b], axes, 64, 32)[0]
     of = oracle_engine.full_trace_grid(pres, [b], axes, 64, 32)[0]
-    assert gf["count"] == of["count"] > 0
-    assert np.array_equal(gf["ex"], of["ex"]) and np.array_equal(gf["ey"], of["ey"])
-    assert cm.rel_err(gf["rho"], of["rho"], 1e-3).max() <= TOL and cm.rel_err(gf["theta"], of["theta"], 1e-3).max() <= TOL
-    assert abs(gf["rms"] - of["rms"]) <= TOL * of["rms"]
+    for lookback in (False, True):                              # both compaction routes
+        gf = hip_engine.full_trace_grid(pres, [b], axes, 64, 32, lookback=lookback)[0]
+        assert gf["count"] == of["count"] > 0
+        assert np.array_equal(gf["ex"], of["ex"]) and np.array_equal(gf["ey"], of["ey"])
+        assert cm.rel_err(gf["rho"], of["rho"], 1e-3).max() <= TOL and cm.rel_err(gf["theta"], of["theta"], 1e-3).max() <= TOL
+        assert abs(gf["rms"] - of["rms"]) <= TOL * of["rms"]
 
 
 def test_grid_double_gauss_config2_small(hip_engine, oracle_engine):
@@ -812,7 +813,7 @@ def test_random_bundles_grid_and_full_trace(hip_engine, oracle_engine):
         for key in ("xv", "yv", "xf", "yf", "xs", "ys"):
             assert np.array_equal(g[key], o[key], equal_nan=True), (case, key)
         assert np.array_equal(g["status"], o["status"]), case
-        gf = hip_engine.full_trace_grid(pres, bundles, axes, ny, nx)
+        gf = hip_engine.full_trace_grid(pres, bundles, axes, ny, nx, lookback=bool(case & 1))   # both compaction routes
         of = oracle_engine.full_trace_grid(pres, bundles, axes, ny, nx)
         for a, b in zip(gf, of):
             assert a["count"] == b["count"], case
