@@ -311,6 +311,22 @@ def bench_single(args, torch, rank, world, local_rank):
             "pipeline_ms": ms, "value": N3 * S3 / (ms * 1e-3), "bound": "FP64 VALU", "mean_rms": float(rms.mean().item())}
         del ex, ey, rho, th
         torch.cuda.empty_cache()
+        # BASELINE config 5: Seidel / spot Monte-Carlo over perturbed instances, Float32 pupil trace, ONE C call
+        from opticalraytracing_jl_amd import batch
+        ninst, k5 = args.instances5, 256
+        mats5 = workloads.config5(api, ninst=ninst)
+        batch.spot_batch(mats5[:64], workloads.DG_A, workloads.DG_H, (0.0, 1.0), k5, engine=eng, dtype=np.float32)   # allocations
+        t0 = time.perf_counter()
+        r5 = batch.spot_batch(mats5, workloads.DG_A, workloads.DG_H, (0.0, 1.0), k5, engine=eng, dtype=np.float32)
+        dt5 = time.perf_counter() - t0
+        rays5 = ninst * 2 * k5 * (k5 // 2)
+        extra["config5_spot_batch_f32"] = {
+            "workload": f"BASELINE config 5: {ninst} perturbed Double-Gauss instances x 2 fields x {k5}x{k5 // 2} half pupil (mirrored, "
+                        f"reference mode), Float32 trace, first-order solve + Seidel sums + aiming + spot RMS per instance in ONE "
+                        f"C call (ort_spot_batch_f32), host arrays in, 16 B per (instance, field) out",
+            "rays": rays5, "intersections": rays5 * 12, "wall_ms": dt5 * 1e3, "value": rays5 * 12 / dt5,
+            "rms_mean": float(np.nanmean(r5["rms"])), "count_mean": float(r5["count"].mean()),
+            "bound": "FP32 VALU; wall time of the whole call incl. the H2D of the prescriptions and the D2H of the results"}
 
     traffic, traffic_source = None, None
     tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
@@ -526,6 +542,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--pupil", type=int, default=1024, help="N = 1: pupil grid edge per bundle (config 2: 1024)")
     ap.add_argument("--pupil3", type=int, default=2048, help="N = 1 extras: pupil edge of the config-3 full_trace run")
+    ap.add_argument("--instances5", type=int, default=10000, help="N = 1 extras: instances of the config-5 Monte-Carlo run")
     ap.add_argument("--pupil4", type=int, default=512, help="N > 1: pupil edge of the zoom sweep (config 4: 512)")
     ap.add_argument("--zoom", type=int, default=32, help="N > 1: zoom positions (config 4: 32)")
     ap.add_argument("--policy", default="fast", choices=["fast", "ieee"],

@@ -117,35 +117,13 @@ def tolerance_run(mats: np.ndarray, a, hprime, fields: Sequence[float] = (0.0,),
     R, t, n = mats[:, :, 0], mats[:, :, 1].copy(), mats[:, :, 2]
     t[:, 0] = np.where(np.isfinite(t[:, 0]), t[:, 0], 0.0)                      # Lens() mutation (Q19)
     BFD = fo["BFD"]
-    # forward / reversed prescriptions (RayTracing.jl:267-277; K, p are zero here)
-    fwd = Prescription(R, t, n)
-    rev_R = -np.concatenate([np.full((ninst, 1), math.inf), R[:, :0:-1]], axis=1)
-    rev_t = t[:, ::-1].copy(); rev_t[:, 0] = BFD
-    rev_n = n[:, ::-1].copy()
-    rev = Prescription(rev_R, rev_t, rev_n, np.zeros_like(rev_R))
-    # aiming: four lanes per (instance, field)
+    # aiming: four lanes per (instance, field), forward / reversed prescriptions built by aim_instances
     na = ninst * nf
-    ain = (_capi.ort_aim_in * na)()
-    dt_in = np.dtype([("system", np.int32), ("stop", np.int32), ("layout_fwd", np.int32), ("layout_rev", np.int32),
-                      ("H", np.float64), ("y_marg", np.float64), ("a_stop", np.float64), ("chief_y_end", np.float64),
-                      ("chief_u_end", np.float64), ("f", np.float64), ("atol", np.float64)])
-    spec = np.frombuffer(ain, dtype=dt_in, count=na)
     inst = np.repeat(np.arange(ninst, dtype=np.int32), nf)
     stop = fo["stop"][inst]
-    spec["system"] = inst; spec["stop"] = stop; spec["layout_fwd"] = 0; spec["layout_rev"] = 1
-    spec["H"] = np.tile(fields, ninst); spec["y_marg"] = fo["y_marg"][inst]
     a_stop = a_arr[inst, stop - 1]
-    spec["a_stop"] = a_stop; spec["chief_y_end"] = fo["chief_y_end"][inst]; spec["chief_u_end"] = fo["chief_u_end"][inst]
-    spec["f"] = fo["f"][inst]; spec["atol"] = EPS
-    aout = (_capi.ort_aim_out * na)()
-    _mark("aim specs (numpy)")
-    sf, sr = eng.system(fwd), eng.system(rev)
-    _mark("upload forward + reversed tables")
-    _capi.check(eng.ctx.lib.ort_aim_f64(eng.ctx.h, sf.h, sr.h, na, ain, aout, eng.base_flags))
-    _mark("aim kernel call")
-    dt_out = np.dtype([(k, np.float64) for k in ("U", "y1", "y2", "y_EP", "hprime", "EP_t", "Ubar", "XP_t")] +
-                      [("iters", np.int32), ("ok", np.int32)])
-    aim = np.frombuffer(aout, dtype=dt_out, count=na)
+    aim = {key: v.reshape(-1) for key, v in aim_instances(mats, a_arr, hprime, fields, engine=eng, fo=fo).items()}
+    _mark("aiming (tables + kernel)")
     if not np.all(aim["ok"] == 1):
         raise RuntimeError(f"ray aiming did not converge for {int(np.sum(aim['ok'] != 1))} (instance, field) pairs")
     # extended prescriptions (PupilSampling.jl:111-114) and the pupil grids (:121-122)

@@ -1,15 +1,23 @@
 #!/bin/bash
-# GPU box: the judged artefacts — default bench line, rocprofv3 --kernel-trace --stats of the SAME
-# command, and the HBM-traffic PMC passes (FETCH_SIZE / WRITE_SIZE in separate runs, counters only).
+# GPU box: the judged artefacts — the driver's bench command, rocprofv3 --kernel-trace --stats of the SAME command, the
+# HBM-traffic PMC passes (FETCH_SIZE / WRITE_SIZE in separate runs, counters only) for the history kernel in both policies
+# and for the two full_trace routes, and SQ counters of the IEEE kernel.
 set -u
 cd /root/repo
 OUT=/root/repo/gpurun_out/final
 rm -rf $OUT; mkdir -p $OUT
-timeout -k 10 400 python bench.py > $OUT/bench.json 2> $OUT/bench.err || { tail -5 $OUT/bench.err; exit 1; }
+timeout -k 10 500 python bench.py --gpus 1 --steps 20 --warmup 5 > $OUT/bench.json 2> $OUT/bench.err || { tail -5 $OUT/bench.err; exit 1; }
 cd /tmp && export TMPDIR=/tmp
-timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -- python3 /root/repo/bench.py > $OUT/stats.log 2>&1 || { tail -5 $OUT/stats.log; exit 1; }
+timeout -k 10 500 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -- python3 /root/repo/bench.py --gpus 1 --steps 20 --warmup 5 > $OUT/stats.log 2>&1 || { tail -5 $OUT/stats.log; exit 1; }
+Q="--steps 5 --warmup 1 --no-cpu-baseline --no-extras --no-verify --sustain-s 0"
 for pol in fast ieee; do
-  timeout -k 10 300 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/fetch_$pol -- python3 /root/repo/bench.py --steps 5 --warmup 1 --no-cpu-baseline --policy $pol > $OUT/fetch_$pol.log 2>&1 || exit 1
-  timeout -k 10 300 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/write_$pol -- python3 /root/repo/bench.py --steps 5 --warmup 1 --no-cpu-baseline --policy $pol > $OUT/write_$pol.log 2>&1 || exit 1
+  timeout -k 10 300 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/fetch_$pol -- python3 /root/repo/bench.py $Q --policy $pol > $OUT/fetch_$pol.log 2>&1 || exit 1
+  timeout -k 10 300 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/write_$pol -- python3 /root/repo/bench.py $Q --policy $pol > $OUT/write_$pol.log 2>&1 || exit 1
 done
-python3 /root/repo/scripts/collect_final.py
+for route in place lookback; do
+  extra=""; [ $route = lookback ] && extra="--ft-lookback"
+  timeout -k 10 300 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/ft_fetch_$route -- python3 /root/repo/bench.py $Q --mode full_trace $extra > $OUT/ft_fetch_$route.log 2>&1 || exit 1
+  timeout -k 10 300 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/ft_write_$route -- python3 /root/repo/bench.py $Q --mode full_trace $extra > $OUT/ft_write_$route.log 2>&1 || exit 1
+done
+timeout -k 10 300 rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY --kernel-trace --output-format csv -d $OUT/sq_both -- python3 /root/repo/bench.py $Q --policy fast > $OUT/sq_both.log 2>&1 || exit 1
+ORT_ROUND=r02 python3 /root/repo/scripts/collect_final.py
