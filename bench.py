@@ -411,19 +411,39 @@ def bench_multi(args, torch, rank, world, local_rank):
     inter_total = total_rays * S
 
     # ---- the communicator: native RCCL through the C ABI (ort_comm_*); gloo rehearsal: torch on CPU tensors ----
-    native = backend == "nccl"
-    comm = None
+    native = backend == "nccl" and os.environ.get("ORT_BENCH_GATHER", "native") == "native"
+    comm, native_note = None, None
     if native:
-        box = [odist.RcclComm.unique_id() if rank == 0 else None]
+        # ort_comm_* (the C ABI's own RCCL communicator).  If it cannot be set up on this node, every rank falls back —
+        # together — to torch.distributed's all_gather_into_tensor on the same device buffers (RCCL as well, one collective)
+        try:
+            box = [odist.RcclComm.unique_id() if rank == 0 else None]
+            if dist is not None:
+                dist.broadcast_object_list(box, src=0)
+            comm = odist.RcclComm(eng, world, rank, box[0])
+            ok = 1
+        except Exception as exc:                                # noqa: BLE001 — reported in the JSON, not swallowed
+            ok, native_note = 0, f"{type(exc).__name__}: {exc}"
         if dist is not None:
-            dist.broadcast_object_list(box, src=0)
-        comm = odist.RcclComm(eng, world, rank, box[0])
+            flag = torch.tensor([ok], dtype=torch.int32, device=dev)
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+            ok = int(flag.item())
+        if not ok:
+            if comm is not None:
+                comm.close()
+            comm, native = None, False
     hits = [torch.zeros((2, slab), dtype=torch.float64, device=dev) for _ in range(2)]
     gathered = [torch.empty((world, 2, slab), dtype=torch.float64, device=dev) for _ in range(2)]
 
     def gather(b, wait):
         if native:
             comm.allgather_hits_packed(hits[b], gathered[b], wait=wait)
+        elif backend == "nccl":                                 # torch's RCCL communicator, device buffers, engine stream order
+            eng.ctx.synchronize()
+            if dist is not None:
+                dist.all_gather_into_tensor(gathered[b].view(world * 2, slab), hits[b])
+            else:
+                gathered[b][0].copy_(hits[b])
         else:
             eng.ctx.synchronize()
             g = torch.empty((world, 2, slab), dtype=torch.float64)
@@ -511,7 +531,9 @@ def bench_multi(args, torch, rank, world, local_rank):
                        "parallelism": f"{world} ranks x contiguous rank-ordered slabs, no data-path collective, 1 reassembly all-gather",
                        "device": info["name"]},
             "allgather": {"impl": "ort_allgather_hits_packed_f64 (native RCCL, one ncclAllGather on the communicator's stream)" if native
-                                  else "torch.distributed gloo on CPU tensors (rehearsal)",
+                                  else ("torch.distributed all_gather_into_tensor (RCCL, device buffers)" if backend == "nccl"
+                                        else "torch.distributed gloo on CPU tensors (rehearsal)"),
+                          "native_fallback_reason": native_note,
                           "nranks_seen": comm.nranks_seen if comm is not None else (dist.get_world_size() if dist is not None else 1),
                           "message_bytes_per_rank": msg_bytes, "bytes_assembled_per_rank": msg_bytes * world,
                           "alone_ms": wall_gather / args.steps * 1e3,

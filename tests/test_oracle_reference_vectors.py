@@ -220,6 +220,20 @@ def test_full_trace_singlet_rms(eng):
     assert e1.r.max() == 1.0
 
 
+def test_tessar_real_spot_diagram_figure(eng):
+    """A second reference-held number for the skew loop OFF the meridional plane: the documentation's figure of
+    `spot_diagram(full_trace(system, 0.0))` on the Tessar of docs/setup.jl (docs/src/Plotting Examples.md:50,
+    docs/src/assets/images/real_spot_diagram.png) carries the title "H = 0.00 / RMS Spot Size = 0.11975"
+    (ext/MakieExtension.jl:243-245 prints ε.RMS with %.5f) and spans about ±0.37 mm in ε_X.  The restatement gives
+    0.11898 (−0.64 %) and ±0.372 mm; the RMS moves by ±0.5 % with the grid alone (k_rays 65, 66: 0.11983,
+    0.11971), so the figure pins the path to ~1 %, ten times tighter than the singlet's ±0.07 of :370."""
+    system = ort.solve(cm.tessar(), cm.TESSAR_A, cm.TESSAR_H, engine=eng)
+    e = ort.full_trace(system, 0.0, engine=eng)
+    assert abs(e.RMS - 0.11975) < 0.01 * 0.11975
+    assert abs(np.abs(e.x).max() - 0.37) < 0.01
+    assert abs(ort.full_trace(system, 0.0, 66, engine=eng).RMS - 0.11975) < 0.005 * 0.11975
+
+
 def test_full_trace_domain_error(eng):
     system = ort.solve(cm.singlet(), [20.0, 20.0], 17.787, engine=eng)
     with pytest.raises(ort.DomainError):

@@ -1,0 +1,58 @@
+// tools/store_ceiling.hip — what HBM write rate can ANY kernel with the history layout reach on this box, sustained?
+// (not part of the product; grounds `roofline.frac` of the history kernel.)  Same launch shape and store pattern as
+// k_trace<..., HIST>: 256 threads, 2 adjacent columns per lane (16-B stores), S rows of TWO arrays [S][ld] per tile of
+// 512 columns, nothing else — vs. a plain linear fill of the same bytes.  Each variant runs >= 1 s back to back.
+// Build: hipcc --offload-arch=gfx950 -O3 -o tools/store_ceiling tools/store_ceiling.hip
+#include <hip/hip_runtime.h>
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
+#define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e)); exit(1); } } while (0)
+typedef double d2 __attribute__((ext_vector_type(2)));
+
+template <bool NT, int WORK>     // WORK: FP64 FMAs per row per lane pair spent before the store (0 = pure stores)
+__global__ __launch_bounds__(256) void k_hist(double* xv, double* yv, long n, int S, long ld)
+{
+    const long col = (long)blockIdx.x * 512 + threadIdx.x * 2;
+    if (col >= n) return;
+    double a = (double)col, b = a + 1.0;
+    for (int r = 0; r < S; ++r) {
+#pragma unroll
+        for (int w = 0; w < WORK; ++w) { a = __builtin_fma(a, 1.0000001, 1e-9); b = __builtin_fma(b, 0.9999999, 1e-9); }
+        d2 vx; vx.x = a; vx.y = b; d2 vy; vy.x = b; vy.y = a;
+        double* px = xv + (long)r * ld + col; double* py = yv + (long)r * ld + col;
+        if (NT) { __builtin_nontemporal_store(vx, (d2*)px); __builtin_nontemporal_store(vy, (d2*)py); }
+        else { *(d2*)px = vx; *(d2*)py = vy; }
+    }
+}
+__global__ __launch_bounds__(256) void k_fill(d2* out, long n2)
+{
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n2; i += (long)gridDim.x * 256) { d2 v; v.x = (double)i; v.y = 1.0; __builtin_nontemporal_store(v, out + i); }
+}
+
+template <typename F> static double sustain(F launch, double seconds)
+{
+    hipEvent_t a, b; CK(hipEventCreate(&a)); CK(hipEventCreate(&b));
+    launch(); CK(hipDeviceSynchronize());
+    long n = 0; auto t0 = std::chrono::steady_clock::now();
+    CK(hipEventRecord(a));
+    do { for (int i = 0; i < 200; ++i) launch(); n += 200; CK(hipDeviceSynchronize()); }
+    while (std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() < seconds);
+    CK(hipEventRecord(b)); CK(hipEventSynchronize(b));
+    float ms; CK(hipEventElapsedTime(&ms, a, b));
+    return ms / n;
+}
+
+int main()
+{
+    const long n = 9437184; const int S = 12; const double bytes = 16.0 * n * S;
+    double *xv, *yv; CK(hipMalloc(&xv, sizeof(double) * n * S)); CK(hipMalloc(&yv, sizeof(double) * n * S));
+    const dim3 g((unsigned)(n / 512)), b(256);
+    auto rep = [&](const char* name, double ms) { printf("%-58s %.4f ms  %.2f TB/s  %.1f %% of 8 TB/s\n", name, ms, bytes / ms / 1e9, bytes / ms / 1e9 / 8000.0 * 100.0); fflush(stdout); };
+    rep("history layout, nontemporal 16-B stores, no arithmetic", sustain([&] { hipLaunchKernelGGL((k_hist<true, 0>), g, b, 0, 0, xv, yv, n, S, n); }, 1.0));
+    rep("history layout, plain 16-B stores, no arithmetic", sustain([&] { hipLaunchKernelGGL((k_hist<false, 0>), g, b, 0, 0, xv, yv, n, S, n); }, 1.0));
+    rep("history layout, nontemporal, 36 FP64 FMAs per ray-row", sustain([&] { hipLaunchKernelGGL((k_hist<true, 36>), g, b, 0, 0, xv, yv, n, S, n); }, 1.0));
+    rep("history layout, nontemporal, 72 FP64 FMAs per ray-row", sustain([&] { hipLaunchKernelGGL((k_hist<true, 72>), g, b, 0, 0, xv, yv, n, S, n); }, 1.0));
+    rep("linear fill of the same bytes (grid-stride, nontemporal)", sustain([&] { hipLaunchKernelGGL(k_fill, dim3(256 * 16), b, 0, 0, (d2*)xv, n * S / 2); hipLaunchKernelGGL(k_fill, dim3(256 * 16), b, 0, 0, (d2*)yv, n * S / 2); }, 1.0));
+    return 0;
+}
