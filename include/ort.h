@@ -54,8 +54,12 @@ extern "C" {
 #define ORT_RAYBASIS      (1u << 2) /* per-ray U=(ybar-y)/z0, V=-x/z0 (PupilSampling.jl:124-127) */
 #define ORT_LAYOUT_INPUT  (1u << 3) /* meridional: input was a Layout -> always atan (Q16) */
 #define ORT_CLIP          (1u << 4) /* paraxial: clip = true (RayTracing.jl:135) */
-#define ORT_FAST_MATH     (1u << 5) /* fused/reciprocal arithmetic, |rel err| << 1e-10; default is
-                                       the op-for-op IEEE sequence of the reference loop */
+#define ORT_FAST_MATH     (1u << 5) /* direction-cosine / fused arithmetic: coordinates within 1e-10 relative of the
+                                       reference sequence (measured <= 5e-12), status identical except within rounding of a
+                                       miss / TIR boundary; a wave holding a ray on which the reference's formulas are not
+                                       the geometry (hit beyond a sphere's equator, direction refracted backward, polynomial
+                                       row outside its conic) retraces with the reference sequence.  Default: the op-for-op
+                                       IEEE sequence of the reference loop, bit-identical to a non-fused CPU evaluation */
 #define ORT_NO_LDS        (1u << 6) /* read the surface table through scalar loads, not LDS */
 #define ORT_FT_LOOKBACK   (1u << 7) /* full_trace: the trace kernel writes the survivors' first half at its final place
                                        (decoupled look-back over the bundle's tiles) instead of staging compacted tiles in
