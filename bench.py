@@ -362,6 +362,13 @@ def bench_single(args, torch, rank, world, local_rank):
                      "algorithmic_bytes_per_launch": algo_bytes,
                      "frac_of_measured_copy_rate": achieved / HBM_MEASURED_COPY_GBS},
     }
+    if args.layout_ceiling and args.mode == "history":
+        c = args.layout_ceiling
+        res["roofline"]["layout_store_ceiling"] = {
+            "GBps": c["GBps"], "kernel_ms": c["ms"], "what": c["kernel"] + f", {c['seconds']} s sustained on this box before the bench "
+            "(tools/store_ceiling.hip, a child process)",
+            "frac_of_it": achieved / c["GBps"],
+            "sustained_frac_of_it": None if sustained is None else sustained["achieved_GBps"] / c["GBps"]}
     if verify is not None:
         res["verify"] = verify
         res["verified"] = verify["verified"]
@@ -576,6 +583,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the summary / config-3 extras")
     ap.add_argument("--no-verify", action="store_true", help="skip the oracle check of the timed output")
+    ap.add_argument("--no-ceiling", action="store_true", help="skip the layout store-ceiling measurement (tools/store_ceiling)")
     ap.add_argument("--sustain-s", type=float, default=1.0, help="seconds of back-to-back launches for the sustained figure (0 = off)")
     ap.add_argument("--mode", default="history", choices=["history", "summary", "full_trace"])
     ap.add_argument("--ft-lookback", action="store_true", help="--mode full_trace: the ORT_FT_LOOKBACK route")
@@ -585,9 +593,20 @@ def main():
     if args.fast_math:
         args.policy = "fast"
 
-    import torch
     from opticalraytracing_jl_amd import dist as odist
     rank, world, local_rank = odist.env_rank_world()
+    # N = 1: what store rate does the history LAYOUT itself sustain on this box (tools/store_ceiling: the same launch
+    # shape and stores, no ray tracing)?  Run as a child process BEFORE this process touches the GPU.
+    args.layout_ceiling = None
+    exe = os.path.join(ROOT, "tools", "store_ceiling")
+    if world == 1 and args.workload != "config4" and not args.no_ceiling and os.path.exists(exe):
+        try:
+            import subprocess
+            out = subprocess.run([exe, "--quick"], capture_output=True, text=True, timeout=60).stdout
+            args.layout_ceiling = json.loads([l for l in out.splitlines() if l.startswith("{")][-1])
+        except Exception:                                       # noqa: BLE001 — a missing helper only drops the extra field
+            args.layout_ceiling = None
+    import torch
     if args.gpus > 1 and world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} needs torchrun with {args.gpus} ranks (WORLD_SIZE={world})")
     if not torch.cuda.is_available():

@@ -10,6 +10,8 @@
 //   history         T[S][ld] surface-major: lane l of a wave writes 16 B (RPT = 2 adjacent
 //                   rays) at consecutive addresses -> 1 KiB per store instruction.
 //   summary         SoA T[N] x {xf, yf, xs, ys} + int32 status[N].
+//   full_trace      workspace T[N] x {ex, ey, r, theta}: tile t of bundle b fills only its compacted survivors at
+//                   b*rpb + 512 t; outputs [nb][2*rpb] (first half = survivors in ray order, second half = mirror).
 // One thread owns RPT = 2 adjacent rays: 16-byte stores and two independent FP64 div/sqrt
 // dependency chains per lane.  Workgroup = 256 threads = 512 rays; a launch is
 // nb * ceil(ny*nx/512) workgroups (>> 256 CUs at every BASELINE config but #1).  Output is

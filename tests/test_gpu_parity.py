@@ -1216,3 +1216,37 @@ def test_device_buffers_through_the_c_abi(hip_engine, oracle_engine):
     assert int(cnt[0]) == of["count"] and abs(rms[0] - of["rms"]) <= TOL * of["rms"]
     for p in ptrs:
         _capi.check(lib.ort_device_free(h, p))
+
+
+def test_config5_full_size_properties(hip_engine, oracle_engine):
+    """BASELINE config 5 at FULL size (10^4 perturbed Double-Gauss instances x 2 fields x 256 x 128 half pupil =
+    6.6e8 rays, Float32 trace, ONE C call `ort_spot_batch_f32`): size-independent properties —
+    (1) a permutation of the instances permutes every output with it (no cross-instance state, a checksum of
+    checksums); (2) a 200-instance slice of the full call equals the same 200 instances run alone, bit for bit;
+    (3) the Float32 spot statistics track the Float64 call on that slice (counts within 1e-4, RMS within 1e-4
+    relative); (4) the first-order structs equal ort_first_order_f64's; and one instance against the per-call route
+    through the oracle (solve -> aim -> full_trace)."""
+    from opticalraytracing_jl_amd import batch, workloads
+    ninst = 10 ** 4
+    mats = workloads.config5(None, ninst=ninst)
+    fields = (0.0, 1.0)
+    full = batch.spot_batch(mats, cm.DG_A, cm.DG_H, fields, 256, engine=hip_engine, dtype=np.float32)
+    assert full["rms"].shape == (ninst, 2) and np.isfinite(full["rms"]).all() and (full["count"] > 0).all()
+    nominal = ort.full_trace(ort.solve(cm.double_gauss(0), cm.DG_A, cm.DG_H, engine=oracle_engine), 0.0, 256, engine=oracle_engine)
+    assert (np.abs(full["rms"][:, 0] / nominal.RMS - 1.0) < 0.5).all()          # perturbations of 1e-3: same spot to tens of percent
+    perm = np.random.default_rng(5).permutation(ninst)
+    shuf = batch.spot_batch(mats[perm], cm.DG_A, cm.DG_H, fields, 256, engine=hip_engine, dtype=np.float32)
+    for key in ("rms", "count", "f", "W040", "stop"):
+        assert np.array_equal(shuf[key], full[key][perm]), key
+    sl = slice(4321, 4521)
+    part = batch.spot_batch(mats[sl], cm.DG_A, cm.DG_H, fields, 256, engine=hip_engine, dtype=np.float32)
+    assert np.array_equal(part["rms"], full["rms"][sl]) and np.array_equal(part["count"], full["count"][sl])
+    p64 = batch.spot_batch(mats[sl], cm.DG_A, cm.DG_H, fields, 256, engine=hip_engine)
+    assert np.abs(part["count"] / p64["count"] - 1.0).max() <= 1e-4 and np.abs(part["rms"] / p64["rms"] - 1.0).max() <= 1e-4
+    fo = batch.first_order_arrays(hip_engine, mats[sl], cm.DG_A, cm.DG_H)
+    for key in ("f", "EBFD", "W040", "W131", "stop"):
+        assert np.array_equal(fo[key], p64[key]), key
+    i = 4400
+    s = ort.solve(mats[i].copy(), cm.DG_A, cm.DG_H, engine=oracle_engine)
+    e = ort.full_trace(s, 1.0, 256, engine=oracle_engine)
+    assert len(e.x) == p64["count"][i - 4321, 1] and abs(e.RMS - p64["rms"][i - 4321, 1]) <= 1e-6 * e.RMS   # aiming atol sqrt(eps)

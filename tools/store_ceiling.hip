@@ -7,6 +7,7 @@
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
+#include <cstring>
 #define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e)); exit(1); } } while (0)
 typedef double d2 __attribute__((ext_vector_type(2)));
 
@@ -25,6 +26,33 @@ __global__ __launch_bounds__(256) void k_hist(double* xv, double* yv, long n, in
         else { *(d2*)px = vx; *(d2*)py = vy; }
     }
 }
+// CPL adjacent columns per lane (2 = the product's shape; 4 = two 16-B stores per row and array, 32 B contiguous per lane),
+// BLK threads per workgroup: does a wider tile write faster?
+template <int CPL, int BLK>
+__global__ __launch_bounds__(BLK) void k_hist_wide(double* xv, double* yv, long n, int S, long ld)
+{
+    const long col = ((long)blockIdx.x * BLK + threadIdx.x) * CPL;
+    if (col >= n) return;
+    const double a = (double)col, b = a + 1.0;
+    for (int r = 0; r < S; ++r) {
+        double* px = xv + (long)r * ld + col; double* py = yv + (long)r * ld + col;
+#pragma unroll
+        for (int c = 0; c < CPL; c += 2) {
+            d2 vx; vx.x = a + r; vx.y = b + c; d2 vy; vy.x = b + r; vy.y = a + c;
+            __builtin_nontemporal_store(vx, (d2*)(px + c)); __builtin_nontemporal_store(vy, (d2*)(py + c));
+        }
+    }
+}
+// surface-major order of the WORKGROUP's writes: all rows of x first, then all rows of y (12 streams at a time instead of 24)
+__global__ __launch_bounds__(256) void k_hist_split(double* xv, double* yv, long n, int S, long ld)
+{
+    const long col = (long)blockIdx.x * 512 + threadIdx.x * 2;
+    if (col >= n) return;
+    const double a = (double)col, b = a + 1.0;
+    for (int r = 0; r < S; ++r) { d2 v; v.x = a + r; v.y = b; __builtin_nontemporal_store(v, (d2*)(xv + (long)r * ld + col)); }
+    for (int r = 0; r < S; ++r) { d2 v; v.x = b + r; v.y = a; __builtin_nontemporal_store(v, (d2*)(yv + (long)r * ld + col)); }
+}
+
 __global__ __launch_bounds__(256) void k_fill(d2* out, long n2)
 {
     for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n2; i += (long)gridDim.x * 256) { d2 v; v.x = (double)i; v.y = 1.0; __builtin_nontemporal_store(v, out + i); }
@@ -43,16 +71,27 @@ template <typename F> static double sustain(F launch, double seconds)
     return ms / n;
 }
 
-int main()
+int main(int argc, char** argv)
 {
+    const bool quick = argc > 1 && !strcmp(argv[1], "--quick");     // bench.py: one line of JSON, ~0.7 s
     const long n = 9437184; const int S = 12; const double bytes = 16.0 * n * S;
     double *xv, *yv; CK(hipMalloc(&xv, sizeof(double) * n * S)); CK(hipMalloc(&yv, sizeof(double) * n * S));
     const dim3 g((unsigned)(n / 512)), b(256);
-    auto rep = [&](const char* name, double ms) { printf("%-58s %.4f ms  %.2f TB/s  %.1f %% of 8 TB/s\n", name, ms, bytes / ms / 1e9, bytes / ms / 1e9 / 8000.0 * 100.0); fflush(stdout); };
+    if (quick) {
+        const double ms = sustain([&] { hipLaunchKernelGGL((k_hist<true, 0>), g, b, 0, 0, xv, yv, n, S, n); }, 1.0);
+        printf("{\"kernel\": \"history layout (256 threads, 16-B non-temporal stores of two [12][9437184] arrays), no ray tracing\", "
+               "\"ms\": %.5f, \"GBps\": %.1f, \"seconds\": 1.0}\n", ms, bytes / ms / 1e6);
+        return 0;
+    }
+    auto rep = [&](const char* name, double ms) { printf("%-58s %.4f ms  %.2f TB/s  %.1f %% of 8 TB/s\n", name, ms, bytes / ms / 1e9, bytes / ms / 1e9 / 8.0 * 100.0); fflush(stdout); };
     rep("history layout, nontemporal 16-B stores, no arithmetic", sustain([&] { hipLaunchKernelGGL((k_hist<true, 0>), g, b, 0, 0, xv, yv, n, S, n); }, 1.0));
     rep("history layout, plain 16-B stores, no arithmetic", sustain([&] { hipLaunchKernelGGL((k_hist<false, 0>), g, b, 0, 0, xv, yv, n, S, n); }, 1.0));
     rep("history layout, nontemporal, 36 FP64 FMAs per ray-row", sustain([&] { hipLaunchKernelGGL((k_hist<true, 36>), g, b, 0, 0, xv, yv, n, S, n); }, 1.0));
     rep("history layout, nontemporal, 72 FP64 FMAs per ray-row", sustain([&] { hipLaunchKernelGGL((k_hist<true, 72>), g, b, 0, 0, xv, yv, n, S, n); }, 1.0));
+    rep("history layout, 4 columns per lane (32 B), 256 threads", sustain([&] { hipLaunchKernelGGL((k_hist_wide<4, 256>), dim3((unsigned)(n / 1024)), dim3(256), 0, 0, xv, yv, n, S, n); }, 1.0));
+    rep("history layout, 2 columns per lane, 512 threads", sustain([&] { hipLaunchKernelGGL((k_hist_wide<2, 512>), dim3((unsigned)(n / 1024)), dim3(512), 0, 0, xv, yv, n, S, n); }, 1.0));
+    rep("history layout, 2 columns per lane, 128 threads", sustain([&] { hipLaunchKernelGGL((k_hist_wide<2, 128>), dim3((unsigned)(n / 256)), dim3(128), 0, 0, xv, yv, n, S, n); }, 1.0));
+    rep("history layout, x rows then y rows", sustain([&] { hipLaunchKernelGGL(k_hist_split, g, b, 0, 0, xv, yv, n, S, n); }, 1.0));
     rep("linear fill of the same bytes (grid-stride, nontemporal)", sustain([&] { hipLaunchKernelGGL(k_fill, dim3(256 * 16), b, 0, 0, (d2*)xv, n * S / 2); hipLaunchKernelGGL(k_fill, dim3(256 * 16), b, 0, 0, (d2*)yv, n * S / 2); }, 1.0));
     return 0;
 }
