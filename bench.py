@@ -225,7 +225,10 @@ def bench_single(args, torch, rank, world, local_rank):
     # ---- correctness of what was just timed: a strided sample of the history against the CPU oracle ----
     verify = None
     if args.mode == "history" and not args.no_verify:
-        verify = verify_sample(pres, bundles, axes, k, xv, yv, args.policy)
+        try:
+            verify = verify_sample(pres, bundles, axes, k, xv, yv, args.policy)
+        except Exception as exc:                                # noqa: BLE001 — reported as not verified, never hidden
+            verify = {"verified": False, "error": f"{type(exc).__name__}: {exc}"}
 
     # ---- the other arithmetic policy, same launch, reported beside the headline ----
     other = None
@@ -252,9 +255,11 @@ def bench_single(args, torch, rank, world, local_rank):
                            "<= 1e-10 relative, status exact (tests/test_gpu_parity.py::_fast_attribution)"}
 
     # ---- extras: summary mode (config 2), BASELINE config 3 through full_trace + compaction ----
-    extra = {}
-    if not args.no_extras and args.mode == "history":
-        del xv, yv
+    def run_extras():
+        """summary mode (config 2), BASELINE config 3 through both full_trace routes + statistics-only, config 5."""
+        nonlocal xv, yv
+        extra = {}
+        xv = yv = None
         out.xv = out.yv = None
         torch.cuda.empty_cache()
         xf = torch.empty(N, dtype=torch.float64, device=dev); yf = torch.empty_like(xf)
@@ -328,6 +333,16 @@ def bench_single(args, torch, rank, world, local_rank):
             "rms_mean": float(np.nanmean(r5["rms"])), "count_mean": float(r5["count"].mean()),
             "bound": "FP32 VALU; wall time of the whole call incl. the H2D of the prescriptions and the D2H of the results"}
 
+        return extra
+
+    extra = {}
+    if not args.no_extras and args.mode == "history":
+        try:
+            extra = run_extras()
+        except Exception as exc:                                # noqa: BLE001 — the headline line must still be printed
+            extra = {"error": f"{type(exc).__name__}: {exc}"}
+            torch.cuda.empty_cache()
+
     traffic, traffic_source = None, None
     tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
     if os.path.exists(tpath):
@@ -379,8 +394,11 @@ def bench_single(args, torch, rank, world, local_rank):
     if extra:
         res["extra"] = extra
     if not args.no_cpu_baseline:
-        res["cpu_baseline"] = cpu_baseline(api, pres, bundles, axes, k)
-        res["cpu_baseline"]["gpu_over_cpu_1core"] = value / res["cpu_baseline"]["value"]
+        try:
+            res["cpu_baseline"] = cpu_baseline(api, pres, bundles, axes, k)
+            res["cpu_baseline"]["gpu_over_cpu_1core"] = value / res["cpu_baseline"]["value"]
+        except Exception as exc:                                # noqa: BLE001
+            res["cpu_baseline"] = {"error": f"{type(exc).__name__}: {exc}"}
     print(json.dumps(res), flush=True)
 
 
