@@ -420,14 +420,23 @@ def bench_multi(args, torch, rank, world, local_rank):
     eng = ort.HipEngine(local_dev, fast_math=fast)
     info = eng.ctx.device_info()
 
-    mats = np.array([workloads.double_gauss(line, -1.5 + 3.0 * z / max(1, args.zoom - 1))
-                     for z in range(args.zoom) for line in (0, 1, 2, 1, 2)])
-    fields = (0.0, 0.5, 0.7, 0.85, 1.0)
-    k = args.pupil4
+    c5 = args.workload == "config5"
+    if c5:        # BASELINE config 5's hit payload: perturbed instances x 256^2 FULL pupil, Float32 hits (8 B per ray)
+        mats = workloads.config5(None, ninst=args.instances5)
+        fields, k, hdt, tdt = (0.0,), 256, np.float32, torch.float32
+        wl = (f"BASELINE config 5: {args.instances5} perturbed Double-Gauss instances (seed 12345; sigma_R/R 1e-3, sigma_t 10 um, sigma_n 1e-4) x "
+              f"{k}x{k} pupil on axis, Float32 trace and hits")
+    else:
+        mats = np.array([workloads.double_gauss(line, -1.5 + 3.0 * z / max(1, args.zoom - 1))
+                         for z in range(args.zoom) for line in (0, 1, 2, 1, 2)])
+        fields, k, hdt, tdt = (0.0, 0.5, 0.7, 0.85, 1.0), args.pupil4, np.float64, torch.float64
+        wl = (f"BASELINE config 4: zoom-lens sweep, {args.zoom} positions x 5 index columns x 5 fields x {k}x{k} pupil "
+              f"(Double-Gauss), Float64")
+    esz = 4 if c5 else 8
     nb_total = mats.shape[0] * len(fields)
     S = mats.shape[1]                                          # extended system: rows + 1 rows -> rows iterations
     unit = "bundle" if nb_total % world == 0 else "row"        # rows: slabs within one pupil row of equal for any world
-    plan = batch.ImageHitsPlan(mats, workloads.DG_A, workloads.DG_H, fields, k, engine=eng, shard=(rank, world), unit=unit)
+    plan = batch.ImageHitsPlan(mats, workloads.DG_A, workloads.DG_H, fields, k, engine=eng, shard=(rank, world), unit=unit, dtype=hdt)
     per = k if unit == "row" else 1
     bounds = odist.shard_bounds(nb_total * per, world)
     rays_of = [(hi - lo) * (k if unit == "row" else k * k) for lo, hi in bounds]
@@ -457,8 +466,8 @@ def bench_multi(args, torch, rank, world, local_rank):
             if comm is not None:
                 comm.close()
             comm, native = None, False
-    hits = [torch.zeros((2, slab), dtype=torch.float64, device=dev) for _ in range(2)]
-    gathered = [torch.empty((world, 2, slab), dtype=torch.float64, device=dev) for _ in range(2)]
+    hits = [torch.zeros((2, slab), dtype=tdt, device=dev) for _ in range(2)]
+    gathered = [torch.empty((world, 2, slab), dtype=tdt, device=dev) for _ in range(2)]
 
     def gather(b, wait):
         if native:
@@ -471,7 +480,7 @@ def bench_multi(args, torch, rank, world, local_rank):
                 gathered[b][0].copy_(hits[b])
         else:
             eng.ctx.synchronize()
-            g = torch.empty((world, 2, slab), dtype=torch.float64)
+            g = torch.empty((world, 2, slab), dtype=tdt)
             if dist is not None:
                 dist.all_gather_into_tensor(g.view(world * 2, slab), hits[b].cpu())
             else:
@@ -520,7 +529,7 @@ def bench_multi(args, torch, rank, world, local_rank):
     ref = None
     verified = own_ok
     if rank == 0 and not args.no_verify:
-        whole = batch.ImageHitsPlan(mats, workloads.DG_A, workloads.DG_H, fields, k, engine=eng)
+        whole = batch.ImageHitsPlan(mats, workloads.DG_A, workloads.DG_H, fields, k, engine=eng, dtype=hdt)
         wh = whole.new_hits()
         whole.trace(wh); eng.ctx.synchronize()
         t0 = time.perf_counter()
@@ -529,7 +538,7 @@ def bench_multi(args, torch, rank, world, local_rank):
         eng.ctx.synchronize()
         t1 = (time.perf_counter() - t0) / 3
         ref = {"n_gpus": 1, "value": inter_total / t1, "ms_per_step": t1 * 1e3,
-               "note": "rank 0 alone, the same 800 bundles, summary trace only (nothing to gather at N = 1), measured after the timed region"}
+               "note": f"rank 0 alone, the same {nb_total} bundles, summary trace only (nothing to gather at N = 1), measured after the timed region"}
         g = gathered[last]
         same = True
         off = 0
@@ -542,20 +551,18 @@ def bench_multi(args, torch, rank, world, local_rank):
     if dist is not None:
         odist.barrier(local_dev)
     if rank == 0:
-        msg_bytes = 16.0 * slab
+        msg_bytes = 2.0 * esz * slab
         res = {
             "metric": METRIC, "value": inter_total * args.steps / wall, "unit": "ray-surface intersections/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": wall / args.steps * 1e3,
-            "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-            "config": {"workload": f"BASELINE config 4: zoom-lens sweep, {args.zoom} positions x 5 index columns x 5 fields x "
-                                   f"{k}x{k} pupil (Double-Gauss, S={S}), Float64, summary trace of each rank's slab + ONE all-gather "
-                                   f"of the image-plane hits per step (inside the timed region, overlapped with the next step's trace), "
-                                   f"{args.policy} arithmetic policy",
+            "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32" if c5 else "f64", "data": "synthetic",
+            "config": {"workload": wl + f" (S={S}), summary trace of each rank's slab + ONE all-gather of the image-plane hits per step "
+                                        f"(inside the timed region, overlapped with the next step's trace), {args.policy} arithmetic policy",
                        "rays_per_step": total_rays, "intersections_per_step": inter_total,
                        "shard_unit": unit, "rays_per_rank": rays_of, "policy": args.policy,
                        "parallelism": f"{world} ranks x contiguous rank-ordered slabs, no data-path collective, 1 reassembly all-gather",
                        "device": info["name"]},
-            "allgather": {"impl": "ort_allgather_hits_packed_f64 (native RCCL, one ncclAllGather on the communicator's stream)" if native
+            "allgather": {"impl": f"ort_allgather_hits_packed_{'f32' if c5 else 'f64'} (native RCCL, one ncclAllGather on the communicator's stream)" if native
                                   else ("torch.distributed all_gather_into_tensor (RCCL, device buffers)" if backend == "nccl"
                                         else "torch.distributed gloo on CPU tensors (rehearsal)"),
                           "native_fallback_reason": native_note,
@@ -566,9 +573,9 @@ def bench_multi(args, torch, rank, world, local_rank):
             "gather_exclusive": {"ms_per_step": wall_trace / args.steps * 1e3, "value": inter_total * args.steps / wall_trace},
             "overlap": {"trace_plus_gather_serial_ms": (wall_trace + wall_gather) / args.steps * 1e3,
                         "measured_ms": wall / args.steps * 1e3},
-            "roofline": {"bound": "valu", "note": "summary trace writes 16 B per ray (1.33 B per intersection): FP64 VALU-bound, see the "
-                                                  "N = 1 line for the HBM-bound history kernel", "achieved": 16.0 * total_rays / world / (wall_trace / args.steps) / 1e9,
-                         "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": 16.0 * total_rays / world / (wall_trace / args.steps) / 1e9 / HBM_PEAK_GBS,
+            "roofline": {"bound": "valu", "note": f"summary trace writes {2 * esz} B per ray ({2 * esz / S:.2f} B per intersection): {'FP32' if c5 else 'FP64'} VALU-bound, see the "
+                                                  "N = 1 line for the HBM-bound history kernel", "achieved": 2.0 * esz * total_rays / world / (wall_trace / args.steps) / 1e9,
+                         "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": 2.0 * esz * total_rays / world / (wall_trace / args.steps) / 1e9 / HBM_PEAK_GBS,
                          "traffic": None},
             "verified": verified,
             "verify": {"own_slab_in_gathered": own_ok, "gathered_equals_single_gpu_trace": None if ref is None else verified},
@@ -605,8 +612,9 @@ def main():
     ap.add_argument("--sustain-s", type=float, default=1.0, help="seconds of back-to-back launches for the sustained figure (0 = off)")
     ap.add_argument("--mode", default="history", choices=["history", "summary", "full_trace"])
     ap.add_argument("--ft-lookback", action="store_true", help="--mode full_trace: the ORT_FT_LOOKBACK route")
-    ap.add_argument("--workload", default="auto", choices=["auto", "config2", "config4"],
-                    help="auto: config 2 at N = 1, config 4 (sharded + all-gather) at N > 1")
+    ap.add_argument("--workload", default="auto", choices=["auto", "config2", "config4", "config5"],
+                    help="auto: config 2 at N = 1, config 4 (sharded + all-gather) at N > 1; config5: the Float32 hit payload of the "
+                         "Monte-Carlo run, sharded + all-gathered the same way")
     args = ap.parse_args()
     if args.fast_math:
         args.policy = "fast"
@@ -617,7 +625,7 @@ def main():
     # shape and stores, no ray tracing)?  Run as a child process BEFORE this process touches the GPU.
     args.layout_ceiling = None
     exe = os.path.join(ROOT, "tools", "store_ceiling")
-    if world == 1 and args.workload != "config4" and not args.no_ceiling and os.path.exists(exe):
+    if world == 1 and args.workload in ("auto", "config2") and not args.no_ceiling and os.path.exists(exe):
         try:
             import subprocess
             out = subprocess.run([exe, "--quick"], capture_output=True, text=True, timeout=60).stdout
@@ -629,7 +637,7 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} needs torchrun with {args.gpus} ranks (WORLD_SIZE={world})")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the engine has no CPU fallback")
-    multi = args.workload == "config4" or (args.workload == "auto" and world > 1)
+    multi = args.workload in ("config4", "config5") or (args.workload == "auto" and world > 1)
     if multi:
         bench_multi(args, torch, rank, world, local_rank)
     else:
