@@ -41,6 +41,9 @@ namespace ort {
 #ifndef ORT_MIN_WAVES
 #define ORT_MIN_WAVES 5      // __launch_bounds__ 2nd argument (waves per SIMD): 96 VGPRs, no spill in the fast history kernel
 #endif
+#ifndef ORT_WAVES_NOHIST
+#define ORT_WAVES_NOHIST ORT_MIN_WAVES   // the same for the kernels without history stores (A/B: 6 = 80 VGPRs spills)
+#endif
 #ifndef ORT_BLOCK
 #define ORT_BLOCK 256          // threads per workgroup (A/B builds: 128 halves the tile and the end-of-launch tail)
 #endif
@@ -161,13 +164,15 @@ __device__ __forceinline__ void load_rec(SurfRec<T>& d, const __attribute__((add
 //                for another (the default: fastest measured);
 //   FT_LOOKBACK  straight to its final position in the first half, found by a decoupled look-back over the
 //                bundle's earlier tiles (tiles taken in ticket order); k_ft_mirror adds the second half — least
-//                HBM traffic (82 vs 100 B/ray), but every tile waits for its predecessors' counts (ORT_FT_LOOKBACK);
+//                HBM traffic (84 vs 103 B/ray measured), but every tile waits for its predecessors' counts and the kernel holds
+//                4 waves per SIMD instead of 5 (ORT_FT_LOOKBACK; 5 % slower);
 //   FT_STATS     per-tile (count, mean, M2, max r) only — nothing ray-sized is written: the statistics-only route.
 enum { FT_NONE = 0, FT_FULL = 1, FT_STATS = 2, FT_LOOKBACK = 3 };
 constexpr int kStatusVignetted = 1 << 17, kStatusVigShift = 20;
 // ------------------------------------------------------------------------------------
 template <typename T, int MATH, bool USE_LDS, bool GRID, bool HIST, bool SUMM, int FT>
-__global__ __launch_bounds__(kBlock, (HIST && SUMM) ? ORT_MIN_WAVES - 1 : ORT_MIN_WAVES) void k_trace(TraceParams<T> p)   // both outputs: 128 VGPRs, no spill
+__global__ __launch_bounds__(kBlock, ((HIST && SUMM) || FT == 3 /* FT_LOOKBACK */) ? ORT_MIN_WAVES - 1 : HIST ? ORT_MIN_WAVES : ORT_WAVES_NOHIST)
+void k_trace(TraceParams<T> p)   // both outputs, look-back epilogue: 128 VGPRs, no spill (96 spilled 48 B per ray to scratch: HBM writes)
 {
     __shared__ SurfRec<T> s_rec[USE_LDS ? kMaxRows : 1];
     __shared__ T s_coef[USE_LDS ? kMaxRows * kMaxCoef : 1];
