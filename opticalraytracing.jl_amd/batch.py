@@ -358,6 +358,7 @@ class ImageHitsPlan:
         self.d_axes = d_axes.to(torch.float32) if self.f32 else d_axes
         torch.cuda.synchronize(dev)
         self.sys = eng.system(ext)                                 # the object, held for the life of the plan
+        self.ext, self.inst, self.aim_U = ext, inst, aim["U"]      # extended prescriptions, local instance and aimed field angle per bundle
         self.segs = segs
 
     def new_hits(self):

@@ -1251,3 +1251,62 @@ def test_config5_full_size_properties(hip_engine, oracle_engine):
     s = ort.solve(mats[i].copy(), cm.DG_A, cm.DG_H, engine=oracle_engine)
     e = ort.full_trace(s, 1.0, 256, engine=oracle_engine)
     assert len(e.x) == p64["count"][i - 4321, 1] and abs(e.RMS - p64["rms"][i - 4321, 1]) <= 1e-6 * e.RMS   # aiming atol sqrt(eps)
+
+
+@pytest.mark.parametrize("policy", ["ieee", "fast"])
+def test_config4_full_size_properties(oracle_engine, policy):
+    """BASELINE config 4 at FULL size (32 zoom positions x 5 index columns x 5 fields x 512^2 full pupil =
+    2.1e8 rays, summary trace into the packed [2][n] hit slab that ONE all-gather sends): size-independent
+    properties — (1) eight row-level shards concatenated in rank order equal the single launch bit for bit (what
+    the reassembly relies on, src/PupilSampling.jl:123,134-137); (2) the pupil's x axis is symmetric about the
+    meridional plane, so hits mirror: x_f(-x) = -x_f(x), y_f(-x) = y_f(x) to 1e-11, NaN pattern exactly; (3) a strided sample of 4000
+    rays against the per-call route through the oracle (explicit pupil coordinates from the plan's own aimed
+    axes): bit-identical in the reference-sequence policy, <= 1e-12 in the fast one."""
+    import torch
+    from opticalraytracing_jl_amd import batch, dist as odist, workloads
+    eng = ort.HipEngine(0, fast_math=(policy == "fast"))
+    mats = np.array([workloads.double_gauss(line, -1.5 + 3.0 * z / 31) for z in range(32) for line in (0, 1, 2, 1, 2)])
+    fields = (0.0, 0.5, 0.7, 0.85, 1.0)
+    k, nb = 512, 160 * 5
+    whole = batch.ImageHitsPlan(mats, workloads.DG_A, workloads.DG_H, fields, k, engine=eng)
+    wh = whole.new_hits(); st = torch.empty(whole.n_rays, dtype=torch.int32, device=whole.dev)
+    whole.trace(wh, st); eng.ctx.synchronize()
+    assert wh.shape == (2, nb * k * k)
+    # (1) 8 ranks, pupil-row shards (800 * 512 rows / 8): slabs start and end on bundle borders here; 7 does not divide
+    for world in (8, 7):
+        off = 0
+        for r in range(world):
+            plan = batch.ImageHitsPlan(mats, workloads.DG_A, workloads.DG_H, fields, k, engine=eng, shard=(r, world), unit="row")
+            h = plan.new_hits(); plan.trace(h); eng.ctx.synchronize()
+            assert torch.equal(torch.nan_to_num(h), torch.nan_to_num(wh[:, off:off + plan.n_rays])), (world, r)
+            off += plan.n_rays
+            del h, plan
+        assert off == whole.n_rays
+    # (2) mirror symmetry in x, every bundle
+    g = wh.view(2, nb, k, k)
+    nanx = torch.isnan(g[0])
+    assert torch.equal(nanx, nanx.flip(-1)) and float(nanx.float().mean()) < 0.5
+    for c, sign in ((0, 1.0), (1, -1.0)):          # x_f antisymmetric, y_f symmetric (the axis values mirror to the last bit or two)
+        worst_sym = 0.0
+        for b0 in range(0, nb, 100):
+            blk = torch.nan_to_num(g[c, b0:b0 + 100])
+            worst_sym = max(worst_sym, float((blk + sign * blk.flip(-1)).abs().max()))
+        assert worst_sym <= 1e-11, (c, worst_sym)
+    # (3) strided sample through the oracle, bundle by bundle (explicit rays: the plan's axes, its aimed field angle)
+    axes = whole.d_axes.cpu().numpy().reshape(nb, 2, k)
+    rng = np.random.default_rng(44)
+    worst, nsample = 0.0, 0
+    for b in rng.choice(nb, 40, replace=False):
+        iy = rng.integers(0, k, 100); ix = rng.integers(0, k, 100)
+        yy, xx = axes[b, 0, iy], axes[b, 1, ix]
+        ox, oy = oracle_engine.skew(whole.ext, yy, xx, np.full(100, math.tan(whole.aim_U[b])), np.zeros(100),
+                                    isys=int(whole.inst[b]), slopes=True)
+        hx = g[0, b][iy, ix].cpu().numpy(); hy = g[1, b][iy, ix].cpu().numpy()
+        if policy == "ieee":
+            assert np.array_equal(hx, ox[-1], equal_nan=True) and np.array_equal(hy, oy[-1], equal_nan=True), b
+        else:
+            assert np.array_equal(np.isnan(hx), np.isnan(ox[-1])), b
+            ok = ~np.isnan(hx)
+            worst = max(worst, float(np.abs(hx[ok] - ox[-1][ok]).max()), float(np.abs(hy[ok] - oy[-1][ok]).max()))
+        nsample += 100
+    assert nsample == 4000 and worst <= 1e-12
