@@ -293,12 +293,50 @@ def test_f32_build_extension(oracle_engine):
     assert np.array_equal(xv, oxv, equal_nan=True) and np.array_equal(yv, oyv, equal_nan=True)
 
 
+def _snell_residual_torch(R, t, n, u, v, X, Y):
+    """max over rays and surfaces of |n1 d1 x N - n2 d2 x N| for a spherical / flat prescription: d the unit chords
+    between consecutive hit points (X, Y: [S][rays] on the device), the launch direction (slopes u = dy/dz, v = dx/dz)
+    in front of the first surface — the chord from the launch plane is too short to define one near the axis —, N the
+    unit normal of the sphere at the hit.  Nothing of the reference's formulas enters."""
+    import torch
+    S = X.shape[0]
+    zv = np.concatenate([[0.0], np.cumsum(t[1:S])])
+
+    def point(i):                                   # hit on surface i (1-based) and its unit normal
+        x, y = X[i - 1], Y[i - 1]
+        if not math.isfinite(R[i]):
+            z = torch.zeros_like(x); nr = torch.stack([z, z, torch.ones_like(x)])
+        else:
+            c = 1.0 / R[i]
+            root = torch.sqrt(1.0 - c * c * (x * x + y * y))
+            z = c * (x * x + y * y) / (1.0 + root)
+            nr = torch.stack([-c * x / root, -c * y / root, torch.ones_like(x)])
+            nr = nr / nr.norm(dim=0)
+        return torch.stack([x, y, zv[i - 1] + z]), nr
+
+    def unit(d):                                    # every ray travels towards +z (see tests/test_oracle_physics.py)
+        return d * (torch.sign(d[2]) / d.norm(dim=0))
+
+    cur, nr = point(1)
+    d1 = torch.tensor([v, u, 1.0], dtype=X.dtype, device=X.device)[:, None].expand(3, X.shape[1])
+    d1 = d1 / d1.norm(dim=0)
+    worst = 0.0
+    for i in range(1, S):
+        nxt, nr_next = point(i + 1)
+        d2 = unit(nxt - cur)
+        res = n[i - 1] * torch.linalg.cross(d1, nr, dim=0) - n[i] * torch.linalg.cross(d2, nr, dim=0)
+        worst = max(worst, float(torch.nan_to_num(res.norm(dim=0)).max()))
+        d1, cur, nr = d2, nxt, nr_next
+    return worst
+
+
 @pytest.mark.parametrize("policy", ["ieee", "fast"])
 def test_device_pointer_path_full_size_properties(oracle_engine, policy):
     """BASELINE config 2 at FULL size (3 fields x 3 index columns x 1024 x 1024, S = 12)
     through the device-pointer ABI (torch tensors).  Too large for the oracle, so check
     size-independent properties: (1) x -> -x mirror symmetry, exact; (2) a strided sample of
-    rays re-traced by the oracle from explicit lists, bit-exact; (3) status histogram sanity."""
+    rays re-traced by the oracle from explicit lists, bit-exact; (3) status histogram sanity;
+    (4) every one of the 9.4e6 rays obeys the vector law of refraction at every surface to 1e-11."""
     import ctypes as C
     import torch
     from opticalraytracing_jl_amd import _capi
@@ -355,6 +393,15 @@ def test_device_pointer_path_full_size_properties(oracle_engine, policy):
     assert np.all((s & 0xffff) == S + 1)
     kept = 1.0 - np.count_nonzero(s >> 16) / N
     assert abs(kept - math.pi / 4) < 0.05
+    # (4) first principles, EVERY ray of the launch (tests/test_oracle_physics.py does this to the oracle): consecutive
+    # hit points obey the vector law of refraction at every surface — only the prescription's geometry is used
+    worst = 0.0
+    for b in range(nb):
+        bd = bundles[b]
+        sysi = bd["system"]
+        worst = max(worst, _snell_residual_torch(pres.R[sysi], pres.t[sysi], pres.n[sysi], math.tan(bd["U"]), math.tan(bd["V"]),
+                                                 xv[:, b * rpb:(b + 1) * rpb], yv[:, b * rpb:(b + 1) * rpb]))
+    assert worst <= 1e-11, worst
 
 
 def test_config4_zoom_sweep_many_systems(hip_engine, oracle_engine):
