@@ -219,7 +219,9 @@ int ort_ctx_domain_error(ort_ctx *ctx, int64_t *ray, int *surface, int64_t *coun
  * One (system, field) pair per entry: the FD-Newton drivers of src/RayTracing.jl:223-240 (real
  * marginal) and :265-296 (real chief, traced through the REVERSED prescription, which the
  * caller uploads as `rev`, built as :267-277 incl. quirk Q17) and the edge-ray search of
- * src/PupilSampling.jl:67-83 (Optim.BFGS in the reference; restated as the same FD-Newton),
+ * src/PupilSampling.jl:67-83 (Optim.BFGS in the reference; restated as the same FD-Newton, ended INSIDE the
+ * stop's edge: y1, y2 are such that the grid's two edge rays pass the filter r > a_stop of :132, as the
+ * reference's do — its published Tessar spot size 0.11975 depends on them),
  * giving the aiming scalars of src/PupilSampling.jl:94-103 that ort_full_trace_f64 consumes.
  * `in`, `out`: host arrays [n] (device arrays with ORT_DEVICE_PTRS).                        */
 typedef struct ort_aim_in {

@@ -905,9 +905,13 @@ __device__ inline MerEnd mer_trace_to(const MerSurf* __restrict__ surf, const do
 // loop's arithmetic, two traces per round side by side.  `trace(v)` returns the MerEnd of a ray launched
 // with the pair's free variable set to v; loss = y_stop - target.  The two pairs of a 4-lane group run
 // different problems concurrently; the loop is group-uniform so the shuffles always see live lanes.
+// inside_edge (the edge rays of the pupil grid): a search that ends OUTSIDE its target |y_stop| = a_stop takes one more
+// Newton step, to atol inside — the grid's edge rays must pass the stop filter r > a_stop (PupilSampling.jl:132) as
+// the reference's do (its published Tessar spot size is reproduced with them and 0.64 % off without).
 template <typename F>
 __device__ __forceinline__ void pair_newton(F&& trace, double& v, double target, double atol, int cap, bool cap_fails,
-                                            int pairbase, int role, MerEnd& e, double& loss, int& iters, int& ok)
+                                            int pairbase, int role, MerEnd& e, double& loss, int& iters, int& ok,
+                                            bool inside_edge = false)
 {
     const double eps = 1.4901161193847656e-08;                   // const ϵ = sqrt(eps()), RayTracing.jl:1
     const bool pert = role & 1;
@@ -920,7 +924,10 @@ __device__ __forceinline__ void pair_newton(F&& trace, double& v, double target,
         const double L0 = __shfl(L, pairbase, 4), L1 = __shfl(L, pairbase + 1, 4);
         if (!conv) {
             loss = L0;
-            if (!(fabs(L0) > atol)) conv = true;                 // NaN ends the loop like the reference (:229,282)
+            if (!(fabs(L0) > atol)) {                            // NaN ends the loop like the reference (:229,282)
+                conv = true;
+                if (inside_edge && L0 * target > 0.0) v -= (L0 + copysign(atol, target)) * eps / (L1 - L0);
+            }
             else if (it >= cap) { conv = true; if (cap_fails) ok = 0; }
             else { v -= L0 * eps / (L1 - L0); ++it; }            // :231,284
         }
@@ -975,7 +982,7 @@ __global__ __launch_bounds__(64) void k_aim(int n, const AimIn* __restrict__ in,
     double yy = y0;
     int ok2 = 1;
     pair_newton([&](double w) { return mer_trace_to(F, cF, S, ncoef, a.layout_fwd, tlF, w, U, a.stop); },
-                yy, target, a.atol, 100, false, pairbase, role, e, loss, iters, ok2);
+                yy, target, a.atol, 100, false, pairbase, role, e, loss, iters, ok2, true);
     if (!(fabs(loss) <= 1e300)) yy = y0;                         // isnan(Δ) ? Inf : Δ keeps the start point (:72,78)
     const double y2e = __shfl(yy, 2, 4);
     const int it_all = iters + __shfl(iters, 2, 4);              // lanes 0 and 2 carry their pairs' counts

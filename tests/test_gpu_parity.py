@@ -1364,12 +1364,15 @@ def test_tessar_spot_figure_of_the_reference_docs(oracle_engine, policy):
     """The one reference-held number that pins the skew loop OFF the meridional plane to its printed digits: the title
     of docs/src/assets/images/real_spot_diagram.png, "RMS Spot Size = 0.11975" for `full_trace(system, 0.0)` on the
     Tessar of docs/setup.jl (tests/test_oracle_reference_vectors.py::test_tessar_real_spot_diagram_figure explains the
-    two edge rays).  Here the whole chain runs on the device: solve and aiming through the HIP engine, grid, trace,
-    stop filter, compaction, mirror and sigma in `ort_full_trace_f64`."""
+    two edge rays).  Here the whole chain runs on the device, twice: (1) the reference's call sequence through the HIP
+    engine (solve, aiming driven from the host, then grid, trace, stop filter, compaction, mirror and sigma in
+    `ort_full_trace_f64`); (2) ONE C call, `ort_spot_batch_f64`: first-order solve, aiming (`k_aim`), trace and
+    statistics all on the device."""
+    from opticalraytracing_jl_amd import batch
     eng = ort.HipEngine(0, fast_math=(policy == "fast"))
     system = ort.solve(cm.tessar(), cm.TESSAR_A, cm.TESSAR_H, engine=eng)
-    aim = ort.full_trace_aim(system.layout, system, 0.0, engine=eng)
-    aim.y1 *= 1.0 - 1e-8; aim.y2 *= 1.0 - 1e-8
-    e = ort.full_trace_grid(system.layout, aim, engine=eng)
+    e = ort.full_trace(system, 0.0, engine=eng)
     assert f"{e.RMS:.5f}" == "0.11975" and len(e.x) == 2 * 1560
     assert abs(np.abs(e.x).max() - 0.37) < 0.01
+    sb = batch.spot_batch(cm.tessar()[None], cm.TESSAR_A, cm.TESSAR_H, (0.0,), 64, engine=eng)
+    assert f"{sb['rms'][0, 0]:.5f}" == "0.11975" and sb["count"][0, 0] == 2 * 1560

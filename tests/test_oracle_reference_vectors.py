@@ -226,23 +226,24 @@ def test_tessar_real_spot_diagram_figure(eng):
     docs/src/assets/images/real_spot_diagram.png) carries the title "H = 0.00 / RMS Spot Size = 0.11975"
     (ext/MakieExtension.jl:243-245 prints ε.RMS with %.5f) and spans about ±0.37 mm in ε_X.
 
-    The restatement reproduces ALL FIVE printed digits — 0.119749 — once the two edge rays of the grid (y = ±y_EP,
+    The restatement reproduces ALL FIVE printed digits — 0.119749 — PROVIDED the two edge rays of the grid (y = ±y_EP,
     x = 0) pass the stop filter.  They sit ON the stop's edge by construction: the grid's end points are the rays aimed
     at r = a_stop (`src/PupilSampling.jl:96-100`), and whether `rᵢ > a_stop` (`:132`) drops them is decided by the
-    last 1e-8 of that aiming — Optim's BFGS in the reference (not in the tree: parity unpinned), an
-    FD-Newton that stops at sqrt(eps) here, which leaves them 1.35e-8 mm OUTSIDE: 1,558 instead of 1,560 rays, RMS
-    0.118984 (−0.64 %; each of the two carries ten times the mean squared error).  Moving the end points inward by
-    1e-8 relative — inside the aiming tolerance of either method — gives the figure's number."""
+    last 1e-8 of that aiming — Optim's BFGS in the reference (not in the tree: parity unpinned).  An
+    FD-Newton that merely stops at sqrt(eps) leaves them 1.35e-8 mm OUTSIDE here: 1,558 instead of 1,560 rays, RMS
+    0.118984 (−0.64 %; each of the two carries ten times the mean squared error).  api._trace_edge_rays therefore
+    ends every edge search inside the edge (one more Newton step when it stopped outside), which is what the figure
+    says the reference's end points do."""
     system = ort.solve(cm.tessar(), cm.TESSAR_A, cm.TESSAR_H, engine=eng)
     e = ort.full_trace(system, 0.0, engine=eng)
-    assert abs(e.RMS - 0.11975) < 0.01 * 0.11975
+    assert f"{e.RMS:.5f}" == "0.11975" and abs(e.RMS - 0.11975) < 5e-6      # "%.5f" of the reference's own run
+    assert len(e.x) == 2 * 1560
     assert abs(np.abs(e.x).max() - 0.37) < 0.01
+    # the sensitivity that decides it: end points 1e-8 (relative) further out lose the two edge rays and 0.64 %
     aim = ort.full_trace_aim(system.layout, system, 0.0, engine=eng)
-    aim.y1 *= 1.0 - 1e-8; aim.y2 *= 1.0 - 1e-8
+    aim.y1 *= 1.0 + 1e-8; aim.y2 *= 1.0 + 1e-8
     e2 = ort.full_trace_grid(system.layout, aim, engine=eng)
-    assert len(e2.x) == len(e.x) + 4                            # the two edge rays and their mirror images
-    assert abs(e2.RMS - 0.11975) < 5e-6, e2.RMS                 # "%.5f" of the reference's own run
-    assert f"{e2.RMS:.5f}" == "0.11975"
+    assert len(e2.x) == len(e.x) - 4 and abs(e2.RMS - 0.118984) < 5e-6
 
 
 def test_full_trace_domain_error(eng):
