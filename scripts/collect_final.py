@@ -46,7 +46,13 @@ for route in ("place", "lookback"):
     tot = sum(sum(v.values()) for v in per.values())
     ft[route] = {"kernels": per, "total_bytes": tot, "bytes_per_ray": tot / 9437184.0,
                  "note": "FETCH_SIZE x2 (half-count correction; uncalibrated for the 8-B-per-lane reads of the second pass) + WRITE_SIZE"}
-json.dump(ft, open(os.path.join(P, f"{tag}_pmc_full_trace_routes.json"), "w"), indent=1)
+ftp = os.path.join(P, f"{tag}_pmc_full_trace_routes.json")
+if os.path.exists(ftp):                       # keep the record of the superseded (spilling) look-back build
+    old = json.load(open(ftp))
+    for key in old:
+        if key not in ft:
+            ft[key] = old[key]
+json.dump(ft, open(ftp, "w"), indent=1)
 sq = {k: d for k, d in counters("sq_both").items() if "k_trace<" in k}
 json.dump(sq, open(os.path.join(P, f"{tag}_pmc_sq_history_both_policies.json"), "w"), indent=1)
 if os.path.exists(os.path.join(F, "bench.json")):
