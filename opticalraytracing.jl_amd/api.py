@@ -649,7 +649,9 @@ def _trace_edge_rays(surfaces, y1, y2, U, stop, a_stop, engine=None, atol: float
         if not math.isfinite(d):
             y = y0                       # isnan(Δ) ? Inf : Δ keeps the start point (:72,78)
         elif d * target > 0.0 and abs(d) <= atol:
-            y -= (d + math.copysign(atol, target)) * EPS / ((pert.y[stop] - target) - d)
+            slope = (pert.y[stop] - target) - d
+            if slope != 0.0 and math.isfinite(slope):
+                y -= (d + math.copysign(atol, target)) * EPS / slope
         out.append(y)
     return out[0], out[1]
 

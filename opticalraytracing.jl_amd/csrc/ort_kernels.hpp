@@ -926,7 +926,10 @@ __device__ __forceinline__ void pair_newton(F&& trace, double& v, double target,
             loss = L0;
             if (!(fabs(L0) > atol)) {                            // NaN ends the loop like the reference (:229,282)
                 conv = true;
-                if (inside_edge && L0 * target > 0.0) v -= (L0 + copysign(atol, target)) * eps / (L1 - L0);
+                if (inside_edge && L0 * target > 0.0) {
+                    const double dv = (L0 + copysign(atol, target)) * eps / (L1 - L0);
+                    if (fabs(dv) <= 1e300) v -= dv;              // (a flat loss gives inf / NaN: keep the end point)
+                }
             }
             else if (it >= cap) { conv = true; if (cap_fails) ok = 0; }
             else { v -= L0 * eps / (L1 - L0); ++it; }            // :231,284
