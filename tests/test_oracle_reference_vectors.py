@@ -239,6 +239,10 @@ def test_tessar_real_spot_diagram_figure(eng):
     assert f"{e.RMS:.5f}" == "0.11975" and abs(e.RMS - 0.11975) < 5e-6      # "%.5f" of the reference's own run
     assert len(e.x) == 2 * 1560
     assert abs(np.abs(e.x).max() - 0.37) < 0.01
+    # the figure shows the two edge rays as the isolated points at (0, +-0.396), above the arcs that end at 0.365
+    top = np.sort(np.abs(e.y))[-8:]
+    assert np.allclose(top[-4:], 0.39560, atol=2e-5) and np.allclose(top[:4], 0.36533, atol=2e-5)
+    assert np.all(e.x[np.abs(e.y) > 0.39] == 0.0)
     # the sensitivity that decides it: end points 1e-8 (relative) further out lose the two edge rays and 0.64 %
     aim = ort.full_trace_aim(system.layout, system, 0.0, engine=eng)
     aim.y1 *= 1.0 + 1e-8; aim.y2 *= 1.0 + 1e-8
