@@ -598,6 +598,14 @@ def test_first_order_and_seidel_batch(hip_engine, oracle_engine):
             close(r[key][0], o[key], key)
         for key in _capi.ORT_SURF_NAMES + _capi.ORT_INC_NAMES:
             close(r[key][0], o[key], key)
+    # the reference's documentation prints the third-order spot size of the Tessar (spot_diagram(W), H = 0): 0.12132
+    # (tests/test_oracle_reference_vectors.py::test_tessar_polynomial_spot_diagram_figure) — from the DEVICE's W040 and n'u'
+    t = cm.tessar()
+    ra = hip_engine.aberrations(t[:, 0], t[:, 1], t[:, 2], cm.TESSAR_A, cm.TESSAR_H)
+    fo = hip_engine.first_order(t[:, 0], t[:, 1], t[:, 2], cm.TESSAR_A, cm.TESSAR_H)[0]
+    xx = np.linspace(-1.0, 1.0, 64)
+    ee = 4.0 * ra["W040"][0] * xx ** 3 * 587.5618e-6 / fo["nu_end"]
+    assert f"{math.sqrt(2.0 * np.sum((ee - ee.sum() / 64) ** 2) / 64):.5f}" == "0.12132"
     r = hip_engine.first_order(cm.cooke()[:, 0], cm.cooke()[:, 1], cm.cooke()[:, 2], cm.COOKE_A, cm.COOKE_H, dn=cm.COOKE_DN)[0]
     assert abs(r["f"] - 101.181) < 1e-3 and abs(r["EBFD"] - 77.405) < 1e-3 and r["stop"] == 5   # test/runtests.jl:53-60
     # a finite, non-zero last thickness: Lens() keeps the last row and the reference needs `rows` semi-diameters

@@ -139,6 +139,48 @@ def test_c_oracle_solve_aberrations_smith_tables():
     assert np.allclose(r["tangential"], r["petzval"] + 1.5 * r["astigmatism"])
 
 
+def _polynomial_spot_rms_on_axis(W040, lam, nu, k=64):
+    """The title of `spot_diagram(W)` at H = 0 (ext/MakieExtension.jl:222-236): x = y = range(-1, 1, k), the sagittal
+    and the tangential fan of the third-order ray error 4 W040 rho^3 lam / nu, variance about the mean over k."""
+    x = np.linspace(-1.0, 1.0, k)
+    e = 4.0 * W040 * x ** 3 * lam / nu
+    var = np.sum((e - e.sum() / k) ** 2) / k
+    return math.sqrt(var + var)
+
+
+def test_tessar_polynomial_spot_diagram_figure(eng):
+    """A reference-held number for the Seidel path: docs/src/assets/images/spot_diagram.png —
+    `spot_diagram(W)`, `W = aberrations(system)` on the Tessar of docs/setup.jl (docs/src/Seidel Aberrations.md:12,
+    Plotting Examples.md:49) — is titled "RMS Spot Size: 0.12132" at H = 0, where only W040 λ / (n′u′) enters.  The C
+    restatement of solve + aberrations (oracle/ort_oracle.c::orc_solve_aberrations, the checker of the device kernel)
+    and the host mirror both give 0.121315: the five printed digits."""
+    from oracle import cpu
+    from opticalraytracing_jl_amd import analysis
+    r = cpu.solve_aberrations(cm.tessar(), cm.TESSAR_A, cm.TESSAR_H)
+    rms = _polynomial_spot_rms_on_axis(r["W040"], 587.5618e-6, r["marginal_nu"][-1])
+    assert f"{rms:.5f}" == "0.12132", rms
+    system = ort.solve(cm.tessar(), cm.TESSAR_A, cm.TESSAR_H, engine=eng)
+    W = analysis.aberrations(system)
+    assert f"{_polynomial_spot_rms_on_axis(W.W040, W.lam, system.marginal.nu[-1]):.5f}" == "0.12132"
+    # The other Seidel figures of the same page carry no printed number, but their curves end at readable places
+    # (H = 1): field_curves.png (ext/MakieExtension.jl:158-176, z = -2 lam W / (n'u' u')) P -1.82, S -1.52, T -0.94;
+    # percent_distortion.png (:184-196, W311 lam / (n'u') / ybar * 100) -0.775 %.  Read off the axes: +-0.02.
+    lam, nu = 587.5618e-6, r["marginal_nu"][-1]
+    alpha = -2.0 / (nu * nu) * lam                               # u' = n'u' in air
+    assert abs(alpha * r["W220P"] - (-1.82)) < 0.02 and abs(alpha * r["W220"] - (-1.52)) < 0.02
+    assert abs(alpha * r["W220T"] - (-0.94)) < 0.02
+    assert abs(r["W311"] * lam / nu / r["chief_y"][-1] * 100.0 - (-0.775)) < 0.01
+    # rayfan.png (slider at H = 0.430; third-order ray errors of src/SeidelAberrations.jl:78-110): eps_Y(y_p = 1) = -0.246,
+    # eps_Y(-1) = +0.249, eps_Y(0) = -0.015 (the distortion term), eps_X(x_p = 1) = -0.266.  Read off the axes: +-0.003.
+    def ray_error(x, y, H):
+        ey = (4 * r["W040"] * (x * x * y + y ** 3) + r["W131"] * H * (x * x + 3 * y * y) + 2 * r["W222"] * H * H * y +
+              2 * r["W220"] * H * H * y + r["W311"] * H ** 3) * lam / nu
+        ex = (4 * r["W040"] * (y * y * x + x ** 3) + r["W131"] * H * (2 * x * y) + 2 * r["W220"] * H * H * x) * lam / nu
+        return ex, ey
+    assert abs(ray_error(0, 1, 0.43)[1] + 0.246) < 0.003 and abs(ray_error(0, -1, 0.43)[1] - 0.249) < 0.003
+    assert abs(ray_error(0, 0, 0.43)[1] + 0.015) < 0.003 and abs(ray_error(1, 0, 0.43)[0] + 0.266) < 0.003
+
+
 # ---- "vignetting" clip semantics :252-257 ---------------------------------------------------
 def test_clip_semantics(cooke_system, eng):
     _, system = cooke_system
