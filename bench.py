@@ -548,6 +548,44 @@ def bench_multi(args, torch, rank, world, local_rank):
             off += n_r
         verified = own_ok and same
         del wh
+    # ---- the same sweep when only spot statistics are wanted ("prefer reducing on device"): every rank runs
+    # ONE C call over its instances (solve, aiming, axes, reference-mode half-pupil trace, statistics on the device) and
+    # the ranks exchange 16 B per bundle — no ray-sized collective, so this one does divide by N
+    stats = None
+    ninst = mats.shape[0]
+    if not args.no_extras and ninst % world == 0:
+        lo, hi = rank * (ninst // world), (rank + 1) * (ninst // world)
+        sub = mats[lo:hi]
+        nloc = (hi - lo) * len(fields)
+        gath = torch.empty((world, 2, nloc), dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
+
+        def stats_step():
+            r = batch.spot_batch(sub, workloads.DG_A, workloads.DG_H, fields, k, engine=eng, dtype=hdt)
+            mine = torch.from_numpy(np.stack([r["count"].reshape(-1).astype(np.float64), r["rms"].reshape(-1)]))
+            mine = mine.to(gath.device)
+            if dist is not None:
+                dist.all_gather_into_tensor(gath.view(world * 2, nloc), mine)
+            else:
+                gath[0].copy_(mine)
+            return r
+
+        stats_step()
+        sync_all()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            stats_step()
+        sync_all()
+        ts = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
+        if dist is not None:
+            dist.all_reduce(ts, op=dist.ReduceOp.MAX)
+        rays_stats = ninst * len(fields) * k * (k // 2)
+        stats = {"what": f"spot statistics of the same sweep: ort_spot_batch_{'f32' if c5 else 'f64'} per rank over its {hi - lo} "
+                         f"instances x {len(fields)} fields x {k}x{k // 2} rays (reference mode: half pupil + mirror), first-order solve "
+                         "and aiming included, then ONE all-gather of (count, RMS) per bundle",
+                 "ms_per_step": float(ts[0]) / args.steps * 1e3, "intersections_per_step": rays_stats * S,
+                 "value": rays_stats * S * args.steps / float(ts[0]), "unit": "ray-surface intersections/s",
+                 "collective_bytes_per_rank": 16 * nloc, "scaling": "strong",
+                 "finite": bool(torch.isfinite(gath[:, 1]).all()), "kept_fraction": float(gath[:, 0].sum()) / rays_stats / 2.0}
     if dist is not None:
         odist.barrier(local_dev)
     if rank == 0:
@@ -582,6 +620,8 @@ def bench_multi(args, torch, rank, world, local_rank):
         }
         if ref is not None:
             res["strong_scaling_reference"] = ref
+        if stats is not None:
+            res["extra"] = {"spot_statistics": stats}
         print(json.dumps(res), flush=True)
     if comm is not None:
         comm.close()
