@@ -17,6 +17,9 @@ split into contiguous rank-ordered slabs (no data-path collective), every rank t
 mode into a packed [2][n] hit slab, and ONE RCCL all-gather per step reassembles the image-plane hits of the
 whole sweep on every rank in the reference's append order (src/PupilSampling.jl:134-137).  The all-gather is
 INSIDE the timed region, on the communicator's own stream, overlapped with the next step's trace.
+The same line also carries the gather-exclusive rate, the all-gather alone, rank 0's bit-for-bit check of the gathered
+hits against its own single-rank trace (and that rate as the strong-scaling reference) and, under `extra`, the spot-
+statistics form of the sweep: one `ort_spot_batch` call per rank and a 16-B-per-bundle all-gather — nothing ray-sized moves.
 
 Prints ONE JSON line on rank 0.
 """
