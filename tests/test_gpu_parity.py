@@ -1384,3 +1384,38 @@ def test_tessar_spot_figure_of_the_reference_docs(oracle_engine, policy):
     assert abs(np.abs(e.x).max() - 0.37) < 0.01
     sb = batch.spot_batch(cm.tessar()[None], cm.TESSAR_A, cm.TESSAR_H, (0.0,), 64, engine=eng)
     assert f"{sb['rms'][0, 0]:.5f}" == "0.11975" and sb["count"][0, 0] == 2 * 1560
+
+
+def test_empty_single_and_all_dropped_inputs(hip_engine, oracle_engine):
+    """The edges of the input space: an empty ray list (nothing to do, ORT_OK), a single ray, a 1 x 1 pupil grid, and a
+    bundle of which NO ray passes the stop filter — the reference then fails in `maximum(r)` over an empty collection
+    (src/PupilSampling.jl:142); the C ABI returns count 0 (and the host mirror raises, as the reference does)."""
+    pres = Prescription.from_matrix(_ext(cm.cooke(), 77.40534796682427))
+    S = pres.rows - 1
+    e = np.zeros(0)
+    gx, gy, gs = hip_engine.skew(pres, e, e, e, e, slopes=True, want_status=True)
+    assert gx.shape == (S, 0) and gy.shape == (S, 0) and gs.shape == (0,)
+    one = [np.array([3.0]), np.array([-2.0]), np.array([0.05]), np.array([-0.02])]
+    gx, gy, gs = hip_engine.skew(pres, *one, slopes=True, want_status=True)
+    ox, oy, os_ = oracle_engine.skew(pres, *one, slopes=True, want_status=True)
+    assert np.array_equal(gx, ox) and np.array_equal(gy, oy) and np.array_equal(gs, os_) and gx.shape == (S, 1)
+    # 1 x 1 pupil grid
+    b = dict(system=0, stop=5, U=0.1, V=0.0, a_stop=10.3, hprime=0.0, yaxis_off=0, xaxis_off=1)
+    axes = np.array([2.0, 1.0])
+    g = hip_engine.grid(pres, [b], axes, 1, 1)
+    o = oracle_engine.grid(pres, [b], axes, 1, 1)
+    assert np.array_equal(g["xv"], o["xv"]) and np.array_equal(g["yv"], o["yv"]) and np.array_equal(g["status"], o["status"])
+    # every ray outside the stop: a 4 x 4 grid far off axis
+    axes = np.concatenate([np.linspace(13.0, 14.0, 4), np.linspace(13.0, 14.0, 4)])
+    b = dict(system=0, stop=5, U=0.0, V=0.0, a_stop=10.3, hprime=0.0, yaxis_off=0, xaxis_off=4)
+    for route in (False, True):
+        r = hip_engine.full_trace_grid(pres, [b], axes, 4, 4, lookback=route)[0]
+        assert r["count"] == 0 and len(r["ex"]) == 0
+    ro = oracle_engine.full_trace_grid(pres, [b], axes, 4, 4)[0]
+    assert ro["count"] == 0
+    sysm = ort.solve(cm.cooke(), cm.COOKE_A, cm.COOKE_H, engine=hip_engine)
+    aim = ort.full_trace_aim(sysm.layout, sysm, 0.0, engine=hip_engine)
+    aim.y1, aim.y2, aim.y_EP = 14.0, 13.0, 14.0                 # a pupil box that misses the stop altogether
+    aim.a_stop = 0.5
+    with pytest.raises(ValueError):
+        ort.full_trace_grid(sysm.layout, aim, 8, engine=hip_engine)
