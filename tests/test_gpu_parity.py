@@ -695,6 +695,16 @@ def test_error_codes(hip_engine):
     big = np.zeros((70, 3)); big[:, 2] = 1.0
     with pytest.raises(_capi.OrtError):
         hip_engine.skew(Prescription.from_matrix(big), [0.0], [0.0], [0.0], [0.0])      # rows > ORT_MAX_ROWS
+    # maximum sizes: a bundle of 2^32 rays is refused before anything is allocated (ray indices inside a bundle are 31-bit)
+    import ctypes as C
+    axes = np.zeros(131072)
+    out = _capi.ort_grid_out_f64()
+    st = np.zeros(4, dtype=np.int32)
+    out.status = st.ctypes.data                                   # never written: the size check comes first
+    barr = _capi.make_bundles([dict(system=0, stop=5, U=0.0, V=0.0, yaxis_off=0, xaxis_off=65536)])
+    rc = hip_engine.ctx.lib.ort_trace_grid_f64(hip_engine.ctx.h, hip_engine.system(pres).h, 1, barr, _capi.ptr(axes), axes.size,
+                                               65536, 65536, C.byref(out), 0)
+    assert rc == -1 and b"too large" in hip_engine.ctx.lib.ort_last_error()
 
 
 def _random_system(rng, rows, aspheric):
