@@ -1429,3 +1429,63 @@ def test_empty_single_and_all_dropped_inputs(hip_engine, oracle_engine):
     aim.a_stop = 0.5
     with pytest.raises(ValueError):
         ort.full_trace_grid(sysm.layout, aim, 8, engine=hip_engine)
+
+
+@pytest.mark.parametrize("policy", ["ieee", "fast"])
+def test_history_beyond_2_31_elements(oracle_engine, policy):
+    """Maximum sizes: a history of 12 x 1.9e8 = 2.27e9 elements per array (36 GB for x and y together — the 288 GB of
+    the card hold eight of these), so that row offsets i * ld + ray pass 2^31 and 2^32 bytes many times over: 20 bundles
+    (the 9 of config 2 and 11 of them again) x 3072^2 rays, S = 12.  Checked: the last history row equals the summary
+    output; the second copy of a bundle equals the first bit for bit (same descriptors, 1.7e9 elements apart); x mirror
+    symmetry of the LAST bundle's last rows; a strided sample incl. the very last ray through the oracle."""
+    import ctypes as C
+    import torch
+    from opticalraytracing_jl_amd import _capi
+    eng = ort.default_engine()
+    k = 3072
+    pres, bundles, axes = _dg_bundles(oracle_engine, k)
+    bundles = (bundles + bundles + bundles)[:20]
+    nb, rpb = len(bundles), k * k
+    N, S = nb * rpb, pres.rows - 1
+    assert S * N > 2 ** 31
+    dev = torch.device("cuda:0")
+    d_axes = torch.from_numpy(axes).to(dev)
+    xv = torch.empty((S, N), dtype=torch.float64, device=dev)
+    yv = torch.empty((S, N), dtype=torch.float64, device=dev)
+    xf = torch.empty(N, dtype=torch.float64, device=dev); yf = torch.empty_like(xf)
+    st = torch.empty(N, dtype=torch.int32, device=dev)
+    out = _capi.ort_grid_out_f64()
+    out.xv, out.yv, out.ld = xv.data_ptr(), yv.data_ptr(), N
+    out.xf, out.yf, out.status = xf.data_ptr(), yf.data_ptr(), st.data_ptr()
+    sysd = eng.system(pres)
+    barr = _capi.make_bundles(bundles)
+    torch.cuda.synchronize()
+    fast = policy == "fast"
+    _capi.check(eng.ctx.lib.ort_trace_grid_f64(eng.ctx.h, sysd.h, nb, barr, d_axes.data_ptr(), axes.size, k, k,
+                                               C.byref(out), _capi.ORT_DEVICE_PTRS | (_capi.ORT_FAST_MATH if fast else 0)))
+    eng.ctx.synchronize()
+    assert torch.equal(torch.nan_to_num(xf), torch.nan_to_num(xv[-1])) and torch.equal(torch.nan_to_num(yf), torch.nan_to_num(yv[-1]))
+    del xf, yf
+    for b in (9, 19):                                            # bundle b repeats bundle b - 9
+        a0, a1 = (b - 9) * rpb, b * rpb
+        assert torch.equal(torch.nan_to_num(xv[:, a1:a1 + rpb]), torch.nan_to_num(xv[:, a0:a0 + rpb]))
+        assert torch.equal(torch.nan_to_num(yv[:, a1:a1 + rpb]), torch.nan_to_num(yv[:, a0:a0 + rpb]))
+    last = xv[S - 2:, (nb - 1) * rpb:].view(2, k, k)
+    assert torch.equal(torch.nan_to_num(last), torch.nan_to_num(-last.flip(-1)))
+    idx = np.unique(np.concatenate([np.arange(0, N, 7000003), [N - 1, N - k, (nb - 1) * rpb]]))
+    ti = torch.from_numpy(idx).to(dev)
+    sxv = xv[:, ti].cpu().numpy(); syv = yv[:, ti].cpu().numpy(); sst = st[ti].cpu().numpy()
+    for b in range(nb):
+        sel = (idx // rpb) == b
+        if not sel.any():
+            continue
+        j = idx[sel] % rpb
+        bd = bundles[b]
+        yy = axes[bd["yaxis_off"] + j // k]; xx = axes[bd["xaxis_off"] + j % k]
+        sub = Prescription(pres.R[bd["system"]], pres.t[bd["system"]], pres.n[bd["system"]])
+        ox, oy, os_ = oracle_engine.skew(sub, yy, xx, np.full(j.size, math.tan(bd["U"])), np.zeros(j.size), slopes=True, want_status=True)
+        if fast:
+            assert cm.rel_err(sxv[:, sel], ox, 1.0).max() <= 1e-12 and cm.rel_err(syv[:, sel], oy, 1.0).max() <= 1e-12
+        else:
+            assert np.array_equal(sxv[:, sel], ox, equal_nan=True) and np.array_equal(syv[:, sel], oy, equal_nan=True)
+        assert np.array_equal(sst[sel] & 0xffff, os_)
