@@ -276,6 +276,21 @@ def bench_single(args, torch, rank, world, local_rank):
             "kernel_ms": ms, "value": inter / (ms * 1e-3), "algorithmic_bytes_per_launch": 36.0 * N,
             "achieved_GBps": 36.0 * N / (ms * 1e-3) / 1e9, "frac": 36.0 * N / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
             "bound": "FP64 VALU (3 B per intersection out)"}
+        # the bound that applies here, from the committed SQ counter passes of this kernel (static, not measured in this run)
+        sqp = os.path.join(ROOT, "profiles", "r02_pmc_sq_summary_both_policies.json")
+        if args.pupil == 1024 and os.path.exists(sqp):
+            try:
+                sq = json.load(open(sqp))
+                key = [k for k in sq if f"<double, {1 if args.policy == 'fast' else 0}," in k][0]
+                c = sq[key]
+                extra["config2_summary"]["valu_roofline"] = {
+                    "instructions_per_intersection": c["SQ_INSTS_VALU"] * 64.0 / inter,
+                    "issue_slots_per_intersection": c["SQ_ACTIVE_INST_VALU"] * 64.0 / inter,
+                    "issue_slot_utilisation": c["SQ_ACTIVE_INST_VALU"] / c["SQ_BUSY_CU_CYCLES"],
+                    "note": "SQ_ACTIVE_INST_VALU (4-cycle issue slots; an FP64 v_rsq / v_rcp takes four) over SQ_BUSY_CU_CYCLES x 4 SIMDs / 4",
+                    "source": "profiles/r02_pmc_sq_summary_both_policies.json (static; scripts/pmc_sq_summary.sh)"}
+            except Exception:                                    # noqa: BLE001 — an optional annotation
+                pass
         del xf, yf, xs, ys, st
         torch.cuda.empty_cache()
         k3 = args.pupil3
