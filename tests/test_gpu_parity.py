@@ -1489,3 +1489,27 @@ def test_history_beyond_2_31_elements(oracle_engine, policy):
         else:
             assert np.array_equal(sxv[:, sel], ox, equal_nan=True) and np.array_equal(syv[:, sel], oy, equal_nan=True)
         assert np.array_equal(sst[sel] & 0xffff, os_)
+
+
+def test_nan_and_inf_inputs(hip_engine, oracle_engine):
+    """The domain's nulls: NaN and +-Inf in the launch data (heights, slopes) — the reference just computes with them.
+    The reference-sequence policy reproduces the oracle's outputs bit for bit (NaN patterns, Inf, status); the fast
+    policy agrees on every NaN pattern and status and on the finite values."""
+    pres = Prescription.from_matrix(_ext(cm.cooke(), 77.40534796682427))
+    specials = [math.nan, math.inf, -math.inf, 0.0, -0.0, 1e308, -1e308, 1e-320]
+    y = [3.0]; x = [-2.0]; u = [0.05]; v = [-0.02]
+    for val in specials:
+        for slot in range(4):
+            row = [3.0, -2.0, 0.05, -0.02]; row[slot] = val
+            y.append(row[0]); x.append(row[1]); u.append(row[2]); v.append(row[3])
+    y, x, u, v = (np.array(a) for a in (y, x, u, v))
+    ox, oy, os_ = oracle_engine.skew(pres, y, x, u, v, slopes=True, want_status=True)
+    gx, gy, gs = hip_engine.skew(pres, y, x, u, v, slopes=True, want_status=True)
+    assert np.array_equal(gs, os_) and np.array_equal(gx, ox, equal_nan=True) and np.array_equal(gy, oy, equal_nan=True)
+    fast = ort.HipEngine(0, fast_math=True)
+    fx, fy, fs = fast.skew(pres, y, x, u, v, slopes=True, want_status=True)
+    assert np.array_equal(fs, os_)
+    assert np.array_equal(np.isnan(fx), np.isnan(ox)) and np.array_equal(np.isnan(fy), np.isnan(oy))
+    fin = np.isfinite(ox) & np.isfinite(oy)
+    assert cm.rel_err(fx[fin], ox[fin], 1.0).max() <= 1e-12 and cm.rel_err(fy[fin], oy[fin], 1.0).max() <= 1e-12
+    assert np.array_equal(np.isinf(fx), np.isinf(ox)) and np.array_equal(np.isinf(fy), np.isinf(oy))
