@@ -472,7 +472,24 @@ def bench_multi(args, torch, rank, world, local_rank):
             box = [odist.RcclComm.unique_id() if rank == 0 else None]
             if dist is not None:
                 dist.broadcast_object_list(box, src=0)
-            comm = odist.RcclComm(eng, world, rank, box[0])
+            # ncclCommInitRank is a rendezvous of all ranks: run it under a watchdog so that a rank that cannot reach its
+            # peers falls back (with everybody else, below) instead of hanging the whole job
+            import threading
+            made = {}
+
+            def make():
+                try:
+                    made["comm"] = odist.RcclComm(eng, world, rank, box[0])
+                except Exception as exc:                        # noqa: BLE001
+                    made["err"] = exc
+            th = threading.Thread(target=make, daemon=True)
+            th.start()
+            th.join(float(os.environ.get("ORT_BENCH_COMM_TIMEOUT_S", "180")))
+            if th.is_alive():
+                raise TimeoutError("ort_comm_create did not return (RCCL rendezvous)")
+            if "err" in made:
+                raise made["err"]
+            comm = made["comm"]
             ok = 1
         except Exception as exc:                                # noqa: BLE001 — reported in the JSON, not swallowed
             ok, native_note = 0, f"{type(exc).__name__}: {exc}"
