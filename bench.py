@@ -537,6 +537,8 @@ def bench_multi(args, torch, rank, world, local_rank):
             b = s & 1
             if with_gather and native and s >= 2:
                 comm.wait_lag(1)                                # hits[b] was last read by the gather of step s - 2
+            elif with_gather and backend == "nccl" and s >= 2:
+                torch.cuda.synchronize(dev)                     # fallback path: torch's collective stream is not ours to order
             plan.trace(hits[b])
             if with_gather:
                 gather(b, wait=False)
