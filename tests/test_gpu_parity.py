@@ -1442,6 +1442,7 @@ def test_history_beyond_2_31_elements(oracle_engine, policy):
     import torch
     from opticalraytracing_jl_amd import _capi
     eng = ort.default_engine()
+    torch.cuda.empty_cache()                                    # 37 GB below: hand back what earlier tests' tensors cached
     k = 3072
     pres, bundles, axes = _dg_bundles(oracle_engine, k)
     bundles = (bundles + bundles + bundles)[:20]
