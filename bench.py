@@ -251,7 +251,20 @@ def bench_single(args, torch, rank, world, local_rank):
                     break
             osus = eng.ctx.timer_stop() / n_l
         oms = timed_launches(eng, ostep, max(3, args.steps))            # ... then the same number of timed launches
-        other = {"policy": "ieee" if fast else "fast", "kernel_ms": oms, "value": inter / (oms * 1e-3),
+        # what bounds the reference-sequence kernel: FP64 issue slots (committed SQ counter pass of this kernel, static)
+        valu_note = None
+        sqh = os.path.join(ROOT, "profiles", "r02_pmc_sq_history_both_policies.json")
+        if k == 1024 and os.path.exists(sqh):
+            try:
+                sq = json.load(open(sqh))
+                c = sq[[kk for kk in sq if f"<double, {0 if fast else 1}," in kk][0]]
+                if "SQ_BUSY_CU_CYCLES" in c:
+                    valu_note = {"instructions_per_intersection": c["SQ_INSTS_VALU"] * 64.0 / inter,
+                                 "issue_slot_utilisation": c["SQ_ACTIVE_INST_VALU"] / c["SQ_BUSY_CU_CYCLES"],
+                                 "source": "profiles/r02_pmc_sq_history_both_policies.json (static; scripts/final_profile.sh)"}
+            except Exception:                                   # noqa: BLE001 — an optional annotation
+                valu_note = None
+        other = {"policy": "ieee" if fast else "fast", "kernel_ms": oms, "value": inter / (oms * 1e-3), "valu_roofline": valu_note,
                  "sustained_kernel_ms": osus, "sustained_frac": None if osus is None else algo_bytes / (osus * 1e-3) / 1e9 / HBM_PEAK_GBS,
                  "achieved_GBps": algo_bytes / (oms * 1e-3) / 1e9, "frac": algo_bytes / (oms * 1e-3) / 1e9 / HBM_PEAK_GBS,
                  "parity": "bit-identical to the CPU oracle (reference operation sequence)" if fast else
