@@ -411,8 +411,10 @@ def bench_single(args, torch, rank, world, local_rank):
     if args.layout_ceiling and args.mode == "history":
         c = args.layout_ceiling
         res["roofline"]["layout_store_ceiling"] = {
-            "GBps": c["GBps"], "kernel_ms": c["ms"], "what": c["kernel"] + f", {c['seconds']} s sustained on this box before the bench "
-            "(tools/store_ceiling.hip, a child process)",
+            "GBps": c["GBps"], "kernel_ms": c["ms"], "runs_GBps": c.get("runs_GBps"),
+            "what": c["kernel"] + f", the better of two {c['seconds']} s sustained runs on this box before the bench "
+            "(tools/store_ceiling.hip, a child process).  A reference rate, not a bound: pure back-to-back stores; the trace "
+            "kernel, whose stores are spaced by arithmetic, lands between 0.87 and 1.09 of it depending on the box",
             "frac_of_it": achieved / c["GBps"],
             "sustained_frac_of_it": None if sustained is None else sustained["achieved_GBps"] / c["GBps"]}
     if verify is not None:
@@ -718,8 +720,12 @@ def main():
     if world == 1 and args.workload in ("auto", "config2") and not args.no_ceiling and os.path.exists(exe):
         try:
             import subprocess
-            out = subprocess.run([exe, "--quick"], capture_output=True, text=True, timeout=60).stdout
-            args.layout_ceiling = json.loads([l for l in out.splitlines() if l.startswith("{")][-1])
+            runs = []
+            for _ in range(2):                                  # the first second also brings the box out of idle clocks
+                out = subprocess.run([exe, "--quick"], capture_output=True, text=True, timeout=60).stdout
+                runs.append(json.loads([l for l in out.splitlines() if l.startswith("{")][-1]))
+            args.layout_ceiling = max(runs, key=lambda r: r["GBps"])
+            args.layout_ceiling["runs_GBps"] = [r["GBps"] for r in runs]
         except Exception:                                       # noqa: BLE001 — a missing helper only drops the extra field
             args.layout_ceiling = None
     import torch
