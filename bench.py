@@ -141,8 +141,8 @@ def bench_single(args, torch, rank, world, local_rank):
     torch.cuda.set_device(local_dev)
     dev = torch.device("cuda", local_dev)
     stream = torch.cuda.current_stream(dev)
-    flags0 = (_capi.ORT_FAST_MATH if fast else 0) | (_capi.ORT_NO_LDS if args.no_lds else 0)
-    eng = ort.HipEngine(local_dev, stream=stream.cuda_stream, fast_math=fast, use_lds=not args.no_lds)
+    flags0 = _capi.ORT_FAST_MATH if fast else 0
+    eng = ort.HipEngine(local_dev, stream=stream.cuda_stream, fast_math=fast)
     ort.set_default_engine(eng)
     info = eng.ctx.device_info()
     lib, h = eng.ctx.lib, eng.ctx.h
@@ -394,7 +394,7 @@ def bench_single(args, torch, rank, world, local_rank):
         "config": {"workload": f"Double-Gauss 10 spherical surfaces + stop + image (S={S}), 3 fields x 3 index "
                                f"columns, {k}x{k} pupil, Float64, {args.mode} output, {args.policy} arithmetic policy",
                    "rays_per_step_per_gpu": N, "intersections_per_step_per_gpu": inter,
-                   "surface_table": "scalar-loads" if args.no_lds else "lds",
+                   "surface_table": "lds",
                    "policy": args.policy,
                    "policy_parity": ("bit-identical to the CPU oracle on every ray (reference operation sequence)" if not fast else
                                      "<= 1e-10 relative vs the reference sequence with identical status on every ray farther than 1e-9 "
@@ -696,7 +696,6 @@ def main():
                          "anomalous waves retrace with the reference sequence); ieee = the reference's IEEE operation sequence "
                          "(bit-identical to the CPU oracle).  The other policy is timed too and reported beside it.")
     ap.add_argument("--fast-math", action="store_true", help="alias of --policy fast")
-    ap.add_argument("--no-lds", action="store_true", help="surface table through scalar loads instead of LDS")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the summary / config-3 extras")
     ap.add_argument("--no-verify", action="store_true", help="skip the oracle check of the timed output")

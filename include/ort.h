@@ -60,7 +60,7 @@ extern "C" {
                                        the geometry (hit beyond a sphere's equator, direction refracted backward, polynomial
                                        row outside its conic) retraces with the reference sequence.  Default: the op-for-op
                                        IEEE sequence of the reference loop, bit-identical to a non-fused CPU evaluation */
-#define ORT_NO_LDS        (1u << 6) /* read the surface table through scalar loads, not LDS */
+/* bit 6 reserved (was ORT_NO_LDS, the scalar-load variant of the surface table: measured, not faster, dropped) */
 #define ORT_FT_LOOKBACK   (1u << 7) /* full_trace: the trace kernel writes the survivors' first half at its final place
                                        (decoupled look-back over the bundle's tiles) instead of staging compacted tiles in
                                        a workspace: 82 instead of 100 B/ray of HBM traffic, but tiles wait for their

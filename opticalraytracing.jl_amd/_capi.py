@@ -23,7 +23,6 @@ ORT_RAYBASIS = 1 << 2
 ORT_LAYOUT_INPUT = 1 << 3
 ORT_CLIP = 1 << 4
 ORT_FAST_MATH = 1 << 5
-ORT_NO_LDS = 1 << 6
 ORT_FT_LOOKBACK = 1 << 7
 ORT_STATUS_STOPPED = 1 << 16
 ORT_STATUS_VIGNETTED = 1 << 17

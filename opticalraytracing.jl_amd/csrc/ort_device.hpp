@@ -25,6 +25,10 @@
 //              vertex-side slope, PupilSampling.jl:16-19), a direction refracted backward (it keeps tracing the
 //              line by its slopes), a polynomial row met outside its conic's radius (NaN tilt, k untouched) —
 //              the step raises `odd` and the kernel retraces that wave with the MATH_IEEE sequence.
+//              The same happens to a ray that comes within kNear (normalised) of one of the reference's BRANCHES —
+//              the sag discriminant's sign (:6), the refraction discriminant's (:25), the equator, the stop filter
+//              (:132) — so every branch outcome (status, TIR, survivor count) is decided by the reference sequence
+//              itself wherever the two arithmetics could disagree: MATH_FAST is status-exact by construction.
 #pragma once
 
 #include <hip/hip_runtime.h>
@@ -51,13 +55,35 @@ struct alignas(16) SurfRec {
     T ome2;    // 1 - eta^2                   MATH_FAST only
     T e2c2;    // eta^2 c^2                   MATH_FAST centre form
     T ec;      // eta |c|                     MATH_FAST centre form
+    T dlim;    // kNear R^2: |sag discriminant| below this -> retrace (centre form, polynomial rows)   MATH_FAST only
+    T zlim;    // |R| (1 - sqrt(kNear)): |sag| beyond this is at / past the equator -> retrace          MATH_FAST centre form
     int32_t finite;   // isfinite(R)          :2
     int32_t ncoef;    // coefficients in use for this row (0 -> p = zero)
-    int32_t farmask;  // MATH_FAST centre form: v_cmp_class mask of the Qz that lie BEYOND the equator (sign(R) Qz > 0)
+    int32_t spare;
     int32_t cls;      // packed wave-uniform class bits (CLS_*), read once per surface
 };
 
+// Near-branch thresholds of MATH_FAST (see the notes at the top).  The fast forms differ from the reference sequence by
+// <= ~1e-11 relative (measured 5e-12, bar 1e-10), so a branch quantity farther than this from its boundary has the same
+// sign in both; Float32: eps is 2^29 times larger.
+template <typename T> struct Near;
+template <> struct Near<double> { static constexpr double thr = 1e-9, root = 3.1622776601683795e-5; };
+template <> struct Near<float> { static constexpr float thr = 1e-4f, root = 1e-2f; };
+
+// Polynomial rows: one record of kPolyRec values per loop iteration, built once per system (host or k_build_tables):
+//   [0,12)  pc[j] = c_j                       value coefficients, zero padded          (Types.jl:21-27)
+//   [12,24) dc[j] = (j+1) c_{j+1}             coefficients of p' (one IEEE product each, as the per-ray T(j) * c[j] was)
+//   [24,30) ev[k] = c_{2k}                    even form, rows whose odd coefficients are all zero:  p(y)  = E(y^2)
+//   [30,36) qd[k] = (2k+2) c_{2k+2}                                                                 p'(y) = y Q(y^2)
+// The kernel stages kPolyLds values per row in LDS: pc | dc, or ev | qd (MATH_FAST, even rows).
+constexpr int kPolyRec = 36, kPolyLds = 24, kPolyMax = 12;
+
 enum { KIND_SPHERE = 0, KIND_FLAT = 1, KIND_CONIC = 2, KIND_POLY = 3, KIND_SPHERE_C = 4 };
+// packed wave-uniform class bits of a row (SurfRec::cls)
+enum { CLS_FINITE = 1, CLS_HASP = 2, CLS_REFR = 4, CLS_TIR = 8, CLS_KIND_SHIFT = 4,
+       CLS_PEVEN = 1 << 8,    // polynomial row whose odd coefficients are all zero (even form, ev | qd)
+       CLS_PBIG = 1 << 9 };   // ... of more than 4 even terms / more than 8 coefficients: the long unrolled chains
+
 
 template <typename T>
 struct Ray {
@@ -85,22 +111,10 @@ template <typename T> __device__ __forceinline__ bool t_isnan(T a) { return a !=
 // +normal/+inf; NaNs are bits 0-1)?  The mask is a runtime operand.
 __device__ __forceinline__ bool t_class(double a, int mask) { return __builtin_amdgcn_class(a, mask); }
 __device__ __forceinline__ bool t_class(float a, int mask) { return __builtin_amdgcn_classf(a, mask); }
-constexpr int kClassPositive = 0x380, kClassNegative = 0x01c;
+constexpr int kClassPositive = 0x380, kClassNegative = 0x01c, kClassNonFinite = 0x207;   // 0x207: NaNs and both infinities
 
 __device__ __forceinline__ double t_abs(double a) { return __builtin_fabs(a); }
 __device__ __forceinline__ float t_abs(float a) { return __builtin_fabsf(a); }
-
-template <typename T> __device__ __forceinline__ T t_max(T a, T b);
-template <> __device__ __forceinline__ double t_max<double>(double a, double b) { return __builtin_fmax(a, b); }
-template <> __device__ __forceinline__ float t_max<float>(float a, float b) { return __builtin_fmaxf(a, b); }
-template <typename T> __device__ __forceinline__ T t_tiny();
-template <> __device__ __forceinline__ double t_tiny<double>() { return 1e-300; }
-template <> __device__ __forceinline__ float t_tiny<float>() { return 1e-36f; }
-
-// Keep a value in a VGPR at this point: stops the compiler from sinking the expensive
-// expression that produced it under a lane mask (a branchy select would split the block and
-// serialise the two rays of a lane).
-template <typename T> __device__ __forceinline__ void pin(T& v) { asm volatile("" : "+v"(v)); }
 
 // Fast reciprocal / reciprocal square root (MATH_FAST): hardware seed (relative error
 // 2^-24.4 / 2^-24.2 on gfx950, tools/ubench.hip) + ONE cubically convergent step:
@@ -133,7 +147,7 @@ __device__ __forceinline__ float fast_rsqrt(float a)
     const float e = __builtin_fmaf(-a * r0, r0, 1.0f);
     return __builtin_fmaf(r0, 0.5f * e, r0);
 }
-// sqrt(a) = a * rsqrt(a); a == 0 -> 0 (the seed is +inf there); a < 0 -> NaN.
+// sqrt(a) = a * rsqrt(a) for a > 0; a < 0 -> NaN (a ray that misses, :9).
 // Float64: g = a r0 refined by ONE Newton step, g (1 + e/2) with e = 1 - g r0: error 3/8 e^2 ~ 2^-50
 // — 5 instructions instead of the 7 of a * fast_rsqrt(a), and it is the sqrt, not the reciprocal root,
 // that the sphere rows need twice per intersection.  Measured against the IEEE policy on configs 2 and 3:
@@ -146,35 +160,53 @@ __device__ __forceinline__ double sqrt_core(double a)
     return __builtin_fma(g, e, g);
 }
 __device__ __forceinline__ float sqrt_core(float a) { return a * fast_rsqrt(a); }
-// sqrt with the reference's edge cases: 0 -> 0, negative (miss / TIR) -> NaN.  The seed of rsq(0) is +inf
-// and 0 * inf = NaN; seeding from a + tiny instead costs one add where a compare and two selects would:
-// a + tiny == a for every a > 1e-284, a = 0 gives 0 * rsq(tiny) = 0 exactly, and a negative radicand
-// (|a| >> tiny) still gives NaN.
-__device__ __forceinline__ double fast_sqrt(double a)
+// (a = 0 gives 0 * inf = NaN, a < 0 NaN: every radicand of the fast arms that can reach zero is a BRANCH quantity of the
+// reference — sag discriminant, refraction discriminant — whose neighbourhood raises `odd`, so the value is never used there)
+
+// p(y), Horner (Types.jl:21-27 restricted to a power series): acc = c[nc-1]; acc = acc * y + c[j], j = nc-2 .. 0 — the
+// loop of the reference restatement, unrolled: a wave-uniform switch enters the chain at the table's width nc, so the
+// operations and their order are the loop's (no zero padding: 0 * inf would differ), the coefficient reads have fixed
+// LDS addresses and nothing waits per term.  pc = the row's value coefficients (record layout: kPolyRec above).
+#define ORT_HORNER_CASE(n, c) case n: acc = acc * y + (c)[n - 2]; [[fallthrough]];
+template <typename T>
+__device__ __forceinline__ T poly_eval(const T* __restrict__ pc, int nc, T y)
 {
-    const double r0 = __builtin_amdgcn_rsq(a + 1e-300);
-    const double g = a * r0, h = 0.5 * r0;
-    const double e = __builtin_fma(-h, g, 0.5);
-    return __builtin_fma(g, e, g);
+    T acc = pc[nc - 1];
+    switch (nc) {
+    ORT_HORNER_CASE(12, pc) ORT_HORNER_CASE(11, pc) ORT_HORNER_CASE(10, pc) ORT_HORNER_CASE(9, pc) ORT_HORNER_CASE(8, pc)
+    ORT_HORNER_CASE(7, pc) ORT_HORNER_CASE(6, pc) ORT_HORNER_CASE(5, pc) ORT_HORNER_CASE(4, pc) ORT_HORNER_CASE(3, pc)
+    case 2: acc = acc * y + pc[0]; [[fallthrough]];
+    default: break;
+    }
+    return acc;
 }
-__device__ __forceinline__ float fast_sqrt(float a) { return a * fast_rsqrt(a + 1e-36f); }
-
-// sqrt of a strictly positive argument (caller clamps): no guard.
+// p'(y): analytic derivative.  The reference takes a complex step with eps = 2^-26 (RayTracing.jl:103); for a polynomial
+// that equals p' up to O(eps^2) relative.  dc[j] = (j+1) c_{j+1}: acc = dc[nc-2]; acc = acc * y + dc[j], j = nc-3 .. 0.
 template <typename T>
-__device__ __forceinline__ T fast_sqrt_pos(T a) { return sqrt_core(a); }
+__device__ __forceinline__ T poly_deriv(const T* __restrict__ dc, int nc, T y)
+{
+    if (nc < 2) return T(0);
+    T acc = dc[nc - 2];
+    switch (nc - 1) {
+    ORT_HORNER_CASE(11, dc) ORT_HORNER_CASE(10, dc) ORT_HORNER_CASE(9, dc) ORT_HORNER_CASE(8, dc) ORT_HORNER_CASE(7, dc)
+    ORT_HORNER_CASE(6, dc) ORT_HORNER_CASE(5, dc) ORT_HORNER_CASE(4, dc) ORT_HORNER_CASE(3, dc)
+    case 2: acc = acc * y + dc[0]; [[fallthrough]];
+    default: break;
+    }
+    return acc;
+}
+#undef ORT_HORNER_CASE
 
-// p(y), Horner (Types.jl:21-27 restricted to a power series).
+// Loop forms over a raw coefficient row c[0 .. nc-1] (meridional kernels: a handful of rays per launch).
 template <typename T>
-__device__ __forceinline__ T poly_eval(const T* __restrict__ c, int nc, T y)
+__device__ __forceinline__ T poly_eval_loop(const T* __restrict__ c, int nc, T y)
 {
     T acc = c[nc - 1];
     for (int j = nc - 2; j >= 0; --j) acc = acc * y + c[j];
     return acc;
 }
-// p'(y): analytic derivative.  The reference takes a complex step with eps = 2^-26
-// (RayTracing.jl:103); for a polynomial that equals p' up to O(eps^2) relative.
 template <typename T>
-__device__ __forceinline__ T poly_deriv(const T* __restrict__ c, int nc, T y)
+__device__ __forceinline__ T poly_deriv_loop(const T* __restrict__ c, int nc, T y)
 {
     if (nc < 2) return T(0);
     T acc = T(nc - 1) * c[nc - 1];
@@ -182,25 +214,37 @@ __device__ __forceinline__ T poly_deriv(const T* __restrict__ c, int nc, T y)
     return acc;
 }
 
-// MATH_FAST forms with fused multiply-adds.  p is needed at the vertex-plane y (sag, :13) and the two
-// derivatives at the surface point (tilt, :18-19, Q2), so p' (y) and p'(x) share one Horner pass in
-// which every coefficient is read (LDS broadcast) and scaled by its power once.
-template <typename T>
-__device__ __forceinline__ T poly_eval_fast(const T* __restrict__ c, int nc, T y)
+// MATH_FAST forms: fused, fixed length (zero padded).  FORM 0 / 1: every odd coefficient of the row is zero (the
+// usual even asphere): p(y) = E(y^2) with NE = 4 / 6 terms, p'(y) = y Q(y^2); x^2 and y^2 are shared with the conic's
+// r^2.  FORM 2 / 3: general series of <= 8 / 12 coefficients.  pl = the row's staged block: ev | qd, or pc | dc.
+template <typename T, int N>
+__device__ __forceinline__ T horner_fast(const T* __restrict__ c, T t)
 {
-    T acc = c[nc - 1];
-    for (int j = nc - 2; j >= 0; --j) acc = t_fma<T>(acc, y, c[j]);
+    T acc = c[N - 1];
+#pragma unroll
+    for (int j = N - 2; j >= 0; --j) acc = t_fma<T>(acc, t, c[j]);
     return acc;
 }
-template <typename T>
-__device__ __forceinline__ void poly_deriv2_fast(const T* __restrict__ c, int nc, T y, T x, T& dpy, T& dpx)
+template <typename T, int FORM>
+__device__ __forceinline__ T poly_value_fast(const T* __restrict__ pl, T y)
 {
-    if (nc < 2) { dpy = T(0); dpx = T(0); return; }
-    dpy = dpx = T(nc - 1) * c[nc - 1];
-    for (int j = nc - 2; j >= 1; --j) {
-        const T dj = T(j) * c[j];
-        dpy = t_fma<T>(dpy, y, dj);
-        dpx = t_fma<T>(dpx, x, dj);
+    if (FORM == 0) return horner_fast<T, 4>(pl, y * y);
+    if (FORM == 1) return horner_fast<T, 6>(pl, y * y);
+    if (FORM == 2) return horner_fast<T, 8>(pl, y);
+    return horner_fast<T, 12>(pl, y);
+}
+// tilt slopes (:18-19, Q2): tx = x is + p'(x), ty = y is + p'(y), `is` = sign(R) / sqrt(R^2 - r^2 (1+K)) (0 on a flat row)
+template <typename T, int FORM>
+__device__ __forceinline__ void poly_tilt_fast(const T* __restrict__ pl, T x, T y, T xx, T yy, T is, T& tx, T& ty)
+{
+    if (FORM == 0 || FORM == 1) {
+        constexpr int NQ = FORM == 0 ? 3 : 5;
+        tx = x * (is + horner_fast<T, NQ>(pl + 6, xx));
+        ty = y * (is + horner_fast<T, NQ>(pl + 6, yy));
+    } else {
+        constexpr int ND = FORM == 2 ? 7 : 11;
+        tx = t_fma<T>(x, is, horner_fast<T, ND>(pl + kPolyMax, x));
+        ty = t_fma<T>(y, is, horner_fast<T, ND>(pl + kPolyMax, y));
     }
 }
 
@@ -329,8 +373,9 @@ __device__ __forceinline__ double ieee_div_nofix(double a, double b, double r)
 // bit for bit except for a = -0.0 (-> +0.0), and a zero's sign reaches no output (no division by it).
 template <typename T, bool FINITE, bool HASP, bool LAST>
 __device__ __forceinline__ void surface_step_ieee(Ray<T>& r, const SurfRec<T>& s,
-                                                  const T* __restrict__ coef)
+                                                  const T* __restrict__ pl)      // the row's pc | dc block (HASP rows)
 {
+    const int nc = HASP ? __builtin_amdgcn_readfirstlane(s.ncoef) : 0;           // wave-uniform: the Horner switch is a scalar branch
     const T tcur = s.t - r.sprev;                    // ts[i] (:54-55 of the previous pass)
     r.y = r.y + r.u * tcur;                          // :46
     r.x = r.x + r.v * tcur;                          // :47
@@ -341,7 +386,7 @@ __device__ __forceinline__ void surface_step_ieee(Ray<T>& r, const SurfRec<T>& s
         const T D = beta * beta - r2 * ((s.opk + r.u * r.u) + r.v * r.v);   // :5
         // :7; sign(R) sqrt(D) is exact, so the fused beta + sign(R) sqrt(D) rounds once, like the reference's sum
         sg = ieee_div(r2, t_fma<T>(s.sgn, ieee_sqrt(D), beta));
-        if (HASP) sg = sg + poly_eval<T>(coef, s.ncoef, r.y);
+        if (HASP) sg = sg + poly_eval<T>(pl, nc, r.y);
         // :6,9 — D < 0 or NaN: sqrt(D) is NaN and so is sg, no select needed
     } else {
         sg = T(0);                                               // :12
@@ -368,8 +413,8 @@ __device__ __forceinline__ void surface_step_ieee(Ray<T>& r, const SurfRec<T>& s
         T tx, ty;
         ieee_div2(s.sgn * r.x, s.sgn * r.y, sq, tx, ty);         // one refined reciprocal, two quotients
         if (HASP) {
-            tx = tx + poly_deriv<T>(coef, s.ncoef, r.x);         // Q2: p'(x) on the x slope
-            ty = ty + poly_deriv<T>(coef, s.ncoef, r.y);
+            tx = tx + poly_deriv<T>(pl + kPolyMax, nc, r.x);     // Q2: p'(x) on the x slope
+            ty = ty + poly_deriv<T>(pl + kPolyMax, nc, r.y);
         }
         const T nrm = ieee_sqrt((tx * tx + ty * ty) + T(1));
         const T inv = ieee_div(T(1), nrm);
@@ -417,11 +462,18 @@ __device__ __forceinline__ void surface_step_ieee_flat(Ray<T>& r, const SurfRec<
     ieee_div2(r.k1, r.k0, r.k2, r.u, r.v);           // :59-60
 }
 
+// |a| < lim as ONE compare (source modifier); false for NaN: a ray that missed outright is no near-branch case.
+template <typename T> __device__ __forceinline__ bool near_zero(T a, T lim) { return t_abs(a) < lim; }
+
 // MATH_FAST, row with a polynomial term: the reference's slope form (sag :1-14, tilt :16-19)
 // with fused arithmetic.  r.sprev is the z offset of the ray point from the current vertex.
-template <typename T>
+// FORM: how the row's polynomial is evaluated (poly_value_fast).  `odd` (see the notes at the top): the sag
+// discriminant within kNear R^2 of zero (:6), the point within that of the conic's radius or outside it (:17: NaN tilt in
+// the reference, k untouched), the refraction discriminant within kNear of zero (:25), a refracted direction (nearly) backward.
+// FINITE = isfinite(R), TIR as for the conic rows (below): both wave-uniform class bits, so the body is straight-line.
+template <typename T, int FORM, bool FINITE, bool TIR>
 __device__ __forceinline__ void surface_step_fast_poly(Ray<T>& r, const SurfRec<T>& s,
-                                                       const T* __restrict__ coef, bool& odd)
+                                                       const T* __restrict__ pl, bool& odd)
 {
     const T ik = fast_rcp(r.k2);
     const T u = r.k1 * ik, v = r.k0 * ik;                        // :59-60
@@ -429,40 +481,42 @@ __device__ __forceinline__ void surface_step_fast_poly(Ray<T>& r, const SurfRec<
     r.y = t_fma<T>(u, tcur, r.y);
     r.x = t_fma<T>(v, tcur, r.x);
     T sg = T(0), is = T(0);
-    if (s.finite) {                                  // wave-uniform (:2)
+    if (FINITE) {                                    // (:2)
+        const T pv = poly_value_fast<T, FORM>(pl, r.y);          // p(y) at the vertex plane (:7, Q2)
         const T beta = t_fma<T>(-r.x, v, t_fma<T>(-r.y, u, s.R));
         const T r2 = t_fma<T>(r.x, r.x, r.y * r.y);
         const T A = t_fma<T>(v, v, t_fma<T>(u, u, s.opk));
         const T D = t_fma<T>(beta, beta, -(r2 * A));
-        sg = t_fma<T>(r2, fast_rcp(t_fma<T>(s.sgn, fast_sqrt(D), beta)), poly_eval_fast<T>(coef, s.ncoef, r.y));
-        sg = (D >= T(0)) ? sg : t_nan<T>();
+        odd = odd || near_zero<T>(D, s.dlim);
+        // D < 0: the root, and with it sg, is NaN (:9) — no select; D = 0 (0 * inf) is a near-branch case, retraced
+        sg = t_fma<T>(r2, fast_rcp(t_fma<T>(s.sgn, sqrt_core(D), beta)), pv);
         r.y = t_fma<T>(sg, u, r.y);
         r.x = t_fma<T>(sg, v, r.x);
-        const T rr = t_fma<T>(r.x, r.x, r.y * r.y);
-        const T rad = t_fma<T>(-rr, s.opk, s.R2);
-        odd = odd || t_class(rad, kClassNegative);   // outside the conic's radius: NaN tilt in the reference (:17), k untouched
-        is = s.sgn * fast_rsqrt(rad);
     }                                                // flat row: sag = 0 without p(y) (:12), tilt = p' only (:18)
+    const T xx = r.x * r.x, yy = r.y * r.y;
+    if (FINITE) {
+        const T rad = t_fma<T>(-(xx + yy), s.opk, s.R2);
+        odd = odd || (rad < s.dlim);
+        is = s.sgn * fast_rsqrt(rad);
+    }
     r.sprev = sg;
-    T dpy, dpx;
-    poly_deriv2_fast<T>(coef, s.ncoef, r.y, r.x, dpy, dpx);
-    const T tx = t_fma<T>(r.x, is, dpx);                         // Q2: p'(x) on the x slope
-    const T ty = t_fma<T>(r.y, is, dpy);
+    T tx, ty;
+    poly_tilt_fast<T, FORM>(pl, r.x, r.y, xx, yy, is, tx, ty);   // Q2: p'(x) on the x slope, p'(y) on the y slope
     const T inv = fast_rsqrt(t_fma<T>(tx, tx, t_fma<T>(ty, ty, T(1))));
-    const T m0 = tx * inv, m1 = ty * inv, m2 = -inv;
-    const T g = -t_fma<T>(r.k2, m2, t_fma<T>(r.k1, m1, r.k0 * m0));
+    // un-normalised normal N = (tx, ty, -1), m = N inv:  g = -k.m,  k' = eta k + (eta g - sqrt(D2)) inv N
+    const T g = t_fma<T>(-r.k1, ty, t_fma<T>(-r.k0, tx, r.k2)) * inv;
     const T D2 = t_fma<T>(-s.eta2, t_fma<T>(-g, g, T(1)), T(1));
-    const bool ok = D2 >= T(0);
-    T cf = t_fma<T>(s.eta, g, -fast_sqrt_pos<T>(t_max<T>(D2, t_tiny<T>())));
-    pin(cf);
-    cf = ok ? cf : T(0);
-    const T ee = ok ? s.eta : T(1);
+    // TIR rows: total internal reflection (D2 < 0: the reference leaves k untouched, Q1) and its neighbourhood (:25) are
+    // left to the reference sequence — one compare instead of a compare and four selects; a NaN ray is neither
+    if (TIR) odd = odd || (D2 < Near<T>::thr);
+    const T cf = t_fma<T>(s.eta, g, -sqrt_core(D2)) * inv;
+    const T ee = s.eta;
     // product on the OLD component first, then accumulate into it: the two-address v_fmac then updates k in
     // place (the other association lands in a temporary and costs a v_mov per component)
-    r.k0 = t_fma<T>(cf, m0, ee * r.k0);
-    r.k1 = t_fma<T>(cf, m1, ee * r.k1);
-    r.k2 = t_fma<T>(cf, m2, ee * r.k2);
-    odd = odd || t_class(r.k2, kClassNegative);
+    r.k0 = t_fma<T>(cf, tx, ee * r.k0);
+    r.k1 = t_fma<T>(cf, ty, ee * r.k1);
+    r.k2 = t_fma<T>(ee, r.k2, -cf);
+    odd = odd || (r.k2 < Near<T>::root);
 }
 
 // MATH_FAST, conic row (sphere, flat, conic) in direction-cosine form.  With the ray point
@@ -480,8 +534,10 @@ __device__ __forceinline__ void surface_step_fast_poly(Ray<T>& r, const SurfRec<
 template <typename T> struct ConicHit { T cn, n2, cosi, cos2; };   // n = (-cn x, -cn y, n2), cos I = k.n
 
 // Transfer to the row and intersection.  Returns false when the row does not refract (flat, eta == 1).
+// `odd` (curved rows): the discriminant E2 (= cos^2 of incidence, dimensionless) within kNear of zero — the miss branch
+// (:6) —, and the hit at or beyond the equator / the conic's radius (axial component of the normal below sqrt(kNear)).
 template <typename T, int KIND, bool REFR>
-__device__ __forceinline__ bool fast_conic_hit(Ray<T>& r, const SurfRec<T>& s, ConicHit<T>& h)
+__device__ __forceinline__ bool fast_conic_hit(Ray<T>& r, const SurfRec<T>& s, ConicHit<T>& h, bool& odd)
 {
     const T z0 = r.sprev - s.t;
     const T c = s.invR;
@@ -498,13 +554,15 @@ __device__ __forceinline__ bool fast_conic_hit(Ray<T>& r, const SurfRec<T>& s, C
         const T F = t_fma<T>(c, P2, T(-2) * z0);
         const T G = t_fma<T>(-c, Pk, r.k2);
         const T E2 = t_fma<T>(G, G, -(c * F));
-        const T E = fast_sqrt(E2);                            // NaN when the ray misses (:9)
+        odd = odd || near_zero<T>(E2, Near<T>::thr);
+        const T E = sqrt_core(E2);                            // NaN when the ray misses (:9); E2 = 0 is retraced
         const T d = F * fast_rcp(G + E);
         r.x = t_fma<T>(d, r.k0, r.x);
         r.y = t_fma<T>(d, r.k1, r.y);
         const T z = t_fma<T>(d, r.k2, z0);
         r.sprev = z;
         h.cn = c; h.n2 = t_fma<T>(-c, z, T(1));                  // unit GEOMETRIC normal (-c x, -c y, 1 - c z)
+        odd = odd || (h.n2 < Near<T>::root);                     // at / beyond the equator: the reference keeps the vertex-side slope
         h.cosi = E; h.cos2 = E2;                                 // k.n = sqrt(G^2 - c F)
     } else {
         const T zk = s.opk * z0;
@@ -514,15 +572,18 @@ __device__ __forceinline__ bool fast_conic_hit(Ray<T>& r, const SurfRec<T>& s, C
         const T G = t_fma<T>(-c, Pk, r.k2);
         const T a = c * t_fma<T>(s.K * r.k2, r.k2, T(1));
         const T E2 = t_fma<T>(G, G, -(a * F));
-        const T E = fast_sqrt(E2);
+        odd = odd || near_zero<T>(E2, Near<T>::thr);
+        const T E = sqrt_core(E2);
         const T d = F * fast_rcp(G + E);
         r.x = t_fma<T>(d, r.k0, r.x);
         r.y = t_fma<T>(d, r.k1, r.y);
         const T z = t_fma<T>(d, r.k2, z0);
         r.sprev = z;
         // |N2|: the reference's tilt is the slope of the VERTEX-side sheet (PupilSampling.jl:16-19), whose normal
-        // has a positive axial component also where the chosen root lies on the far sheet (free source modifier)
+        // has a positive axial component also where the chosen root lies on the far sheet (free source modifier);
+        // N2^2 = (R^2 - r^2 (1+K)) / R^2, the tilt's radicand (:17): near zero the slope blows up -> retraced
         const T N0 = c * r.x, N1 = c * r.y, N2 = t_abs(t_fma<T>(-c * s.opk, z, T(1)));
+        odd = odd || (N2 < Near<T>::root);
         const T inv = fast_rsqrt(t_fma<T>(N2, N2, t_fma<T>(N1, N1, N0 * N0)));
         h.cn = c * inv; h.n2 = N2 * inv;
         h.cosi = t_fma<T>(r.k2, h.n2, -h.cn * t_fma<T>(r.k1, r.y, r.k0 * r.x));
@@ -533,37 +594,32 @@ __device__ __forceinline__ bool fast_conic_hit(Ray<T>& r, const SurfRec<T>& s, C
 
 // vector Snell (:21-32) with n = -m:  k' = eta k + (cos I' - eta cos I) n
 //   1 - eta^2 (1 - cos^2 I) = (1 - eta^2) + eta^2 cos^2 I
+// TIR rows: a radicand within kNear of zero (:25) raises `odd`.
 template <typename T, bool TIR>
-__device__ __forceinline__ void fast_snell(Ray<T>& r, const SurfRec<T>& s, const ConicHit<T>& h)
+__device__ __forceinline__ void fast_snell(Ray<T>& r, const SurfRec<T>& s, const ConicHit<T>& h, bool& odd)
 {
     const T D2 = t_fma<T>(s.eta2, h.cos2, s.ome2);
-    T cp = fast_sqrt_pos<T>(t_max<T>(D2, t_tiny<T>()));          // radicand clamped: no NaN, sqrt(0) ~ 0
-    T gam = t_fma<T>(-s.eta, h.cosi, cp);
-    T ee = s.eta;
-    if (TIR) {                                                   // TIR / NaN: k stays (Q1)
-        pin(gam);
-        const bool ok = D2 >= T(0);
-        gam = ok ? gam : T(0);
-        ee = ok ? ee : T(1);
-    }
+    // TIR rows: D2 < 0 (k untouched in the reference, Q1) and the neighbourhood of the branch (:25) raise `odd` — the
+    // wave retraces with the reference sequence, so no select here; elsewhere D2 >= 1 - eta^2 > 0.  NaN passes through.
+    if (TIR) odd = odd || (D2 < Near<T>::thr);
+    const T gam = t_fma<T>(-s.eta, h.cosi, sqrt_core(D2));
     const T gc = gam * h.cn;
-    r.k0 = t_fma<T>(-gc, r.x, ee * r.k0);                        // in-place form, see surface_step_fast_poly
-    r.k1 = t_fma<T>(-gc, r.y, ee * r.k1);
-    r.k2 = t_fma<T>(gam, h.n2, ee * r.k2);
+    r.k0 = t_fma<T>(-gc, r.x, s.eta * r.k0);                     // in-place form, see surface_step_fast_poly
+    r.k1 = t_fma<T>(-gc, r.y, s.eta * r.k1);
+    r.k2 = t_fma<T>(gam, h.n2, s.eta * r.k2);
 }
 
-// `odd`: see the MATH_FAST notes at the top.  Flat rows cannot raise it (k2' = cos I' >= 0); curved rows test the
-// refracted k2 (one v_cmp_class) and, spheres, the side of the equator the hit lies on (one more).
+// `odd`: see the MATH_FAST notes at the top.  Flat rows raise it only through the TIR radicand (k2' = cos I' >= 0);
+// curved rows also test the refracted k2 (one compare).
 template <typename T, int KIND, bool REFR, bool TIR>
 __device__ __forceinline__ void surface_step_fast_conic(Ray<T>& r, const SurfRec<T>& s, bool& odd)
 {
     ConicHit<T> h;
-    if (!fast_conic_hit<T, KIND, REFR>(r, s, h)) return;
-    if (KIND == KIND_SPHERE) odd = odd || t_class(h.n2, kClassNegative);    // beyond the equator: 1 - c z < 0
-    fast_snell<T, TIR>(r, s, h);
+    if (!fast_conic_hit<T, KIND, REFR>(r, s, h, odd)) return;
+    fast_snell<T, TIR>(r, s, h, odd);
     // backward direction: impossible for 0 < eta <= 1 (gam >= 0 and the normal's axial component is positive once
     // far-cap hits are out), so only the rows of the TIR class (eta > 1, or a mirror's eta < 0) are tested
-    if (KIND != KIND_FLAT && TIR) odd = odd || t_class(r.k2, kClassNegative);
+    if (KIND != KIND_FLAT && TIR) odd = odd || (r.k2 < Near<T>::root);
 }
 
 // MATH_FAST, strongly curved sphere (|R| <= kCentreFormMaxR) in CENTRE form: with Q = P - C
@@ -582,7 +638,7 @@ __device__ __forceinline__ void fast_sphere_c_hit(Ray<T>& r, const SurfRec<T>& s
     const T b = t_fma<T>(Qz0, r.k2, t_fma<T>(r.y, r.k1, r.x * r.k0));
     const T q = t_fma<T>(Qz0, Qz0, t_fma<T>(r.y, r.y, r.x * r.x));
     disc = t_fma<T>(b, b, s.R2 - q);
-    sq = fast_sqrt(disc);                                        // NaN when the ray misses (:9)
+    sq = sqrt_core(disc);                                        // NaN when the ray misses (:9); disc = 0 is retraced
     const T d = -t_fma<T>(s.sgn, sq, b);
     r.x = t_fma<T>(d, r.k0, r.x);
     r.y = t_fma<T>(d, r.k1, r.y);
@@ -590,78 +646,126 @@ __device__ __forceinline__ void fast_sphere_c_hit(Ray<T>& r, const SurfRec<T>& s
     r.sprev = Qz + s.R;
 }
 
-// Snell coefficients with the geometric normal -Q/R (every hit on the vertex-side cap): D2 = radicand of
-// cos I', gam = cos I' - eta cos I.
+// Snell with the geometric normal -Q/R (every hit on the vertex-side cap): D2 = radicand of cos I',
+// gam = cos I' - eta cos I,  k' = eta k + gam n.
 template <typename T>
-__device__ __forceinline__ void fast_sphere_c_coeffs(const SurfRec<T>& s, T sq, T disc, T& D2, T& gam)
+__device__ __forceinline__ void fast_sphere_c_refract(Ray<T>& r, const SurfRec<T>& s, T sq, T Qz, T D2)
 {
-    D2 = t_fma<T>(s.e2c2, disc, s.ome2);                         // (1 - eta^2) + eta^2 cos^2 I
-    const T cp = fast_sqrt_pos<T>(t_max<T>(D2, t_tiny<T>()));
-    gam = t_fma<T>(-s.ec, sq, cp);                               // cos I = |c| sq
-}
-
-template <typename T, bool TIR>
-__device__ __forceinline__ void fast_sphere_c_apply(Ray<T>& r, const SurfRec<T>& s, T Qz, T D2, T gam)
-{
-    T ee = s.eta;
-    if (TIR) {                                                   // TIR / NaN: k stays (Q1)
-        pin(gam);
-        const bool ok = D2 >= T(0);
-        gam = ok ? gam : T(0);
-        ee = ok ? ee : T(1);
-    }
+    const T gam = t_fma<T>(-s.ec, sq, sqrt_core(D2));            // cos I = |c| sq
     const T gc = gam * s.invR;
-    r.k0 = t_fma<T>(-gc, r.x, ee * r.k0);                        // in-place form, see surface_step_fast_poly
-    r.k1 = t_fma<T>(-gc, r.y, ee * r.k1);
-    r.k2 = t_fma<T>(-gc, Qz, ee * r.k2);
+    r.k0 = t_fma<T>(-gc, r.x, s.eta * r.k0);                     // in-place form, see surface_step_fast_poly
+    r.k1 = t_fma<T>(-gc, r.y, s.eta * r.k1);
+    r.k2 = t_fma<T>(-gc, Qz, s.eta * r.k2);
 }
 
-// Centre-form row.  `odd` (see the MATH_FAST notes at the top): sign(R) Qz > 0 is a hit beyond the equator — ONE
-// v_cmp_class against the row's mask, NaN-safe — and a negative refracted k2 one more.
+// Centre-form row.  `odd` (see the MATH_FAST notes at the top), one compare each: the discriminant within kNear R^2 of
+// zero (the miss branch, :6); the sag |z| = |Qz + R| beyond |R| (1 - sqrt(kNear)) — the hit at or past the equator
+// (z / R runs from 0 at the vertex to 1 at the equator and 2 at the far pole), NaN-safe; TIR rows: the refraction
+// radicand below kNear — total internal reflection itself and the neighbourhood of its branch (:25) — and a refracted
+// k2 that is not clearly forward.
 template <typename T, bool TIR>
 __device__ __forceinline__ void surface_step_fast_sphere_c(Ray<T>& r, const SurfRec<T>& s, bool& odd)
 {
-    T sq, disc, Qz, D2, gam;
+    T sq, disc, Qz;
     fast_sphere_c_hit<T>(r, s, sq, disc, Qz);
-    fast_sphere_c_coeffs<T>(s, sq, disc, D2, gam);
-    odd = odd || t_class(Qz, s.farmask);
-    fast_sphere_c_apply<T, TIR>(r, s, Qz, D2, gam);
-    if (TIR) odd = odd || t_class(r.k2, kClassNegative);        // see surface_step_fast_conic
+    odd = odd || near_zero<T>(disc, s.dlim);
+    odd = odd || (t_abs(r.sprev) > s.zlim);
+    const T D2 = t_fma<T>(s.e2c2, disc, s.ome2);                 // (1 - eta^2) + eta^2 cos^2 I
+    if (TIR) odd = odd || (D2 < Near<T>::thr);                   // TIR and its neighbourhood: see fast_snell
+    fast_sphere_c_refract<T>(r, s, sq, Qz, D2);
+    if (TIR) odd = odd || (r.k2 < Near<T>::root);                // see surface_step_fast_conic
+}
+
+// ---- table construction, shared by the host (ort_system_create) and the device (k_build_tables) -----------------
+// One record from row i+1 of the prescription as loop iteration i sees it.  nc = coefficients in use (0: p = zero),
+// pcls = the CLS_P* bits of the row's polynomial record.  Every derived field is ONE IEEE operation on the row's data,
+// the same on both sides.
+// Returns the row's ARMS level (below).
+template <typename T>
+__host__ __device__ inline int make_rec(SurfRec<T>& r, T t, T Rv, T n1, T n2, T Kv, int nc, int pcls)
+{
+    r.t = t; r.R = Rv; r.R2 = Rv * Rv;
+    r.sgn = Rv > T(0) ? T(1) : (Rv < T(0) ? T(-1) : Rv);
+    r.opk = T(1) + Kv; r.eta = n1 / n2; r.eta2 = r.eta * r.eta; r.K = Kv;
+    r.finite = __builtin_isfinite(Rv) ? 1 : 0;
+    r.invR = r.finite ? T(1) / Rv : T(0);
+    const T absc = r.invR < T(0) ? -r.invR : r.invR, absR = Rv < T(0) ? -Rv : Rv;
+    r.ome2 = T(1) - r.eta2; r.e2c2 = r.eta2 * (r.invR * r.invR); r.ec = r.eta * absc;
+    r.dlim = r.finite ? (T)Near<T>::thr * r.R2 : T(0);
+    r.zlim = r.finite ? absR * (T(1) - (T)Near<T>::root) : T(0);
+    r.ncoef = nc; r.spare = 0;
+    int kind = nc > 0 ? KIND_POLY : (!r.finite ? KIND_FLAT : (Kv != T(0) ? KIND_CONIC : KIND_SPHERE));
+    if (kind == KIND_SPHERE && (double)absR <= kCentreFormMaxR && sizeof(T) == 8) {
+        kind = KIND_SPHERE_C;                  // MATH_FAST centre form; K (== 0 here) carries t + R
+        r.K = r.t + Rv;
+    }
+    r.cls = (r.finite ? CLS_FINITE : 0) | (nc > 0 ? CLS_HASP : 0) | ((r.eta != T(1)) ? CLS_REFR : 0) |
+            (!(r.eta > T(0) && r.eta <= T(1)) ? CLS_TIR : 0) | (kind << CLS_KIND_SHIFT) | (nc > 0 ? pcls : 0);
+    return kind == KIND_POLY ? 2 : (kind == KIND_CONIC || (kind == KIND_SPHERE && sizeof(T) == 8)) ? 1 : 0;
+}
+
+// One polynomial record (layout: kPolyRec above) from a raw coefficient row c[0 .. ncoef); returns its CLS_P* bits.
+// `nc_out`: the table width when any coefficient is non-zero AFTER the cast to T, else 0 (an all-zero row is the
+// reference's `zero` polynomial).
+template <typename T>
+__host__ __device__ inline int make_poly_rec(T* rec, const double* c, int ncoef, int* nc_out)
+{
+    for (int j = 0; j < kPolyRec; ++j) rec[j] = T(0);
+    int top = -1; bool odd_nz = false;
+    for (int j = 0; j < ncoef && j < kPolyMax; ++j) {
+        const T v = c ? (T)c[j] : T(0);
+        rec[j] = v;
+        if (v != T(0)) { top = j; odd_nz = odd_nz || (j & 1); }
+    }
+    for (int j = 0; j + 1 < kPolyMax; ++j) rec[kPolyMax + j] = T(j + 1) * rec[j + 1];
+    for (int k = 0; k < 6; ++k) rec[24 + k] = rec[2 * k];
+    for (int k = 0; k < 5; ++k) rec[30 + k] = T(2 * k + 2) * rec[2 * k + 2];
+    *nc_out = top >= 0 ? ncoef : 0;
+    int cls = odd_nz ? 0 : CLS_PEVEN;
+    if ((!odd_nz && top > 6) || (odd_nz && top > 7)) cls |= CLS_PBIG;
+    return cls;
 }
 
 // All N rays of a lane through one surface.  `cls` packs the row's wave-uniform class bits
 // (scalar register): the branch is taken once per surface, the bodies are straight-line.
-enum { CLS_FINITE = 1, CLS_HASP = 2, CLS_REFR = 4, CLS_TIR = 8, CLS_KIND_SHIFT = 4 };
-
 // odd (MATH_FAST only): raised when a ray of this lane leaves the domain of the fast forms (see the notes at the top).
 // last (MATH_IEEE only, wave-uniform): this is the final loop iteration, see surface_step_ieee.
-template <typename T, int MATH, int N>
+// ARMS: which row classes the kernel build carries (make_rec's `arms` level of a row; a batch runs the build of its
+// highest row).  Every arm that shares the surface loop costs the others register copies at the loop's merge points
+// (the allocator gives the loop-carried ray state different homes in different arms), so the loop of a plain
+// spherical system holds the centre-form sphere and flat arms and NOTHING else:
+//   ARMS_BASIC    centre-form spheres (Float32: general-form spheres) + flat rows
+//   ARMS_GENERAL  + general-form spheres (Float64 rows with |R| > kCentreFormMaxR) and conics
+//   ARMS_POLY     + polynomial rows: two interleaved ~100-instruction chains + the row's coefficients need the
+//                 128-VGPR budget (k_trace's launch bounds); at 96 they park tens of values per row in scratch
+enum { ARMS_BASIC = 0, ARMS_GENERAL = 1, ARMS_POLY = 2 };
+template <typename T, int MATH, int N, int ARMS>
 __device__ __forceinline__ void surface_step_n(Ray<T> (&r)[N], const SurfRec<T>& s,
-                                               const T* __restrict__ coef, int cls, bool last, bool& odd)
+                                               const T* __restrict__ pl, int cls, bool last, bool& odd)
 {
 #define ORT_ALL_RAYS(call) _Pragma("unroll") for (int q = 0; q < N; ++q) { call; }
     if (MATH == MATH_IEEE) {
         // hot arms first (spherical / conic rows and flat rows without a polynomial), as independent ifs; rows
         // with a polynomial and the final iteration share one grouped arm
-        const bool fin = cls & CLS_FINITE, hasp = cls & CLS_HASP;
-        if (fin && !hasp && !last)  { ORT_ALL_RAYS((surface_step_ieee<T, true, false, false>(r[q], s, coef))) }
+        const bool fin = cls & CLS_FINITE, hasp = ARMS >= ARMS_POLY && (cls & CLS_HASP);
+        if (fin && !hasp && !last)  { ORT_ALL_RAYS((surface_step_ieee<T, true, false, false>(r[q], s, pl))) }
         if (!fin && !hasp && !last) { ORT_ALL_RAYS((surface_step_ieee_flat<T>(r[q], s))) }
         if (hasp || last) {
             if (last) {
                 if (fin) {
-                    if (hasp) { ORT_ALL_RAYS((surface_step_ieee<T, true, true, true>(r[q], s, coef))) }
-                    else      { ORT_ALL_RAYS((surface_step_ieee<T, true, false, true>(r[q], s, coef))) }
-                } else        { ORT_ALL_RAYS((surface_step_ieee<T, false, false, true>(r[q], s, coef))) }
+                    if (hasp) { ORT_ALL_RAYS((surface_step_ieee<T, true, true, true>(r[q], s, pl))) }
+                    else      { ORT_ALL_RAYS((surface_step_ieee<T, true, false, true>(r[q], s, pl))) }
+                } else        { ORT_ALL_RAYS((surface_step_ieee<T, false, false, true>(r[q], s, pl))) }
             } else {
-                if (fin) { ORT_ALL_RAYS((surface_step_ieee<T, true, true, false>(r[q], s, coef))) }
-                else     { ORT_ALL_RAYS((surface_step_ieee<T, false, true, false>(r[q], s, coef))) }
+                if (fin) { ORT_ALL_RAYS((surface_step_ieee<T, true, true, false>(r[q], s, pl))) }
+                else     { ORT_ALL_RAYS((surface_step_ieee<T, false, true, false>(r[q], s, pl))) }
             }
         }
     } else {
         // INDEPENDENT ifs on scalar conditions, not an else-if chain: each arm merges only with its own skip
         // path, which the register coalescer joins with the loop-carried state (updates in place); a multi-arm
         // merge costs a v_mov_b64 per state component per surface.
-        const int kind = cls >> CLS_KIND_SHIFT;
+        const int kind = (cls >> CLS_KIND_SHIFT) & 7;
         const bool tir = cls & CLS_TIR;
         const bool refr = cls & CLS_REFR;
         if (kind == KIND_SPHERE_C && !tir) { ORT_ALL_RAYS((surface_step_fast_sphere_c<T, false>(r[q], s, odd))) }
@@ -672,15 +776,24 @@ __device__ __forceinline__ void surface_step_n(Ray<T> (&r)[N], const SurfRec<T>&
         constexpr bool kF32 = sizeof(T) == 4;
         if (kF32 && kind == KIND_SPHERE && !tir) { ORT_ALL_RAYS((surface_step_fast_conic<T, KIND_SPHERE, true, false>(r[q], s, odd))) }
         if (kF32 && kind == KIND_SPHERE && tir)  { ORT_ALL_RAYS((surface_step_fast_conic<T, KIND_SPHERE, true, true>(r[q], s, odd))) }
-        if ((!kF32 && kind == KIND_SPHERE) || kind == KIND_CONIC || kind == KIND_POLY) {   // the general forms share ONE arm:
+        if (ARMS >= ARMS_GENERAL && ((!kF32 && kind == KIND_SPHERE) || kind == KIND_CONIC || (ARMS >= ARMS_POLY && kind == KIND_POLY))) {   // the general forms share ONE arm:
             // as independent arms they drag their merge copies back onto the path of the sphere / flat rows (measured)
             if (!kF32 && kind == KIND_SPHERE) {
                 if (tir) { ORT_ALL_RAYS((surface_step_fast_conic<T, KIND_SPHERE, true, true>(r[q], s, odd))) }
                 else     { ORT_ALL_RAYS((surface_step_fast_conic<T, KIND_SPHERE, true, false>(r[q], s, odd))) }
             } else if (kind == KIND_CONIC) {
                 ORT_ALL_RAYS((surface_step_fast_conic<T, KIND_CONIC, true, true>(r[q], s, odd)))
-            } else {
-                ORT_ALL_RAYS((surface_step_fast_poly<T>(r[q], s, coef, odd)))
+            } else if (ARMS >= ARMS_POLY) {
+                // polynomial rows: FORM = how p is evaluated (even form needs a finite R: the staged block is ev | qd only then)
+                const bool fin = cls & CLS_FINITE, big = cls & CLS_PBIG, even = (cls & CLS_PEVEN) && fin;
+#define ORT_POLY_ARM(FORM, FIN) { if (tir) { ORT_ALL_RAYS((surface_step_fast_poly<T, FORM, FIN, true>(r[q], s, pl, odd))) } \
+                                  else     { ORT_ALL_RAYS((surface_step_fast_poly<T, FORM, FIN, false>(r[q], s, pl, odd))) } }
+                if (even && !big)             ORT_POLY_ARM(0, true)
+                else if (even)                ORT_POLY_ARM(1, true)
+                else if (fin && !big)         ORT_POLY_ARM(2, true)
+                else if (fin)                 ORT_POLY_ARM(3, true)
+                else                          ORT_POLY_ARM(3, false)
+#undef ORT_POLY_ARM
             }
         }
     }

@@ -104,30 +104,31 @@ struct ort_system {
     int nsys = 0, rows = 0, ncoef = 0;
     SurfRec<double>* rec64 = nullptr;
     SurfRec<float>* rec32 = nullptr;
-    double* coef64 = nullptr;
-    float* coef32 = nullptr;
+    double* coef64 = nullptr;      // [nsys][rows][ncoef] raw coefficients (meridional kernels)
+    double* poly64 = nullptr;      // [nsys][S][kPolyRec] polynomial records of the skew kernels (ort_device.hpp)
+    float* poly32 = nullptr;
     MerSurf* mer = nullptr;        // [nsys][S]
     std::vector<double> t_last;    // t[rows-1] per system (meridional ts tail)
     double* d_tlast = nullptr;     // the same on the device (aiming kernel)
     void* slab = nullptr;          // the one device allocation all of the above point into
     double* ap64 = nullptr;        // [nsys][S] squared clear semi-diameters (ort_system_set_apertures), or null
     float* ap32 = nullptr;
+    int arms64 = 0, arms32 = 0;    // highest ARMS level among the batch's rows: which kernel build runs it
 };
 
 namespace {
 
-template <typename T> T sgn_of(T R) { return R > 0 ? T(1) : (R < 0 ? T(-1) : R); }
-
+// Per-surface records (+ polynomial records when the batch carries coefficients) of nsys prescriptions; the same
+// make_rec / make_poly_rec the device-side table builder runs (ort_device.hpp).
 template <typename T>
-void build_records(int nsys, int rows, int ncoef, const double* R, const double* t, const double* n,
-                   const double* K, const double* coef, std::vector<SurfRec<T>>& out, std::vector<T>& cout)
+int build_records(int nsys, int rows, int ncoef, const double* R, const double* t, const double* n,
+                  const double* K, const double* coef, std::vector<SurfRec<T>>& out, std::vector<T>& pout)
 {
     const int S = rows - 1;
+    int arms = 0;
     out.resize((size_t)nsys * S);
-    if (coef && ncoef > 0) {
-        cout.resize((size_t)nsys * rows * ncoef);
-        for (size_t i = 0; i < cout.size(); ++i) cout[i] = (T)coef[i];
-    }
+    const bool hasp = coef && ncoef > 0;
+    if (hasp) pout.assign((size_t)nsys * S * kPolyRec, T(0));
     for (int s = 0; s < nsys; ++s) {
         const double* Rs = R + (size_t)s * rows;
         const double* ts = t + (size_t)s * rows;
@@ -136,51 +137,28 @@ void build_records(int nsys, int rows, int ncoef, const double* R, const double*
         for (int i = 0; i < S; ++i) {
             SurfRec<T> r;
             memset(&r, 0, sizeof r);
-            const T Rv = (T)Rs[i + 1];
-            const T Kv = Ks ? (T)Ks[i + 1] : T(0);
-            r.t = (T)ts[i];
-            r.R = Rv;
-            r.R2 = Rv * Rv;
-            r.sgn = sgn_of<T>(Rv);
-            r.opk = T(1) + Kv;
-            r.eta = (T)ns[i] / (T)ns[i + 1];
-            r.eta2 = r.eta * r.eta;
-            r.K = Kv;
-            r.finite = std::isfinite(Rv) ? 1 : 0;
-            r.invR = r.finite ? T(1) / Rv : T(0);
-            int nc = 0;
-            if (coef && ncoef > 0) {
-                const double* c = coef + ((size_t)s * rows + (i + 1)) * ncoef;
-                for (int j = 0; j < ncoef; ++j) if ((T)c[j] != T(0)) nc = ncoef;   // all-zero row == `zero`
-            }
-            r.ncoef = nc;
-            int kind = nc > 0 ? KIND_POLY : (!r.finite ? KIND_FLAT : (Kv != T(0) ? KIND_CONIC : KIND_SPHERE));
-            if (kind == KIND_SPHERE && std::fabs((double)Rv) <= kCentreFormMaxR && sizeof(T) == 8) {
-                kind = KIND_SPHERE_C;              // MATH_FAST centre form; K (== 0 here) carries t + R
-                r.K = r.t + Rv;
-            }
-            r.farmask = Rv > T(0) ? kClassPositive : kClassNegative;   // Qz beyond the equator: sign(R) Qz > 0
-            r.ome2 = T(1) - r.eta2;
-            r.e2c2 = r.eta2 * (r.invR * r.invR);
-            r.ec = r.eta * std::fabs(r.invR);
-            r.cls = (r.finite ? CLS_FINITE : 0) | (nc > 0 ? CLS_HASP : 0) | ((r.eta != T(1)) ? CLS_REFR : 0) |
-                    (!(r.eta > T(0) && r.eta <= T(1)) ? CLS_TIR : 0) |
-                    (kind << CLS_KIND_SHIFT);
+            int nc = 0, pcls = 0;
+            if (hasp)
+                pcls = make_poly_rec<T>(pout.data() + ((size_t)s * S + i) * kPolyRec, coef + ((size_t)s * rows + (i + 1)) * ncoef, ncoef, &nc);
+            arms = std::max(arms, make_rec<T>(r, (T)ts[i], (T)Rs[i + 1], (T)ns[i], (T)ns[i + 1], Ks ? (T)Ks[i + 1] : T(0), nc, pcls));
             out[(size_t)s * S + i] = r;
         }
     }
+    return arms;
 }
 
 template <typename T> struct Sel;
 template <> struct Sel<double> {
     static const SurfRec<double>* rec(const ort_system* s) { return s->rec64; }
-    static const double* coef(const ort_system* s) { return s->coef64; }
+    static const double* poly(const ort_system* s) { return s->poly64; }
     static const double* ap2(const ort_system* s) { return s->ap64; }
+    static int arms(const ort_system* s) { return s->arms64; }
 };
 template <> struct Sel<float> {
     static const SurfRec<float>* rec(const ort_system* s) { return s->rec32; }
-    static const float* coef(const ort_system* s) { return s->coef32; }
+    static const float* poly(const ort_system* s) { return s->poly32; }
     static const float* ap2(const ort_system* s) { return s->ap32; }
+    static int arms(const ort_system* s) { return s->arms32; }
 };
 
 // pick the kernel instantiation
@@ -190,12 +168,13 @@ int launch_trace(ort_ctx* ctx, const TraceParams<T>& p, int64_t blocks, unsigned
     if (blocks <= 0) return ORT_OK;
     if (blocks > 0x7fffffffLL) return fail(ORT_EINVAL, "launch too large: %lld workgroups", (long long)blocks);
     const bool fast = flags & ORT_FAST_MATH;
-    const bool lds = !(flags & ORT_NO_LDS);
     dim3 g((unsigned)blocks), b(kBlock);
-    if (!fast && lds)  hipLaunchKernelGGL((k_trace<T, MATH_IEEE, true,  GRID, HIST, SUMM, FT>), g, b, 0, ctx->stream, p);
-    if (!fast && !lds) hipLaunchKernelGGL((k_trace<T, MATH_IEEE, false, GRID, HIST, SUMM, FT>), g, b, 0, ctx->stream, p);
-    if (fast && lds)   hipLaunchKernelGGL((k_trace<T, MATH_FAST, true,  GRID, HIST, SUMM, FT>), g, b, 0, ctx->stream, p);
-    if (fast && !lds)  hipLaunchKernelGGL((k_trace<T, MATH_FAST, false, GRID, HIST, SUMM, FT>), g, b, 0, ctx->stream, p);
+    // the build that carries the arms this batch's rows need (p.arms: ort_system::arms64 / arms32, surface_step_n)
+#define ORT_LAUNCH(M, A) hipLaunchKernelGGL((k_trace<T, M, A, GRID, HIST, SUMM, FT>), g, b, 0, ctx->stream, p)
+    if (p.arms <= ARMS_BASIC)        { if (fast) ORT_LAUNCH(MATH_FAST, ARMS_BASIC);   else ORT_LAUNCH(MATH_IEEE, ARMS_BASIC); }
+    else if (p.arms == ARMS_GENERAL) { if (fast) ORT_LAUNCH(MATH_FAST, ARMS_GENERAL); else ORT_LAUNCH(MATH_IEEE, ARMS_GENERAL); }
+    else                             { if (fast) ORT_LAUNCH(MATH_FAST, ARMS_POLY);    else ORT_LAUNCH(MATH_IEEE, ARMS_POLY); }
+#undef ORT_LAUNCH
     HIP_TRY(hipGetLastError());
     return ORT_OK;
 }
@@ -318,7 +297,7 @@ int trace_grid_impl(ort_ctx* ctx, const ort_system* sys, int nb, const ort_bundl
 
     TraceParams<T> p;
     memset(&p, 0, sizeof p);
-    p.recs = Sel<T>::rec(sys); p.coefs = Sel<T>::coef(sys); p.S = S; p.ncoef = sys->ncoef; p.apert2 = Sel<T>::ap2(sys);
+    p.recs = Sel<T>::rec(sys); p.polys = Sel<T>::poly(sys); p.arms = Sel<T>::arms(sys); p.S = S; p.apert2 = Sel<T>::ap2(sys);
     rc = upload_bundles<T>(ctx, sys, nb, bundles, ny, nx, axes_len, flags, &p.bundles); if (rc) return rc;
     p.ny = ny; p.nx = nx; p.rpb = rpb; p.tiles_per_bundle = (int)((rpb + kTile - 1) / kTile);
     p.raybasis = (flags & ORT_RAYBASIS) ? 1 : 0;
@@ -386,7 +365,7 @@ int trace_list_impl(ort_ctx* ctx, const ort_system* sys, int isys, int64_t nrays
     if (hist && ld < nrays) return fail(ORT_EINVAL, "ld %lld < rays %lld", (long long)ld, (long long)nrays);
     TraceParams<T> p;
     memset(&p, 0, sizeof p);
-    p.recs = Sel<T>::rec(sys); p.coefs = Sel<T>::coef(sys); p.S = S; p.ncoef = sys->ncoef; p.apert2 = Sel<T>::ap2(sys);
+    p.recs = Sel<T>::rec(sys); p.polys = Sel<T>::poly(sys); p.arms = Sel<T>::arms(sys); p.S = S; p.apert2 = Sel<T>::ap2(sys);
     p.nrays = nrays; p.isys = isys; p.slopes_given = (flags & ORT_INPUT_SLOPES) ? 1 : 0;
     const int64_t blocks = (nrays + kTile - 1) / kTile;
     if (flags & ORT_DEVICE_PTRS) {
@@ -548,7 +527,7 @@ int full_trace_impl(ort_ctx* ctx, const ort_system* sys, int nb, const ort_bundl
 
     TraceParams<T> p;
     memset(&p, 0, sizeof p);
-    p.recs = Sel<T>::rec(sys); p.coefs = Sel<T>::coef(sys); p.S = S; p.ncoef = sys->ncoef; p.apert2 = Sel<T>::ap2(sys);
+    p.recs = Sel<T>::rec(sys); p.polys = Sel<T>::poly(sys); p.arms = Sel<T>::arms(sys); p.S = S; p.apert2 = Sel<T>::ap2(sys);
     rc = upload_bundles<T>(ctx, sys, nb, bundles, ny, nx, axes_len, flags, &p.bundles); if (rc) return rc;
     p.ny = ny; p.nx = nx; p.rpb = rpb; p.tiles_per_bundle = (int)((rpb + kTile - 1) / kTile);
     p.raybasis = (flags & ORT_RAYBASIS) ? 1 : 0;
@@ -605,12 +584,12 @@ int spot_batch_impl(ort_ctx* ctx, int nsys, int rows, const double* R, const dou
     unsigned char* hres = hpin ? hpin + in_cnt * sizeof(double) : nullptr;   // results land behind the inputs
     unsigned char* dres = dpack ? dpack + in_cnt * sizeof(double) : nullptr;
     FirstOrderOut* d_fo; SurfRec<T>* d_rec; MerSurf *d_mf, *d_mr; double *d_tlf, *d_tlr, *d_ends; T* d_axes;
-    AimIn* d_ain; AimOut* d_aout; DevBundle<T>* d_bd; int* d_flag; T* d_cext = nullptr; double* d_crev = nullptr;
+    AimIn* d_ain; AimOut* d_aout; DevBundle<T>* d_bd; int* d_flag; T* d_poly = nullptr; double* d_crev = nullptr;
     if (dres) d_fo = reinterpret_cast<FirstOrderOut*>(dres + o_fo);
     else { rc = dev_out<FirstOrderOut>(ctx, SL_SB_FO, (size_t)nsys, &d_fo); if (rc) return rc; }
     rc = dev_out<SurfRec<T>>(ctx, SL_SB_REC, nr, &d_rec); if (rc) return rc;
     if (ncoef > 0) {
-        rc = dev_out<T>(ctx, SL_SB_CEXT, (size_t)nsys * (rows + 1) * ncoef, &d_cext); if (rc) return rc;
+        rc = dev_out<T>(ctx, SL_SB_CEXT, nr * kPolyRec, &d_poly); if (rc) return rc;
         rc = dev_out<double>(ctx, SL_SB_CREV, n_c, &d_crev); if (rc) return rc;
     }
     rc = dev_out<MerSurf>(ctx, SL_SB_MF, (size_t)nsys * (rows - 1), &d_mf); if (rc) return rc;
@@ -627,7 +606,16 @@ int spot_batch_impl(ort_ctx* ctx, int nsys, int rows, const double* R, const dou
     else { rc = dev_out<int>(ctx, SL_SB_FLAG, 1, &d_flag); if (rc) return rc; }
     TraceParams<T> p;
     memset(&p, 0, sizeof p);
-    p.recs = d_rec; p.coefs = d_cext; p.S = S; p.ncoef = ncoef; p.bundles = d_bd; p.axes = d_axes;
+    p.recs = d_rec; p.polys = d_poly; p.S = S; p.bundles = d_bd; p.axes = d_axes;
+    // which kernel build: coefficients -> polynomial arms; conic constants, or a Float64 row too weak for the centre form
+    // (|R| > kCentreFormMaxR; device-resident prescriptions cannot be inspected: assume one) -> general arms
+    p.arms = ncoef > 0 ? ARMS_POLY : ARMS_BASIC;
+    if (p.arms == ARMS_BASIC) {
+        bool general = K != nullptr || (devp && sizeof(T) == 8);
+        if (!devp && sizeof(T) == 8)
+            for (size_t i = 0; i < nr && !general; ++i) general = std::isfinite(R[i]) && std::fabs(R[i]) > kCentreFormMaxR;
+        if (general) p.arms = ARMS_GENERAL;
+    }
     p.ny = k_rays; p.nx = k2; p.rpb = rpb; p.tiles_per_bundle = (int)((rpb + kTile - 1) / kTile);
     hipStream_t st = ctx->stream;
     auto nblk = [](int64_t n, int b) { return dim3((unsigned)((n + b - 1) / b)); };
@@ -637,7 +625,7 @@ int spot_batch_impl(ort_ctx* ctx, int nsys, int rows, const double* R, const dou
     hipLaunchKernelGGL(k_first_order, nblk(nsys, 64), dim3(64), 0, st, nsys, rows, dR, dt, dn, da, (const double*)nullptr, dh,
                        587.5618e-6, d_fo, (double*)nullptr, (double*)nullptr);
     hipLaunchKernelGGL((k_build_tables<T>), nblk((int64_t)nr, kBlock), dim3(kBlock), 0, st, nsys, rows, dR, dt, dn, dK,
-                       ncoef > 0 ? dcoef : (const double*)nullptr, ncoef, d_fo, d_rec, d_cext, d_mf, d_mr, d_crev, d_tlf, d_tlr);
+                       ncoef > 0 ? dcoef : (const double*)nullptr, ncoef, d_fo, d_rec, d_poly, d_mf, d_mr, d_crev, d_tlf, d_tlr);
     hipLaunchKernelGGL(k_build_aim, nblk(na, kBlock), dim3(kBlock), 0, st, nsys, nfields, rows, d_fo, da, dfields, layout ? 1 : 0, d_ain);
     hipLaunchKernelGGL(k_aim, nblk((int64_t)na * 4, 64), dim3(64), 0, st, na, d_ain, d_mf, ncoef > 0 ? dcoef : (const double*)nullptr, d_tlf,
                        d_mr, (const double*)d_crev, d_tlr, rows - 1, ncoef, d_aout);
@@ -826,10 +814,11 @@ int ort_system_create(ort_ctx* ctx, int nsys, int rows, const double* R, const d
     if (!coef) ncoef = 0;
     if (ncoef == 0) coef = nullptr;
     const int S = rows - 1;
-    std::vector<SurfRec<double>> r64; std::vector<double> c64;
-    std::vector<SurfRec<float>> r32; std::vector<float> c32;
-    build_records<double>(nsys, rows, ncoef, R, t, n, K, coef, r64, c64);
-    build_records<float>(nsys, rows, ncoef, R, t, n, K, coef, r32, c32);
+    std::vector<SurfRec<double>> r64; std::vector<double> p64;
+    std::vector<SurfRec<float>> r32; std::vector<float> p32;
+    const int arms64 = build_records<double>(nsys, rows, ncoef, R, t, n, K, coef, r64, p64);
+    const int arms32 = build_records<float>(nsys, rows, ncoef, R, t, n, K, coef, r32, p32);
+    const size_t n_c64 = ncoef > 0 ? (size_t)nsys * rows * ncoef : 0;             // raw rows for the meridional kernels
     std::vector<MerSurf> mer((size_t)nsys * S);
     ort_system* sys = new (std::nothrow) ort_system();
     if (!sys) return fail(ORT_ENOMEM, "out of host memory");
@@ -846,22 +835,23 @@ int ort_system_create(ort_ctx* ctx, int nsys, int rows, const double* R, const d
         }
         sys->t_last[(size_t)s] = t[(size_t)s * rows + rows - 1];
     }
-    sys->ctx = ctx; sys->nsys = nsys; sys->rows = rows; sys->ncoef = ncoef;
+    sys->ctx = ctx; sys->nsys = nsys; sys->rows = rows; sys->ncoef = ncoef; sys->arms64 = arms64; sys->arms32 = arms32;
     // one device slab for every table of the batch (one hipMalloc, one staged copy): allocation
     // calls dominate the upload of 10^4-instance batches otherwise
     auto pad = [](size_t b) { return (b + 255) & ~(size_t)255; };
     const size_t b_r64 = pad(r64.size() * sizeof(SurfRec<double>)), b_r32 = pad(r32.size() * sizeof(SurfRec<float>));
     const size_t b_mer = pad(mer.size() * sizeof(MerSurf)), b_tl = pad(sys->t_last.size() * sizeof(double));
-    const size_t b_c64 = ncoef > 0 ? pad(c64.size() * sizeof(double)) : 0, b_c32 = ncoef > 0 ? pad(c32.size() * sizeof(float)) : 0;
-    const size_t total = b_r64 + b_r32 + b_mer + b_tl + b_c64 + b_c32;
+    const size_t b_c64 = pad(n_c64 * sizeof(double)), b_p64 = pad(p64.size() * sizeof(double)), b_p32 = pad(p32.size() * sizeof(float));
+    const size_t total = b_r64 + b_r32 + b_mer + b_tl + b_c64 + b_p64 + b_p32;
     std::vector<unsigned char> stage(total, 0);
     size_t o = 0;
     const size_t o_r64 = o; memcpy(stage.data() + o, r64.data(), r64.size() * sizeof(SurfRec<double>)); o += b_r64;
     const size_t o_r32 = o; memcpy(stage.data() + o, r32.data(), r32.size() * sizeof(SurfRec<float>)); o += b_r32;
     const size_t o_mer = o; memcpy(stage.data() + o, mer.data(), mer.size() * sizeof(MerSurf)); o += b_mer;
     const size_t o_tl = o; memcpy(stage.data() + o, sys->t_last.data(), sys->t_last.size() * sizeof(double)); o += b_tl;
-    const size_t o_c64 = o; if (ncoef > 0) memcpy(stage.data() + o, c64.data(), c64.size() * sizeof(double)); o += b_c64;
-    const size_t o_c32 = o; if (ncoef > 0) memcpy(stage.data() + o, c32.data(), c32.size() * sizeof(float)); o += b_c32;
+    const size_t o_c64 = o; if (ncoef > 0) memcpy(stage.data() + o, coef, n_c64 * sizeof(double)); o += b_c64;
+    const size_t o_p64 = o; if (ncoef > 0) memcpy(stage.data() + o, p64.data(), p64.size() * sizeof(double)); o += b_p64;
+    const size_t o_p32 = o; if (ncoef > 0) memcpy(stage.data() + o, p32.data(), p32.size() * sizeof(float)); o += b_p32;
     {
         hipError_t e = hipMalloc(&sys->slab, total);
         if (e == hipSuccess) e = hipMemcpy(sys->slab, stage.data(), total, hipMemcpyHostToDevice);
@@ -873,7 +863,10 @@ int ort_system_create(ort_ctx* ctx, int nsys, int rows, const double* R, const d
         sys->rec32 = reinterpret_cast<SurfRec<float>*>(base + o_r32);
         sys->mer = reinterpret_cast<MerSurf*>(base + o_mer);
         sys->d_tlast = reinterpret_cast<double*>(base + o_tl);
-        if (ncoef > 0) { sys->coef64 = reinterpret_cast<double*>(base + o_c64); sys->coef32 = reinterpret_cast<float*>(base + o_c32); }
+        if (ncoef > 0) {
+            sys->coef64 = reinterpret_cast<double*>(base + o_c64);
+            sys->poly64 = reinterpret_cast<double*>(base + o_p64); sys->poly32 = reinterpret_cast<float*>(base + o_p32);
+        }
     }
     if (rc) { ort_system_destroy(sys); return rc; }
     *out = sys;

@@ -1,10 +1,8 @@
 // ort_kernels.hpp — gfx950 kernels of the batched ray-trace engine.
 //
 // Layout in HBM
-//   surface table   SurfRec<T>[nsys][S]  (+ coef T[nsys][rows][ncoef]); a workgroup copies
-//                   the S records of ITS system into LDS once (<= 5 KiB) — or, with
-//                   USE_LDS = false, indexes global memory with a wave-uniform address so
-//                   the compiler issues scalar loads into SGPRs.
+//   surface table   SurfRec<T>[nsys][S]  (+ polynomial records T[nsys][S][kPolyRec]); a workgroup copies
+//                   the S records of ITS system into LDS once (<= 8 KiB + 12 KiB of coefficients).
 //   rays            never stored: a bundle's rays are generated from two 1-D axes (L2
 //                   resident) — or read once, coalesced, from SoA lists.
 //   history         T[S][ld] surface-major: lane l of a wave writes 16 B (RPT = 2 adjacent
@@ -73,9 +71,9 @@ template <> struct Vec2<float> { using type = fvec2_t; };
 template <typename T>
 struct TraceParams {
     const SurfRec<T>* recs;     // [nsys][S]
-    const T* coefs;             // [nsys][rows][ncoef] or null
+    const T* polys;             // [nsys][S][kPolyRec] polynomial records (ort_device.hpp) or null
+    int arms;                   // highest ARMS level among the batch's rows (host: which kernel build to launch)
     int S;                      // loop iterations = rows - 1
-    int ncoef;
     // grid source
     const DevBundle<T>* bundles;
     const T* axes;
@@ -145,15 +143,6 @@ __device__ __forceinline__ float dev_hypot(float a, float b) { return ::hypotf(a
 __device__ __forceinline__ double dev_atan2(double a, double b) { return ::atan2(a, b); }
 __device__ __forceinline__ float dev_atan2(float a, float b) { return ::atan2f(a, b); }
 
-// Member-wise copy of one record out of the constant address space (scalar loads).
-template <typename T>
-__device__ __forceinline__ void load_rec(SurfRec<T>& d, const __attribute__((address_space(4))) SurfRec<T>* s, int i)
-{
-    d.t = s[i].t; d.R = s[i].R; d.R2 = s[i].R2; d.sgn = s[i].sgn; d.opk = s[i].opk; d.eta = s[i].eta;
-    d.eta2 = s[i].eta2; d.K = s[i].K; d.invR = s[i].invR; d.ome2 = s[i].ome2; d.e2c2 = s[i].e2c2; d.ec = s[i].ec;
-    d.finite = s[i].finite; d.ncoef = s[i].ncoef; d.farmask = s[i].farmask; d.cls = s[i].cls;
-}
-
 // ------------------------------------------------------------------------------------
 // The hot kernel.  GRID: rays generated from bundle axes; otherwise read from lists.
 // HIST: write per-surface history.  SUMM: write image/stop hits + status.
@@ -170,12 +159,14 @@ __device__ __forceinline__ void load_rec(SurfRec<T>& d, const __attribute__((add
 enum { FT_NONE = 0, FT_FULL = 1, FT_STATS = 2, FT_LOOKBACK = 3 };
 constexpr int kStatusVignetted = 1 << 17, kStatusVigShift = 20;
 // ------------------------------------------------------------------------------------
-template <typename T, int MATH, bool USE_LDS, bool GRID, bool HIST, bool SUMM, int FT>
-__global__ __launch_bounds__(kBlock, ((HIST && SUMM) || FT == 3 /* FT_LOOKBACK */) ? ORT_MIN_WAVES - 1 : HIST ? ORT_MIN_WAVES : ORT_WAVES_NOHIST)
-void k_trace(TraceParams<T> p)   // both outputs, look-back epilogue: 128 VGPRs, no spill (96 spilled 48 B per ray to scratch: HBM writes)
+// ARMS: the row classes this build carries (surface_step_n): the batch's highest row decides (ort_system::arms).
+template <typename T, int MATH, int ARMS, bool GRID, bool HIST, bool SUMM, int FT>
+__global__ __launch_bounds__(kBlock, (ARMS == ARMS_POLY || (HIST && SUMM) || FT == 3 /* FT_LOOKBACK */) ? ORT_MIN_WAVES - 1 : HIST ? ORT_MIN_WAVES : ORT_WAVES_NOHIST)
+void k_trace(TraceParams<T> p)   // both outputs, look-back epilogue, polynomial arms: 128 VGPRs (at 96 they park tens of values per row in scratch)
 {
-    __shared__ SurfRec<T> s_rec[USE_LDS ? kMaxRows : 1];
-    __shared__ T s_coef[USE_LDS ? kMaxRows * kMaxCoef : 1];
+    constexpr bool POLY = ARMS == ARMS_POLY;
+    __shared__ SurfRec<T> s_rec[kMaxRows];
+    __shared__ __attribute__((aligned(16))) T s_poly[POLY ? kMaxRows * kPolyLds : 1];
     __shared__ int s_wcnt[kBlock / 64];
     __shared__ double s_wsx[kBlock / 64], s_wsy[kBlock / 64], s_wmax[kBlock / 64];
 
@@ -222,20 +213,25 @@ void k_trace(TraceParams<T> p)   // both outputs, look-back epilogue: 128 VGPRs,
         gbase = j0;
     }
     const SurfRec<T>* __restrict__ grec = p.recs + (int64_t)sysid * S;
-    const T* __restrict__ gcoef = p.coefs ? p.coefs + (int64_t)sysid * (S + 1) * p.ncoef : nullptr;
-    const int ncoef = p.ncoef;
+    const T* __restrict__ gpoly = (POLY && p.polys) ? p.polys + (int64_t)sysid * S * kPolyRec : nullptr;
     // clear-aperture extension (no reference counterpart): wave-uniform row pointer, null = off
     typedef const __attribute__((address_space(4))) T* CApPtr;  // wave-uniform address: scalar loads
     const CApPtr gap2 = (ORT_APERTURES && (SUMM || FT) && p.apert2) ? (CApPtr)(uintptr_t)(p.apert2 + (int64_t)sysid * S) : (CApPtr)0;
 
-    if (USE_LDS) {
+    {
         // stage this system's table: S records of sizeof(SurfRec<T>) bytes, as 16-B words
         constexpr int kW = sizeof(SurfRec<T>) / 16;
         const uint4* src = reinterpret_cast<const uint4*>(grec);
         uint4* dst = reinterpret_cast<uint4*>(s_rec);
         for (int w = tid; w < S * kW; w += kBlock) dst[w] = src[w];
-        if (gcoef)
-            for (int w = tid; w < S * ncoef; w += kBlock) s_coef[w] = gcoef[ncoef + w];  // rows 1..S
+        if (POLY && gpoly) {
+            // kPolyLds values per row: the even form ev | qd for MATH_FAST on rows that have one, else pc | dc
+            for (int w = tid; w < S * kPolyLds; w += kBlock) {
+                const int row = w / kPolyLds, e = w - row * kPolyLds;
+                const bool even = MATH == MATH_FAST && (grec[row].cls & (CLS_PEVEN | CLS_FINITE)) == (CLS_PEVEN | CLS_FINITE);
+                s_poly[w] = gpoly[row * kPolyRec + ((even && e < 12) ? 24 + e : e)];
+            }
+        }
         __syncthreads();
     }
 
@@ -304,28 +300,25 @@ void k_trace(TraceParams<T> p)   // both outputs, look-back epilogue: 128 VGPRs,
         vec_all = __all(two && al);
     }
 
-    // USE_LDS = false: the table is read through the CONSTANT address space with a wave-uniform
-    // address -> s_load into SGPRs (scalar cache), the next row prefetched while this one computes.
-    typedef const __attribute__((address_space(4))) SurfRec<T>* CRecPtr;
-    const CRecPtr crec = (CRecPtr)(uintptr_t)grec;
     const int stop_u = __builtin_amdgcn_readfirstlane(stopi);    // bundle-uniform: the stop capture is a scalar branch
     // The surface loop in arithmetic policy M.  MATH_FAST returns whether a ray of this lane left the domain of
     // the fast forms (`odd`, ort_device.hpp).
     auto trace_surfaces = [&](auto math) -> bool {
         constexpr int M = decltype(math)::value;
         bool odd = false;
-        SurfRec<T> nxt;
-        if (!USE_LDS) load_rec<T>(nxt, crec, 0);
+        if (M == MATH_FAST) {                                    // Inf / NaN launch data: the reference just computes with
+#pragma unroll                                                   // them, and so does its own operation sequence (retrace)
+            for (int r = 0; r < kRPT; ++r)
+                odd = odd || t_class(ray[r].x, kClassNonFinite) || t_class(ray[r].y, kClassNonFinite) ||
+                      t_class(ray[r].k0 + ray[r].k1, kClassNonFinite);
+        }
         for (int i = 0; i < S; ++i) {
-            SurfRec<T> cur;
-            if (!USE_LDS) {
-                cur = nxt;
-                load_rec<T>(nxt, crec, (i + 1 < S) ? i + 1 : i);
-            }
-            const SurfRec<T>& rec = USE_LDS ? s_rec[i] : cur;
-            const T* cf = USE_LDS ? (s_coef + i * ncoef) : (gcoef ? gcoef + (int64_t)(i + 1) * ncoef : nullptr);
+            const SurfRec<T>& rec = s_rec[i];
             const int cls = __builtin_amdgcn_readfirstlane(rec.cls);     // wave-uniform -> scalar branch
-            surface_step_n<T, M, kRPT>(ray, rec, cf, cls, i == S - 1, odd);
+            // the staged block is laid out for the kernel's own policy; the (cold) MATH_IEEE retrace of a MATH_FAST kernel
+            // reads its pc | dc block from the table itself
+            const T* cf = (M == MATH) ? (s_poly + i * kPolyLds) : (gpoly ? gpoly + i * kPolyRec : nullptr);
+            surface_step_n<T, M, kRPT, ARMS>(ray, rec, cf, cls, i == S - 1, odd);
             if (SUMM || FT) {
 #pragma unroll
                 for (int r = 0; r < kRPT; ++r) {
@@ -334,8 +327,13 @@ void k_trace(TraceParams<T> p)   // both outputs, look-back epilogue: 128 VGPRs,
                     st[r] += __builtin_isunordered(ray[r].x, ray[r].y) ? 0 : 1;
                 }
                 if (i == stop_u) {
+                    const T a2 = a_stop * a_stop, alim = (T)Near<T>::thr * a2;
 #pragma unroll
-                    for (int r = 0; r < kRPT; ++r) { xs_[r] = ray[r].x; ys_[r] = ray[r].y; }
+                    for (int r = 0; r < kRPT; ++r) {
+                        xs_[r] = ray[r].x; ys_[r] = ray[r].y;
+                        // within kNear of the stop's edge the filter r > a_stop (:132) is decided by the reference sequence
+                        if (M == MATH_FAST) odd = odd || near_zero<T>(t_fma<T>(xs_[r], xs_[r], t_fma<T>(ys_[r], ys_[r], -a2)), alim);
+                    }
                 }
                 if (gap2) {                                          // scalar branch: one s_cbranch when off
                     const T a2 = gap2[i];
@@ -344,6 +342,7 @@ void k_trace(TraceParams<T> p)   // both outputs, look-back epilogue: 128 VGPRs,
                         // bit 17: outside the clear aperture of some surface; bits 20..27 count the surfaces
                         // passed before that -> 1-based index of the first vignetting surface = count + 1
                         const T r2 = ray[r].x * ray[r].x + ray[r].y * ray[r].y;
+                        if (M == MATH_FAST) odd = odd || near_zero<T>(r2 - a2, (T)Near<T>::thr * a2);
                         st[r] |= (r2 > a2) ? kStatusVignetted : 0;
                         st[r] += (st[r] & kStatusVignetted) ? 0 : (1 << kStatusVigShift);
                     }
@@ -801,7 +800,7 @@ __device__ __forceinline__ double mer_step(const MerSurf& s, const double* __res
         const double sec = 1.0 / ::cos(U);
         const double D = beta * beta - y2 * (sec * sec + s.K);    // :79
         sg = y2 / (beta + s.sgn * __builtin_sqrt(D));             // :81
-        sg = sg + (s.ncoef > 0 ? poly_eval<double>(c, s.ncoef, y) : 0.0);
+        sg = sg + (s.ncoef > 0 ? poly_eval_loop<double>(c, s.ncoef, y) : 0.0);
         sg = (D >= 0.0) ? sg : __builtin_nan("");                 // :80,83
     } else sg = 0.0;                                              // :86
     y = y + sg * tU;                                              // :158
@@ -813,7 +812,7 @@ __device__ __forceinline__ double mer_step(const MerSurf& s, const double* __res
         theta = ::asin(q);                                        // :162
     } else {
         double tl = s.sgn * y / __builtin_sqrt(s.R * s.R - y * y * (1.0 + s.K));   // :98
-        tl = tl + (s.ncoef > 0 ? poly_deriv<double>(c, s.ncoef, y) : 0.0);
+        tl = tl + (s.ncoef > 0 ? poly_deriv_loop<double>(c, s.ncoef, y) : 0.0);
         theta = ::atan(tl);
     }
     const double sin_ip = s.n1 * ::sin(U + theta) / s.n2;         // :163
@@ -1255,23 +1254,6 @@ __global__ __launch_bounds__(64) void k_first_order(int nsys, int rows, const do
 // src/RayTracing.jl:267-277), turn first-order results into aiming requests, and aiming results
 // into bundle descriptors and axis end points (src/PupilSampling.jl:94-122).
 // ------------------------------------------------------------------------------------
-template <typename T>
-__device__ __forceinline__ void make_rec(SurfRec<T>& r, T t, T Rv, T n1, T n2, T Kv, int nc)
-{
-    r.t = t; r.R = Rv; r.R2 = Rv * Rv;
-    r.sgn = Rv > T(0) ? T(1) : (Rv < T(0) ? T(-1) : Rv);
-    r.opk = T(1) + Kv; r.eta = n1 / n2; r.eta2 = r.eta * r.eta; r.K = Kv;
-    r.finite = __builtin_isfinite(Rv) ? 1 : 0;
-    r.invR = r.finite ? T(1) / Rv : T(0);
-    r.ome2 = T(1) - r.eta2; r.e2c2 = r.eta2 * (r.invR * r.invR); r.ec = r.eta * fabs(r.invR);
-    r.ncoef = nc;
-    int kind = nc > 0 ? KIND_POLY : (!r.finite ? KIND_FLAT : (Kv != T(0) ? KIND_CONIC : KIND_SPHERE));
-    if (kind == KIND_SPHERE && fabs((double)Rv) <= kCentreFormMaxR && sizeof(T) == 8) { kind = KIND_SPHERE_C; r.K = r.t + Rv; }
-    r.farmask = Rv > T(0) ? kClassPositive : kClassNegative;
-    r.cls = (r.finite ? CLS_FINITE : 0) | (nc > 0 ? CLS_HASP : 0) | ((r.eta != T(1)) ? CLS_REFR : 0) |
-            (!(r.eta > T(0) && r.eta <= T(1)) ? CLS_TIR : 0) | (kind << CLS_KIND_SHIFT);
-}
-
 // number of coefficients in use for a row: the whole width if any entry is non-zero AFTER the cast to T
 // (an all-zero row is the reference's `zero` polynomial), as ort_system_create does on the host
 template <typename T>
@@ -1282,15 +1264,15 @@ __device__ __forceinline__ int row_ncoef(const double* __restrict__ c, int ncoef
     return nc;
 }
 
-// one thread per (system, loop index i): extended skew table [nsys][rows] (+ its coefficient rows
-// [nsys][rows+1][ncoef]), forward and reversed meridional tables [nsys][rows-1] (+ the reversed coefficient
+// one thread per (system, loop index i): extended skew table [nsys][rows] (+ its polynomial records
+// [nsys][rows][kPolyRec]), forward and reversed meridional tables [nsys][rows-1] (+ the reversed coefficient
 // rows [nsys][rows][ncoef]; the forward ones are the input), last thicknesses.  K, coef may be null.
 template <typename T>
 __global__ __launch_bounds__(kBlock) void k_build_tables(int nsys, int rows, const double* __restrict__ R, const double* __restrict__ t,
                                                          const double* __restrict__ n, const double* __restrict__ K,
                                                          const double* __restrict__ coef, int ncoef,
                                                          const FirstOrderOut* __restrict__ fo,
-                                                         SurfRec<T>* __restrict__ rec_ext, T* __restrict__ coef_ext,
+                                                         SurfRec<T>* __restrict__ rec_ext, T* __restrict__ poly_ext,
                                                          MerSurf* __restrict__ mer_fwd, MerSurf* __restrict__ mer_rev,
                                                          double* __restrict__ crev, double* __restrict__ tl_fwd,
                                                          double* __restrict__ tl_rev)
@@ -1310,15 +1292,13 @@ __global__ __launch_bounds__(kBlock) void k_build_tables(int nsys, int rows, con
         const double Re = real ? Rs[i + 1] : __builtin_inf();
         const double n1 = ns[i], n2 = real ? ns[i + 1] : 1.0;
         const double Ke = (real && Ks) ? Ks[i + 1] : 0.0;                // K = [surfaces.K; 0.0]  (:112)
-        const int nc = (real && cs) ? row_ncoef<T>(cs + (int64_t)(i + 1) * ncoef, ncoef) : 0;
+        int nc = 0, pcls = 0;
+        if (poly_ext)                                                    // p = [surfaces.p; zero]  (:113)
+            pcls = make_poly_rec<T>(poly_ext + ((int64_t)s * rows + i) * kPolyRec, (real && cs) ? cs + (int64_t)(i + 1) * ncoef : nullptr,
+                                    ncoef, &nc);
         SurfRec<T> r;
-        make_rec<T>(r, (T)te, (T)Re, (T)n1, (T)n2, (T)Ke, nc);
+        make_rec<T>(r, (T)te, (T)Re, (T)n1, (T)n2, (T)Ke, nc, pcls);
         rec_ext[(int64_t)s * rows + i] = r;
-        if (coef_ext) {
-            T* ce = coef_ext + (int64_t)s * (rows + 1) * ncoef;
-            for (int j = 0; j < ncoef; ++j) ce[(int64_t)(i + 1) * ncoef + j] = (real && cs) ? (T)cs[(int64_t)(i + 1) * ncoef + j] : T(0);
-            if (i == 0) for (int j = 0; j < ncoef; ++j) ce[j] = cs ? (T)cs[j] : T(0);
-        }
     }
     if (i < rows - 1) {
         MerSurf m;

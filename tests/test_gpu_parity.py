@@ -34,6 +34,20 @@ def _ext(surfaces, focus):
     return e
 
 
+def _engine(policy):
+    """The default (reference-sequence) engine or a FAST-policy one on the same device."""
+    return ort.default_engine() if policy == "ieee" else ort.HipEngine(0, fast_math=True)
+
+
+def _same(policy, g, o, what=None):
+    """Bit-identical in the reference-sequence policy; NaN pattern identical and <= 1e-10 relative in the FAST one."""
+    if policy == "ieee":
+        assert np.array_equal(g, o, equal_nan=True), what
+    else:
+        assert np.array_equal(np.isnan(g), np.isnan(o)), what
+        assert cm.rel_err(g, o, 1.0).max() <= TOL, (what, cm.rel_err(g, o, 1.0).max())
+
+
 @pytest.mark.parametrize("name", ["cooke", "tessar", "catadioptric", "double_gauss"])
 def test_skew_list_bitexact_with_slopes(hip_engine, oracle_engine, name):
     M = {"cooke": _ext(cm.cooke(), 77.40534796682427), "tessar": _ext(cm.tessar(), 40.0),
@@ -92,11 +106,13 @@ def _dg_bundles(engine, k, fields=(0.0, 0.7, 1.0), lines=(0, 1, 2)):
     return workloads.square_pupil_bundles(api, systems, k, fields=fields)
 
 
+@pytest.mark.parametrize("policy", ["ieee", "fast"])
 @pytest.mark.parametrize("H", [0.0, 1.0])
-def test_grid_cooke_config1_bitexact(hip_engine, oracle_engine, H):
+def test_grid_cooke_config1_bitexact(oracle_engine, H, policy):
     """BASELINE config 1 (H = 0 and H = 1): Cooke triplet, 1 field, 64 x 32 half pupil (reference
-    mode) — grid history / summary bit-identical, and the full_trace pipeline (filter, ordered compaction, mirror,
-    rho, theta, RMS) against the oracle's."""
+    mode) — grid history / summary bit-identical (FAST: <= 1e-10, status and survivor counts exact), and the full_trace
+    pipeline (filter, ordered compaction, mirror, rho, theta, RMS) against the oracle's."""
+    hip_engine = _engine(policy)
     system = ort.solve(cm.cooke(), cm.COOKE_A, cm.COOKE_H, engine=oracle_engine)
     aim = ort.full_trace_aim(system.layout, system, H, engine=oracle_engine)
     pres = ort.extended_prescription(system.layout, aim.focus)
@@ -105,13 +121,13 @@ def test_grid_cooke_config1_bitexact(hip_engine, oracle_engine, H):
     g = hip_engine.grid(pres, [b], axes, 64, 32)
     o = oracle_engine.grid(pres, [b], axes, 64, 32)
     for key in ("xv", "yv", "xf", "yf", "xs", "ys"):
-        assert np.array_equal(g[key], o[key], equal_nan=True), key
+        _same(policy, g[key], o[key], key)
     assert np.array_equal(g["status"], o["status"])
     of = oracle_engine.full_trace_grid(pres, [b], axes, 64, 32)[0]
     for lookback in (False, True):                              # both compaction routes
         gf = hip_engine.full_trace_grid(pres, [b], axes, 64, 32, lookback=lookback)[0]
         assert gf["count"] == of["count"] > 0
-        assert np.array_equal(gf["ex"], of["ex"]) and np.array_equal(gf["ey"], of["ey"])
+        _same(policy, gf["ex"], of["ex"], "ex"); _same(policy, gf["ey"], of["ey"], "ey")
         assert cm.rel_err(gf["rho"], of["rho"], 1e-3).max() <= TOL and cm.rel_err(gf["theta"], of["theta"], 1e-3).max() <= TOL
         assert abs(gf["rms"] - of["rms"]) <= TOL * of["rms"]
 
@@ -127,10 +143,9 @@ def test_grid_double_gauss_config2_small(hip_engine, oracle_engine):
     assert ((o["status"] >> 16) & 1).any()                   # some rays fail the stop filter
 
 
-def test_grid_odd_sizes_and_no_lds(oracle_engine):
-    """Ragged tiles (rays per bundle not a multiple of the 512-ray tile, odd nx) and the
-    scalar-load variant of the surface table."""
-    eng = ort.HipEngine(0, use_lds=False)
+def test_grid_odd_sizes(oracle_engine):
+    """Ragged tiles (rays per bundle not a multiple of the 512-ray tile, odd nx)."""
+    eng = ort.default_engine()
     pres, bundles, axes = _dg_bundles(oracle_engine, 37, fields=(0.0, 1.0), lines=(0, 2))
     g = eng.grid(pres, bundles, axes, 37, 37)
     o = oracle_engine.grid(pres, bundles, axes, 37, 37)
@@ -151,9 +166,12 @@ def test_fast_math_within_tolerance(oracle_engine):
     assert flips == 0, f"{flips} stop-filter flips"
 
 
-def test_aspheric_config3_small(hip_engine, oracle_engine):
+@pytest.mark.parametrize("policy", ["ieee", "fast"])
+def test_aspheric_config3_small(oracle_engine, policy):
     """Config 3 shape: conic + polynomial terms on 4 surfaces.  The device uses the analytic
-    p'; the reference a complex step (RayTracing.jl:103) — equal to O(eps^2)."""
+    p'; the reference a complex step (RayTracing.jl:103) — equal to O(eps^2).  FAST: the even-form polynomial arm
+    (ort_device.hpp, surface_step_fast_poly) on realistic rays at the plain bar, no amplification."""
+    hip_engine = _engine(policy)
     M4, coef = cm.double_gauss_aspheric()
     ext = np.vstack([M4, [math.inf, 0.0, 1.0, 0.0]])
     ext[-2, 1] = 57.8
@@ -168,15 +186,17 @@ def test_aspheric_config3_small(hip_engine, oracle_engine):
     assert max(cm.rel_err(gx, ox, 1.0).max(), cm.rel_err(gy, oy, 1.0).max()) <= 1e-12
 
 
+@pytest.mark.parametrize("policy", ["ieee", "fast"])
 @pytest.mark.parametrize("H", [0.0, 0.7, 1.0])
-def test_full_trace_singlet(hip_engine, oracle_engine, H):
+def test_full_trace_singlet(oracle_engine, H, policy):
     """The reference's own full_trace case (test/runtests.jl:364-372), grid stage on the GPU."""
+    hip_engine = _engine(policy)
     system = ort.solve(cm.singlet(), [20.0, 20.0], 17.787, engine=oracle_engine)
     aim = ort.full_trace_aim(system.layout, system, H, engine=oracle_engine)
     g = ort.full_trace_grid(system.layout, aim, 64, engine=hip_engine)
     o = ort.full_trace_grid(system.layout, aim, 64, engine=oracle_engine)
     assert len(g.x) == len(o.x)                              # same survivors, same order
-    assert np.array_equal(g.x, o.x) and np.array_equal(g.y, o.y)
+    _same(policy, g.x, o.x, "x"); _same(policy, g.y, o.y, "y")
     assert cm.rel_err(g.r, o.r, 1e-3).max() <= TOL           # hypot: ocml vs glibc
     assert cm.rel_err(g.t, o.t, 1e-3).max() <= TOL           # atan2
     assert abs(g.RMS - o.RMS) <= TOL * o.RMS
@@ -453,16 +473,19 @@ def test_config5_monte_carlo_instances(oracle_engine):
     assert cm.rel_err(xv, o["xv"], 1.0).max() <= 1e-4 and cm.rel_err(yv, o["yv"], 1.0).max() <= 1e-4
 
 
-def test_config3_full_size_aspheric_properties(oracle_engine):
+@pytest.mark.parametrize("policy", ["ieee", "fast"])
+def test_config3_full_size_aspheric_properties(oracle_engine, policy):
     """BASELINE config 3 at FULL size: 3 x 3 bundles x 2048 x 2048 pupil (37.7 M rays, S = 12),
-    4 aspheric surfaces, full_trace pipeline with stop-filter compaction, device pointers.
+    4 aspheric surfaces, full_trace pipeline with stop-filter compaction, device pointers, in both policies.
     Properties: survivors ~ pi/4 of the pupil square; compacted first half equals the filtered
     summary trace in ray order (checked on one bundle against a second, independent launch);
-    mirror halves exact; a strided sample of rays equals the oracle to 1e-12."""
+    mirror halves exact; a strided sample of rays equals the oracle to 1e-12; FAST: the survivor count of every
+    bundle equals the reference-sequence policy's (the stop filter is decided identically, PupilSampling.jl:132)."""
     import ctypes as C
     import torch
     from opticalraytracing_jl_amd import _capi, api, workloads
-    eng = ort.default_engine()
+    eng = _engine(policy)
+    pf = _capi.ORT_FAST_MATH if policy == "fast" else 0
     k = 2048
     pres, bundles, axes = workloads.config3(api, k, engine=oracle_engine)
     nb, rpb = len(bundles), k * k
@@ -477,11 +500,17 @@ def test_config3_full_size_aspheric_properties(oracle_engine):
     torch.cuda.synchronize()
     _capi.check(eng.ctx.lib.ort_full_trace_f64(eng.ctx.h, sysd.h, nb, barr, d_axes.data_ptr(), axes.size, k, k,
                                                ex.data_ptr(), ey.data_ptr(), rho.data_ptr(), th.data_ptr(),
-                                               cnt.data_ptr(), rms.data_ptr(), _capi.ORT_DEVICE_PTRS))
+                                               cnt.data_ptr(), rms.data_ptr(), _capi.ORT_DEVICE_PTRS | pf))
     eng.ctx.synchronize()
     c = cnt.cpu().numpy(); r = rms.cpu().numpy()
     assert np.all(c % 2 == 0) and np.all(np.abs(c / 2 / rpb - math.pi / 4) < 0.10)
     assert np.all(np.isfinite(r)) and np.all(r > 0)
+    if policy == "fast":      # counts and RMS against the reference-sequence policy of the same call (statistics-only route)
+        c2 = torch.empty_like(cnt); r2 = torch.empty_like(rms)
+        _capi.check(eng.ctx.lib.ort_full_trace_f64(eng.ctx.h, sysd.h, nb, barr, d_axes.data_ptr(), axes.size, k, k,
+                                                   None, None, None, None, c2.data_ptr(), r2.data_ptr(), _capi.ORT_DEVICE_PTRS))
+        eng.ctx.synchronize()
+        assert torch.equal(c2, cnt) and float(((r2 - rms).abs() / r2).max()) <= 1e-10
     # bundle 4: summary trace + host filter == compacted first half, in order; mirror exact
     b = 4
     xf = torch.empty(rpb, dtype=torch.float64, device=dev); yf = torch.empty_like(xf)
@@ -490,7 +519,7 @@ def test_config3_full_size_aspheric_properties(oracle_engine):
     out.xf, out.yf, out.xs, out.ys, out.status = xf.data_ptr(), yf.data_ptr(), xs.data_ptr(), ys.data_ptr(), st.data_ptr()
     one = _capi.make_bundles([bundles[b]])
     _capi.check(eng.ctx.lib.ort_trace_grid_f64(eng.ctx.h, sysd.h, 1, one, d_axes.data_ptr(), axes.size, k, k,
-                                               C.byref(out), _capi.ORT_DEVICE_PTRS))
+                                               C.byref(out), _capi.ORT_DEVICE_PTRS | pf))
     eng.ctx.synchronize()
     keep = (st >> 16) == 0
     m = int(c[b]) // 2
@@ -727,15 +756,14 @@ def _random_system(rng, rows, aspheric):
     return R, t, n, K, coef
 
 
-# FAST-policy attribution (tests below; measured tables: scripts/fast_attribution.py, profiles/r02_fast_attribution*.log).
-# The FAST forms differ from the reference sequence by rounding only; wherever the reference's formulas stop being
-# the geometry (far-cap hits, backward directions, polynomial rows outside their conic) the kernel retraces the
-# wave with the reference sequence itself.  A rounding difference is amplified by the conditioning of the ray's
-# path, which the oracle measures on itself:
-#   margin = smallest normalised distance to a miss / TIR / equator boundary (oracle skew_margins),
-#   sens   = largest relative change of any coordinate under a 1e-13 relative perturbation of the launch data.
-FAST_FLIP_MARGIN = 1e-9   # a status flip is attributable only to a discriminant within 1e-9 (normalised) of zero
-FAST_MARGIN = 1e-6        # rays closer than this to a boundary are not value-compared (and must be rare)
+# FAST policy (tests below; measured tables: scripts/fast_attribution.py).  The FAST forms differ from the reference
+# sequence by rounding only.  Wherever the two could DECIDE differently — a ray within 1e-9 (normalised) of a miss / TIR /
+# equator / stop-edge branch, or where the reference's formulas stop being the geometry (far-cap hits, backward
+# directions, polynomial rows outside their conic) — the kernel retraces the wave with the reference sequence itself
+# (ort_device.hpp, `odd`).  So: status identical on EVERY ray, no allowance; coordinates compared on EVERY ray, no
+# exclusion zone.  A rounding difference is amplified by the conditioning of the ray's path, which the oracle measures on
+# itself (sens = largest relative change of any coordinate under a 1e-13 relative perturbation of the launch data): the
+# bar is 1e-10, or 100 x that response for the rare ill-conditioned ray (counted and bounded below).
 FAST_TOL = 1e-10          # BASELINE north_star: 1e-10 relative
 FAST_AMP = 100.0          # ... or 100 x the oracle's own response to the 1e-13 perturbation, whichever is larger
 
@@ -748,35 +776,31 @@ def _deviation(ax, ay, bx, by):
 
 
 def _fast_attribution(fast, oracle_engine, pres, y, x, u, v, tag):
-    """One prescription: FAST vs oracle, every ray classified by the oracle.  Asserts (1) a status flip only
-    within FAST_FLIP_MARGIN of a branch boundary, (2) NaN patterns identical and coordinates within
-    max(FAST_TOL, FAST_AMP * sens) on every other ray farther than FAST_MARGIN from a boundary — far-cap hits,
-    post-TIR paths and huge coordinates included.  Returns (rays, rays within FAST_MARGIN, far-cap rays, flips)."""
+    """One prescription: FAST vs oracle on every ray.  Asserts (1) status identical on every ray, (2) NaN patterns
+    identical and coordinates within max(FAST_TOL, FAST_AMP * sens) on every ray — far-cap hits, post-TIR paths, near-
+    boundary rays and huge coordinates included.  Returns (rays, rays that needed the amplified bar, far-cap rays)."""
     ox, oy, os_ = oracle_engine.skew(pres, y, x, u, v, slopes=True, want_status=True)
     d = 1e-13
     px, py = oracle_engine.skew(pres, y * (1 + d), x * (1 - d), u * (1 + d), v * (1 - d), slopes=True)
     sens = _deviation(px, py, ox, oy)
     fx, fy, fs = fast.skew(pres, y, x, u, v, slopes=True, want_status=True)
     mg = oracle_engine.skew_margins(pres, y, x, u, v)
-    cond = np.min(np.abs(mg[:, :3]), axis=1)
     err = _deviation(fx, fy, ox, oy)
     flip = fs != os_
-    bad_flip = flip & (cond > FAST_FLIP_MARGIN)
-    assert not bad_flip.any(), (tag, "status", int(bad_flip.sum()), float(cond[bad_flip].min()), mg[bad_flip][:3])
-    bad = ~flip & (cond > FAST_MARGIN) & ~(err <= np.maximum(FAST_TOL, FAST_AMP * sens))
-    assert not bad.any(), (tag, "coordinates", int(bad.sum()), float(err[bad].max()), float(sens[bad].max()), float(cond[bad].min()),
-                           int((mg[bad, 3] > 0).sum()))
-    return y.size, int((cond <= FAST_MARGIN).sum()), int((mg[:, 3] > 0).sum()), int(flip.sum())
+    assert not flip.any(), (tag, "status", int(flip.sum()), mg[flip][:3])
+    bad = ~(err <= np.maximum(FAST_TOL, FAST_AMP * sens))
+    assert not bad.any(), (tag, "coordinates", int(bad.sum()), float(err[bad].max()), float(sens[bad].max()), mg[bad][:3])
+    return y.size, int((err > FAST_TOL).sum()), int((mg[:, 3] > 0).sum())
 
 
 def test_random_systems_property(hip_engine, oracle_engine):
     """120 random prescriptions (2-14 rows; flat rows, both curvature signs, conics, polynomial
     terms, glass/air sequences that TIR and miss) x 1500 random skew rays each: the IEEE policy is
-    BIT-IDENTICAL to the oracle on every ray incl. NaN patterns and status; every deviation of the FAST
-    policy is attributed ray by ray (see _fast_attribution): no blanket tolerance."""
+    BIT-IDENTICAL to the oracle on every ray incl. NaN patterns and status; the FAST policy has the same status on
+    every ray and every ray's coordinates within the bar (see _fast_attribution)."""
     rng = np.random.default_rng(2024)
     fast = ort.HipEngine(0, fast_math=True)
-    ntot = nill = nfar = nflip = 0
+    ntot = nill = nfar = 0
     for case in range(120):
         rows = int(rng.integers(2, 15))
         aspheric = case % 3 == 0
@@ -792,19 +816,19 @@ def test_random_systems_property(hip_engine, oracle_engine):
             assert cm.rel_err(gx, ox, 1.0).max() <= 1e-11 and cm.rel_err(gy, oy, 1.0).max() <= 1e-11, case
         else:
             assert np.array_equal(gx, ox, equal_nan=True) and np.array_equal(gy, oy, equal_nan=True), case
-        a, b, c, f = _fast_attribution(fast, oracle_engine, pres, y, x, u, v, case)
-        ntot += a; nill += b; nfar += c; nflip += f
-    assert nill <= 1e-4 * ntot and nflip <= 1e-5 * ntot, (nill, nflip, ntot)
+        a, b, c = _fast_attribution(fast, oracle_engine, pres, y, x, u, v, case)
+        ntot += a; nill += b; nfar += c
+    assert nill <= 1e-4 * ntot, (nill, ntot)             # rays beyond 1e-10 (ill-conditioned paths, within 100 x sens): rare
 
 
 def test_fast_policy_far_cap_and_wide_bundles(oracle_engine):
     """The FAST policy on what a lens designer never traces but the reference defines: strongly curved rows
     (|R| 6.5-30 mm) under +-14 mm, +-0.2 rad bundles — thousands of FAR-CAP hits (beyond a sphere's equator,
     where the reference refracts with the vertex-side normal, src/PupilSampling.jl:16-19), TIR and miss
-    sequences, directions refracted backward.  Same ray-by-ray attribution."""
+    sequences, directions refracted backward.  Same checks on every ray."""
     rng = np.random.default_rng(31337)
     fast = ort.HipEngine(0, fast_math=True)
-    ntot = nill = nfar = nflip = 0
+    ntot = nill = nfar = 0
     for case in range(60):
         rows = int(rng.integers(3, 15))
         aspheric = case % 3 == 0
@@ -814,10 +838,10 @@ def test_fast_policy_far_cap_and_wide_bundles(oracle_engine):
         m = 2000
         y = rng.uniform(-14, 14, m); x = rng.uniform(-14, 14, m)
         u = np.tan(rng.uniform(-0.2, 0.2, m)); v = np.tan(rng.uniform(-0.2, 0.2, m))
-        a, b, c, f = _fast_attribution(fast, oracle_engine, pres, y, x, u, v, case)
-        ntot += a; nill += b; nfar += c; nflip += f
+        a, b, c = _fast_attribution(fast, oracle_engine, pres, y, x, u, v, case)
+        ntot += a; nill += b; nfar += c
     assert nfar >= 1000, nfar                      # the far-cap rule is exercised, not vacuous
-    assert nill <= 2e-3 * ntot and nflip <= 1e-4 * ntot, (nill, nflip, ntot)
+    assert nill <= 2e-3 * ntot, (nill, ntot)
 
 
 def test_random_systems_meridional_and_paraxial(hip_engine, oracle_engine):
@@ -847,10 +871,13 @@ def test_random_systems_meridional_and_paraxial(hip_engine, oracle_engine):
         assert np.array_equal(hip_engine.abcd(L.M[:, 0], L.M[:, 1]), oracle_engine.abcd(L.M[:, 0], L.M[:, 1]))
 
 
-def test_random_bundles_grid_and_full_trace(hip_engine, oracle_engine):
+@pytest.mark.parametrize("policy", ["ieee", "fast"])
+def test_random_bundles_grid_and_full_trace(oracle_engine, policy):
     """Random multi-system batches, ragged grid shapes (odd nx, nx < 64, rays per bundle not a
     multiple of the tile), random stop rows and stop radii: grid summary/history and the
-    full_trace pipeline (filter, ordered compaction, mirror, sigma) against the oracle."""
+    full_trace pipeline (filter, ordered compaction, mirror, sigma) against the oracle.  FAST: status (stop-filter bit
+    included) and survivor counts EQUAL the oracle's, coordinates <= 1e-10."""
+    hip_engine = _engine(policy)
     rng = np.random.default_rng(99)
     for case in range(25):
         rows = int(rng.integers(4, 12))
@@ -876,14 +903,14 @@ def test_random_bundles_grid_and_full_trace(hip_engine, oracle_engine):
         g = hip_engine.grid(pres, bundles, axes, ny, nx)
         o = oracle_engine.grid(pres, bundles, axes, ny, nx)
         for key in ("xv", "yv", "xf", "yf", "xs", "ys"):
-            assert np.array_equal(g[key], o[key], equal_nan=True), (case, key)
+            _same(policy, g[key], o[key], (case, key))
         assert np.array_equal(g["status"], o["status"]), case
         gf = hip_engine.full_trace_grid(pres, bundles, axes, ny, nx, lookback=bool(case & 1))   # both compaction routes
         of = oracle_engine.full_trace_grid(pres, bundles, axes, ny, nx)
         for a, b in zip(gf, of):
             assert a["count"] == b["count"], case
             if b["count"]:
-                assert np.array_equal(a["ex"], b["ex"]) and np.array_equal(a["ey"], b["ey"]), case
+                _same(policy, a["ex"], b["ex"], case); _same(policy, a["ey"], b["ey"], case)
                 assert cm.rel_err(a["rho"], b["rho"], 1e-3).max() <= TOL and cm.rel_err(a["theta"], b["theta"], 1e-3).max() <= TOL
                 assert abs(a["rms"] - b["rms"]) <= TOL * max(b["rms"], 1e-6), case
             else:
