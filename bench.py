@@ -501,7 +501,14 @@ def bench_multi(args, torch, rank, world, local_rank):
             th.start()
             th.join(float(os.environ.get("ORT_BENCH_COMM_TIMEOUT_S", "180")))
             if th.is_alive():
-                raise TimeoutError("ort_comm_create did not return (RCCL rendezvous)")
+                # ncclCommInitRank did not return: a thread of this process is still inside RCCL on this GPU.  Nothing may
+                # run beside a half-built communicator — report and leave (every rank times out the same way)
+                if rank == 0:
+                    print(json.dumps({"metric": METRIC, "value": None, "unit": "ray-surface intersections/s", "n_gpus": world,
+                                      "error": "RCCL rendezvous timeout: ort_comm_create (ncclCommInitRank) did not return within "
+                                               f"{os.environ.get('ORT_BENCH_COMM_TIMEOUT_S', '180')} s", "nranks_seen": None}), flush=True)
+                sys.stdout.flush()
+                os._exit(3)
             if "err" in made:
                 raise made["err"]
             comm = made["comm"]
@@ -669,6 +676,10 @@ def bench_multi(args, torch, rank, world, local_rank):
                          "traffic": None},
             "verified": verified,
             "verify": {"own_slab_in_gathered": own_ok, "gathered_equals_single_gpu_trace": None if ref is None else verified},
+            # for a curve over N drawn from ONE workload: the ranks the collective really spanned, and what rank 0 alone makes
+            # of this same sweep (the N = 1 bench line is BASELINE config 2, another workload)
+            "nranks_seen": comm.nranks_seen if comm is not None else (dist.get_world_size() if dist is not None else 1),
+            "single_rank_same_workload_value": None if ref is None else ref["value"],
         }
         if ref is not None:
             res["strong_scaling_reference"] = ref
@@ -679,6 +690,50 @@ def bench_multi(args, torch, rank, world, local_rank):
         comm.close()
     if dist is not None:
         dist.destroy_process_group()
+
+
+def spawn_ranks(n: int, argv, timeout_s: float = 3300.0):
+    """`python bench.py --gpus N` without a launcher: start the N ranks as ONE child process tree
+    (`python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 ...`, one rank per GPU) BEFORE
+    this process imports torch or touches the GPU, relay the children's output, and return (return code, rank 0's JSON
+    line or None).  Never exec: the parent stays a plain process and exits with the children's code."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:                                  # a free rendezvous port on the loopback interface
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__), *argv]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")            # dmabuf IPC: RCCL across processes needs it on this host driver
+    env["ORT_BENCH_SPAWNED"] = "1"
+    line = None
+    proc = subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=None, text=True, env=env)
+    try:
+        for out in proc.stdout:                                  # relay as it comes: a long run keeps printing
+            if out.startswith("{") and line is None:
+                line = out.strip()
+            sys.stdout.write(out); sys.stdout.flush()
+        rc = proc.wait(timeout=timeout_s)
+    except Exception:                                            # noqa: BLE001
+        proc.kill()
+        raise
+    return rc, line
+
+
+def selftest_ranks():
+    """What a spawned rank does under --selftest-ranks: rendezvous over gloo on the CPU (no GPU needed), agree on the
+    world size, rank 0 prints one JSON line.  tests/test_dist_gloo.py drives the spawn path through this."""
+    import torch
+    import torch.distributed as dist
+    from opticalraytracing_jl_amd import dist as odist
+    rank, world, _ = odist.env_rank_world()
+    odist.init_process_group("gloo")
+    t = torch.tensor([rank + 1], dtype=torch.int64)
+    dist.all_reduce(t)
+    if rank == 0:
+        print(json.dumps({"selftest": True, "world": world, "rank_sum": int(t[0]), "spawned": os.environ.get("ORT_BENCH_SPAWNED") == "1"}), flush=True)
+    dist.destroy_process_group()
 
 
 def main():
@@ -706,12 +761,25 @@ def main():
     ap.add_argument("--workload", default="auto", choices=["auto", "config2", "config4", "config5"],
                     help="auto: config 2 at N = 1, config 4 (sharded + all-gather) at N > 1; config5: the Float32 hit payload of the "
                          "Monte-Carlo run, sharded + all-gathered the same way")
+    ap.add_argument("--selftest-ranks", action="store_true", help="spawned ranks only rendezvous (gloo, CPU) and report: the launcher's own test")
     args = ap.parse_args()
     if args.fast_math:
         args.policy = "fast"
 
     from opticalraytracing_jl_amd import dist as odist
     rank, world, local_rank = odist.env_rank_world()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # called the way the driver calls --gpus 1: launch the ranks ourselves, before anything here touches the GPU
+        rc, line = spawn_ranks(args.gpus, sys.argv[1:])
+        if line is None and rc == 0:
+            rc = 4
+            sys.stderr.write("bench.py: the ranks exited without a JSON line\n")
+        raise SystemExit(rc)
+    if args.gpus > 1 and world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but the launcher started {world} rank(s)")
+    if args.selftest_ranks:
+        selftest_ranks()
+        return
     # N = 1: what store rate does the history LAYOUT itself sustain on this box (tools/store_ceiling: the same launch
     # shape and stores, no ray tracing)?  Run as a child process BEFORE this process touches the GPU.
     args.layout_ceiling = None
@@ -728,8 +796,6 @@ def main():
         except Exception:                                       # noqa: BLE001 — a missing helper only drops the extra field
             args.layout_ceiling = None
     import torch
-    if args.gpus > 1 and world != args.gpus:
-        raise SystemExit(f"--gpus {args.gpus} needs torchrun with {args.gpus} ranks (WORLD_SIZE={world})")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the engine has no CPU fallback")
     multi = args.workload in ("config4", "config5") or (args.workload == "auto" and world > 1)

@@ -37,7 +37,7 @@
 extern "C" {
 #endif
 
-#define ORT_VERSION 200            /* 0.2.0: ort_aim_out gained XP_t; ort_aberrations_f64, ort_fan_f64 */
+#define ORT_VERSION 300            /* 0.3.0: ort_wavegrad_f64; ORT_NO_LDS dropped; look-back faults are reported */
 #define ORT_MAX_ROWS 64            /* surface-matrix rows per system, object row included */
 #define ORT_MAX_NCOEF 12           /* polynomial coefficients per surface */
 
@@ -95,6 +95,7 @@ int ort_ctx_device_info(ort_ctx *ctx, char *name, int name_len, int *cus, int *c
  * history is 1.8 GB, 30 ms over PCIe against 0.3 ms of kernel.  upload / download block until the copy is
  * done; free waits for the context's stream first.                                                      */
 int ort_device_malloc(ort_ctx *ctx, size_t bytes, void **out);
+/* waits for the context's stream AND for the collectives in flight on its communicators' own streams (ort_comm_*). */
 int ort_device_free(ort_ctx *ctx, void *p);
 int ort_device_upload(ort_ctx *ctx, void *dst_device, const void *src_host, size_t bytes);
 int ort_device_download(ort_ctx *ctx, void *dst_host, const void *src_device, size_t bytes);
@@ -201,6 +202,16 @@ int ort_full_trace_f32(ort_ctx *ctx, const ort_system *sys, int nb, const ort_bu
                        float *ex, float *ey, float *rho, float *theta,
                        int64_t *count, double *rms, unsigned flags);
 
+/* wavegrad(eps, lambda) = (eps.x nu / lambda, eps.y nu / lambda), src/PupilSampling.jl:165-167: the transverse errors of
+ * nb full_trace results in waves, without bringing them to the host first.  ex, ey, gx, gy : [nb][cap] (cap = 2*ny*nx,
+ * the slab stride of ort_full_trace_f64); count : [nb] valid entries per slab; nu : [nb] = system.marginal.nu[end].
+ * Out of place, like the reference's map; every pointer host or device per ORT_DEVICE_PTRS. */
+int ort_wavegrad_f64(ort_ctx *ctx, int nb, int64_t cap, const int64_t *count, const double *nu, double lambda,
+                     const double *ex, const double *ey, double *gx, double *gy, unsigned flags);
+/* Testing aid: shift the context's look-back ticket base against the device counter, the bookkeeping fault that
+ * ort_full_trace_* with ORT_FT_LOOKBACK must report (ORT_EHIP; device-pointer callers see count = -1, rms = NaN). */
+int ort_ctx_test_skew_tickets(ort_ctx *ctx, int64_t delta);
+
 /* ---- meridional real-ray trace: raytrace(surfaces, y, U, RealRay; K, p) ---------------
  * src/RayTracing.jl:145-169.  y_out, U_out, ts_out : [rows][ld] (row 0 = input ray;
  * ts_out = per-ray distances whose cumsum is RealRay.z, Types.jl:61-63; may be NULL).    */
@@ -250,7 +261,8 @@ int ort_aim_f64(ort_ctx *ctx, const ort_system *fwd, const ort_system *rev, int 
  * src/SeidelAberrations.jl:116-137: for every request the k_rays rays y = range(y_m / k, y_m, k), U = 0 through
  * system `system` of the batch in one launch, each extended to the exit pupil and to the focal plane:
  *   y_XP[i] = ray.y[end] + tan(ray.u[end]) XP_t,   eps[i] = ray.y[end] + tan(ray.u[end]) (BFD - sag(ray))
- * (the last ray is the real marginal ray itself, :127-128).  descending != 0 walks the range backwards,
+ * (the last ray is the real marginal ray itself, :127-128: its sag is taken against the paraxial vertex, s_last without the
+ * last thickness, :125-127 — the same number whenever the prescription ends in image space).  descending != 0 walks the range backwards,
  * range(y_m, y_m / k, k): with BFD = the paraxial or the marginal back focal distance this is the ray set
  * and the image-space end points of the caustic plot (ext/MakieExtension.jl:364-381; its per-surface
  * polylines are ort_trace_meridional_f64's history).  y_m, XP_t come from ort_aim_f64 (y_EP, XP_t).

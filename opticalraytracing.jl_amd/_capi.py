@@ -124,6 +124,8 @@ SIGNATURES = {
     "ort_make_axes_f64": (_i, [_p, _i, _i, _i, _p, _p, _u]),
     "ort_full_trace_f64": (_i, [_p, _p, _i, C.POINTER(ort_bundle), _p, _l, _i, _i, _p, _p, _p, _p, _p, _p, _u]),
     "ort_full_trace_f32": (_i, [_p, _p, _i, C.POINTER(ort_bundle), _p, _l, _i, _i, _p, _p, _p, _p, _p, _p, _u]),
+    "ort_wavegrad_f64": (_i, [_p, _i, _l, _p, _p, C.c_double, _p, _p, _p, _p, _u]),
+    "ort_ctx_test_skew_tickets": (_i, [_p, _l]),
     "ort_aim_f64": (_i, [_p, _p, _p, _i, C.POINTER(ort_aim_in), C.POINTER(ort_aim_out), _u]),
     "ort_fan_f64": (_i, [_p, _p, _i, C.POINTER(ort_fan_in), _i, _i, _p, _p, _u]),
     "ort_first_order_f64": (_i, [_p, _i, _i, _p, _p, _p, _p, _p, _p, C.c_double, C.POINTER(ort_first_order), _u]),

@@ -848,6 +848,8 @@ def full_trace_batch(systems: Sequence[System], fields: Sequence[float], k_rays:
 
 
 def wavegrad(err: RealRayError, lam: float = LAMBDA):                 # PupilSampling.jl:165-167
+    """map(field -> getfield(ε, field) * ε.nu / λ, (:x, :y)) — the transverse errors in waves.  A host-resident
+    RealRayError: two elementwise IEEE operations here; device-resident slabs: HipEngine.wavegrad (ort_wavegrad_f64)."""
     return err.x * err.nu / lam, err.y * err.nu / lam
 
 

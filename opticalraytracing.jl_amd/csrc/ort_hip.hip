@@ -68,7 +68,7 @@ enum { SL_IN0 = 0, SL_IN1, SL_IN2, SL_IN3, SL_OUT0, SL_OUT1, SL_OUT2, SL_OUT3, S
        SL_BUNDLES, SL_AXES, SL_WEX, SL_WEY, SL_WR, SL_WTH, SL_TCNT, SL_TSX, SL_TSY, SL_TRM,
        SL_TOFF, SL_TSQ, SL_AGG, SL_RES0, SL_RES1, SL_TAB0, SL_TAB1, SL_TAB2, SL_TAB3,
        SL_SB_FO, SL_SB_REC, SL_SB_MF, SL_SB_MR, SL_SB_TLF, SL_SB_TLR, SL_SB_AIN, SL_SB_AOUT, SL_SB_ENDS, SL_SB_FLAG,
-       SL_SB_FIELDS, SL_SB_A, SL_SB_HP, SL_SB_PACK, SL_SB_CEXT, SL_SB_CREV, SL_FTSTATE, SL_FTTICKET, SL_DOMAIN, SL_COUNT };
+       SL_SB_FIELDS, SL_SB_A, SL_SB_HP, SL_SB_PACK, SL_SB_CEXT, SL_SB_CREV, SL_FTSTATE, SL_FTTICKET, SL_FTERR, SL_DOMAIN, SL_COUNT };
 
 }  // namespace
 
@@ -85,6 +85,7 @@ struct ort_ctx {
     size_t ft_state_cap = 0;                   // capacity of SL_FTSTATE the zero fill was done for
     unsigned ft_epoch = 0;
     unsigned long long ft_ticket_base = 0;
+    std::vector<struct ort_comm*> comms;       // live communicators of this context (their streams may hold buffers in flight)
     int pinned(size_t bytes, unsigned char** out)
     {
         if (bytes > pin_cap) {
@@ -201,6 +202,8 @@ int check_sys(ort_ctx* ctx, const ort_system* sys)
     if (sys->ctx != ctx) return fail(ORT_EINVAL, "system belongs to another context");
     return ORT_OK;
 }
+
+int sync_comm_streams(ort_ctx* ctx);    // (defined beside ort_comm, below)
 
 // copy a host array into a scratch slot (synchronous with respect to the host buffer)
 template <typename T>
@@ -431,7 +434,7 @@ int run_full_trace(ort_ctx* ctx, TraceParams<T>& p, int nb, T* ex, T* ey, T* rho
         }
         return ORT_OK;
     }
-    double* chunk_sq; FtBundleAgg* agg;
+    double* chunk_sq; FtBundleAgg* agg; int* ft_err = nullptr;
     rc = dev_out<double>(ctx, SL_TSQ, (size_t)tiles, &chunk_sq); if (rc) return rc;
     rc = dev_out<FtBundleAgg>(ctx, SL_AGG, (size_t)nb, &agg); if (rc) return rc;
     T *dex = ex, *dey = ey, *drho = rho, *dth = theta;
@@ -445,10 +448,11 @@ int run_full_trace(ort_ctx* ctx, TraceParams<T>& p, int nb, T* ex, T* ey, T* rho
         // default route: tile-local compaction into a workspace | tile offsets + bundle aggregates | placement of the
         // survivors in both halves + squared deviations | sigma.  No workgroup waits for another.
         T *wex, *wey, *wr, *wth; int64_t* tile_off;
-        rc = dev_out<T>(ctx, SL_WEX, (size_t)N, &wex); if (rc) return rc;
-        rc = dev_out<T>(ctx, SL_WEY, (size_t)N, &wey); if (rc) return rc;
-        rc = dev_out<T>(ctx, SL_WR, (size_t)N, &wr); if (rc) return rc;
-        rc = dev_out<T>(ctx, SL_WTH, (size_t)N, &wth); if (rc) return rc;
+        const size_t nw = (size_t)tiles * kTile;                 // a slot of kTile entries per tile
+        rc = dev_out<T>(ctx, SL_WEX, nw, &wex); if (rc) return rc;
+        rc = dev_out<T>(ctx, SL_WEY, nw, &wey); if (rc) return rc;
+        rc = dev_out<T>(ctx, SL_WR, nw, &wr); if (rc) return rc;
+        rc = dev_out<T>(ctx, SL_WTH, nw, &wth); if (rc) return rc;
         rc = dev_out<int64_t>(ctx, SL_TOFF, (size_t)tiles, &tile_off); if (rc) return rc;
         p.out_ex = wex; p.out_ey = wey; p.out_r = wr; p.out_th = wth;
         rc = launch_trace<T, true, false, false, FT_FULL>(ctx, p, tiles, flags); if (rc) return rc;
@@ -473,27 +477,36 @@ int run_full_trace(ort_ctx* ctx, TraceParams<T>& p, int nb, T* ex, T* ey, T* rho
             ctx->ft_ticket_base = 0;
         }
         p.ft_ticket = static_cast<unsigned long long*>(ctx->slot[SL_FTTICKET].p);
+        rc = dev_out<int>(ctx, SL_FTERR, 1, &p.ft_err); if (rc) return rc;
+        HIP_TRY(hipMemsetAsync(p.ft_err, 0, sizeof(int), ctx->stream));
+        ft_err = p.ft_err;
         ctx->ft_epoch = (ctx->ft_epoch + 1) & 0x3fffffffu;
         if (ctx->ft_epoch == 0) ctx->ft_epoch = 1;
         p.ft_epoch = ctx->ft_epoch;
         p.ft_ticket_base = ctx->ft_ticket_base;
-        ctx->ft_ticket_base += (unsigned long long)tiles;
         p.out_ex = dex; p.out_ey = dey; p.out_r = drho; p.out_th = dth;
         rc = launch_trace<T, true, false, false, FT_LOOKBACK>(ctx, p, tiles, flags); if (rc) return rc;
+        ctx->ft_ticket_base += (unsigned long long)tiles;        // only a launch that went out has taken its tickets
         hipLaunchKernelGGL(k_ft_scan, dim3((unsigned)nb), dim3(kBlock), 0, ctx->stream,
                            p.tile_cnt, p.tile_sx, p.tile_sy, p.tile_rmax, p.tiles_per_bundle, (int64_t*)nullptr, agg);
         HIP_TRY(hipGetLastError());
         hipLaunchKernelGGL((k_ft_mirror<T>), dim3((unsigned)tiles), dim3(kBlock), 0, ctx->stream,
-                           rpb, p.tiles_per_bundle, agg, dex, dey, drho, dth, chunk_sq);
+                           rpb, p.tiles_per_bundle, agg, dex, dey, drho, dth, chunk_sq, (const int*)ft_err);
         HIP_TRY(hipGetLastError());
     }
     hipLaunchKernelGGL(k_ft_finalize, dim3((unsigned)nb), dim3(kBlock), 0, ctx->stream,
-                       chunk_sq, p.tiles_per_bundle, agg, dcount, drms);
+                       chunk_sq, p.tiles_per_bundle, agg, dcount, drms, (const int*)ft_err);
     HIP_TRY(hipGetLastError());
     if (!devp) {
+        int herr = 0;
         rc = from_device<int64_t>(ctx, count, dcount, (size_t)nb); if (rc) return rc;
         rc = from_device<double>(ctx, rms, drms, (size_t)nb); if (rc) return rc;
+        if (ft_err) { rc = from_device<int>(ctx, &herr, ft_err, 1); if (rc) return rc; }
         HIP_TRY(hipStreamSynchronize(ctx->stream));
+        if (herr)
+            return fail(ORT_EHIP, "full_trace look-back fault (%s): the survivors' offsets are not trustworthy, nothing was returned",
+                        (herr & 2) ? "tile tickets outside the launch: the context's ticket base and the device counter disagree"
+                                   : "a tile waited for a predecessor beyond the poll cap");
         for (int b = 0; b < nb; ++b) {
             const size_t off = (size_t)b * 2 * rpb, cnt = (size_t)count[b];
             if (!cnt) continue;
@@ -776,8 +789,48 @@ int ort_device_free(ort_ctx* ctx, void* p)
 {
     int rc = check_ctx(ctx); if (rc) return rc;
     if (!p) return ORT_OK;
-    HIP_TRY(hipStreamSynchronize(ctx->stream));                 // no launch of this context may still use it
+    HIP_TRY(hipStreamSynchronize(ctx->stream));                 // no launch of this context may still use it,
+    rc = sync_comm_streams(ctx); if (rc) return rc;             // nor a collective still in flight on a communicator's own stream
     HIP_TRY(hipFree(p));
+    return ORT_OK;
+}
+
+// Testing aid (tests/test_gpu_parity.py): shift the context's look-back ticket base against the device counter — the
+// bookkeeping fault the look-back route must REPORT (ORT_EHIP) rather than misplace survivors.
+int ort_ctx_test_skew_tickets(ort_ctx* ctx, int64_t delta)
+{
+    int rc = check_ctx(ctx); if (rc) return rc;
+    ctx->ft_ticket_base += (unsigned long long)delta;
+    return ORT_OK;
+}
+
+// wavegrad(eps, lambda) (src/PupilSampling.jl:165-167) of full_trace results, device or host buffers.
+int ort_wavegrad_f64(ort_ctx* ctx, int nb, int64_t cap, const int64_t* count, const double* nu, double lambda,
+                     const double* ex, const double* ey, double* gx, double* gy, unsigned flags)
+{
+    int rc = check_ctx(ctx); if (rc) return rc;
+    if (nb <= 0 || cap <= 0 || !count || !nu || !ex || !ey || !gx || !gy || !(lambda > 0.0)) return fail(ORT_EINVAL, "bad wavegrad arguments");
+    const bool devp = flags & ORT_DEVICE_PTRS;
+    const int64_t chunks = (cap + kTile - 1) / kTile;
+    if (chunks * nb > 0x7fffffffLL) return fail(ORT_EINVAL, "launch too large");
+    const int64_t* dcount = count; const double *dnu = nu, *dex = ex, *dey = ey; double *dgx = gx, *dgy = gy;
+    const size_t n = (size_t)nb * (size_t)cap;
+    if (!devp) {
+        rc = to_device<int64_t>(ctx, SL_IN0, count, (size_t)nb, &dcount); if (rc) return rc;
+        rc = to_device<double>(ctx, SL_IN1, nu, (size_t)nb, &dnu); if (rc) return rc;
+        rc = to_device<double>(ctx, SL_IN2, ex, n, &dex); if (rc) return rc;
+        rc = to_device<double>(ctx, SL_IN3, ey, n, &dey); if (rc) return rc;
+        rc = dev_out<double>(ctx, SL_OUT0, n, &dgx); if (rc) return rc;
+        rc = dev_out<double>(ctx, SL_OUT1, n, &dgy); if (rc) return rc;
+    }
+    hipLaunchKernelGGL((k_wavegrad<double>), dim3((unsigned)(chunks * nb)), dim3(kBlock), 0, ctx->stream, cap, (int)chunks, dcount, dnu,
+                       lambda, dex, dey, dgx, dgy);
+    HIP_TRY(hipGetLastError());
+    if (!devp) {
+        rc = from_device<double>(ctx, gx, dgx, n); if (rc) return rc;
+        rc = from_device<double>(ctx, gy, dgy, n); if (rc) return rc;
+        HIP_TRY(hipStreamSynchronize(ctx->stream));
+    }
     return ORT_OK;
 }
 
@@ -1383,6 +1436,12 @@ struct ort_comm {
 };
 
 namespace {
+int sync_comm_streams(ort_ctx* ctx)
+{
+    for (ort_comm* c : ctx->comms)
+        if (c && c->stream) HIP_TRY(hipStreamSynchronize(c->stream));
+    return ORT_OK;
+}
 int comm_begin(ort_comm* c)          // comm stream waits for everything queued on the context's stream so far
 {
     HIP_TRY(hipEventRecord(c->ev_in, c->ctx->stream));
@@ -1426,6 +1485,7 @@ int ort_comm_create(ort_ctx* ctx, int nranks, int rank, const void* id128, ort_c
     if (e != hipSuccess) { ort_comm_destroy(c); return fail(ORT_EHIP, "communicator resources: %s", hipGetErrorString(e)); }
     int r = g_rccl.CommInitRank(&c->comm, nranks, id, rank);
     if (r != 0) { c->comm = nullptr; ort_comm_destroy(c); return fail(ORT_EHIP, "ncclCommInitRank failed: %s", g_rccl.GetErrorString ? g_rccl.GetErrorString(r) : "?"); }
+    ctx->comms.push_back(c);
     *out = c;
     return ORT_OK;
 }
@@ -1433,6 +1493,7 @@ int ort_comm_create(ort_ctx* ctx, int nranks, int rank, const void* id128, ort_c
 int ort_comm_destroy(ort_comm* comm)
 {
     if (!comm) return ORT_OK;
+    for (auto& q : comm->ctx->comms) if (q == comm) q = nullptr;
     hipError_t e = hipSetDevice(comm->ctx->device); (void)e;
     if (comm->stream) { e = hipStreamSynchronize(comm->stream); (void)e; }
     e = hipStreamSynchronize(comm->ctx->stream); (void)e;

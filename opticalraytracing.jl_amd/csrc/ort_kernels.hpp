@@ -8,8 +8,8 @@
 //   history         T[S][ld] surface-major: lane l of a wave writes 16 B (RPT = 2 adjacent
 //                   rays) at consecutive addresses -> 1 KiB per store instruction.
 //   summary         SoA T[N] x {xf, yf, xs, ys} + int32 status[N].
-//   full_trace      workspace T[N] x {ex, ey, r, theta}: tile t of bundle b fills only its compacted survivors at
-//                   b*rpb + 512 t; outputs [nb][2*rpb] (first half = survivors in ray order, second half = mirror).
+//   full_trace      workspace T[tiles][512] x {ex, ey, r, theta}: a tile fills only its compacted survivors of its own
+//                   slot; outputs [nb][2*rpb] (first half = survivors in ray order, second half = mirror).
 // One thread owns RPT = 2 adjacent rays: 16-byte stores and two independent FP64 div/sqrt
 // dependency chains per lane.  Workgroup = 256 threads = 512 rays; a launch is
 // nb * ceil(ny*nx/512) workgroups (>> 256 CUs at every BASELINE config but #1).  Output is
@@ -90,13 +90,14 @@ struct TraceParams {
     T* xf; T* yf; T* xs; T* ys;
     int32_t* status;
     // full_trace: where the trace kernel puts a tile's compacted survivors (ex, ey, UN-normalised stop radius, theta).
-    // FT_FULL: out_* = workspace [N], tile t of bundle b at b*rpb + t*kTile.  FT_LOOKBACK: out_* = the caller's
+    // FT_FULL: out_* = workspace [tiles][kTile], a slot per tile.  FT_LOOKBACK: out_* = the caller's
     // ex / ey / rho / theta [nb][2*rpb], at the offset found by a decoupled look-back over the bundle's tiles
     T* out_ex; T* out_ey; T* out_r; T* out_th;
     unsigned long long* ft_state;       // [tiles] look-back words: state (2 bits) | epoch (30 bits) | prefix (32 bits)
     unsigned long long* ft_ticket;      // tiles are taken in ticket order: every predecessor of a tile has started
     unsigned long long ft_ticket_base;  // tickets handed out by earlier launches
     unsigned ft_epoch;                  // launch number: words of earlier launches read as "not yet written"
+    int* ft_err;                        // look-back fault word: bit 0 = a wait hit its poll cap, bit 1 = a ticket outside the grid
     int32_t* tile_cnt; double* tile_sx; double* tile_sy; double* tile_rmax;
     double* tile_m2x; double* tile_m2y;     // FT_STATS: sums of squared deviations about the tile means
 };
@@ -134,6 +135,30 @@ __device__ __forceinline__ void store_vec2(T* p, T a, T b)
 #else
     *reinterpret_cast<typename Vec2<T>::type*>(p) = v2;
 #endif
+}
+
+// ------------------------------------------------------------------------------------
+// 16-byte streaming of a compacted tile held in LDS to an arbitrarily aligned place of an output array: `head`
+// scalar elements up to the first 16-byte boundary of the destination, then one aligned vector per thread and trip
+// (2 doubles / 4 floats, non-temporal), then a scalar tail.  F maps the staged value to the stored one.
+template <typename T, typename F>
+__device__ __forceinline__ void stream_out(T* __restrict__ dst, const T* __restrict__ lds, int c, int tid, F f)
+{
+    constexpr int V = 16 / (int)sizeof(T);
+    typedef T vec_t __attribute__((ext_vector_type(V)));
+    const int mis = (int)((reinterpret_cast<uintptr_t>(dst) & 15) / sizeof(T));     // elements past a 16-byte boundary
+    const int head = min(c, mis ? V - mis : 0);
+    const int nvec = (c - head) / V;
+    if (tid < head) __builtin_nontemporal_store(f(lds[tid]), dst + tid);
+    for (int g = tid; g < nvec; g += kBlock) {
+        const int j = head + g * V;
+        vec_t v;
+#pragma unroll
+        for (int q = 0; q < V; ++q) v[q] = f(lds[j + q]);
+        __builtin_nontemporal_store(v, reinterpret_cast<vec_t*>(dst + j));
+    }
+    const int j = head + nvec * V + tid;                                            // < V - 1 elements left
+    if (j < c) __builtin_nontemporal_store(f(lds[j]), dst + j);
 }
 
 __device__ __forceinline__ double dev_tan(double a) { return ::tan(a); }
@@ -183,7 +208,10 @@ void k_trace(TraceParams<T> p)   // both outputs, look-back epilogue, polynomial
 #else
             unsigned long long tk = atomicAdd(p.ft_ticket, 1ull) - p.ft_ticket_base;
 #endif
-            if (tk >= gridDim.x) tk = gridDim.x - 1;                 // (never out of the grid, whatever the host passed)
+            if (tk >= gridDim.x) {                                   // host bookkeeping fault: never index out of the grid, and say so —
+                tk = gridDim.x - 1;                                  // the call returns an error instead of misplaced survivors
+                atomicOr(p.ft_err, 2);
+            }
             // tickets walk the bundles round-robin (ticket = tile * nb + bundle): the tiles in flight at any time
             // are spread over all the bundles' chains, so each look-back chain below is nb times shorter; a tile's
             // predecessors in its bundle still hold lower tickets
@@ -374,6 +402,18 @@ void k_trace(TraceParams<T> p)   // both outputs, look-back epilogue, polynomial
         trace_surfaces(std::integral_constant<int, MATH_IEEE>{});
     }
 
+    // The stop filter r > a_stop (PupilSampling.jl:131-132).  The reference sequence takes hypot.  MATH_FAST decides by
+    // r^2 against a_stop^2 — the same outcome for every ray farther than kNear from the edge — and only the rays within
+    // kNear of it (their wave has retraced with the reference sequence, see the stop capture above) take the hypot.
+    auto outside_stop = [&](T xs, T ys, T& r2) -> bool {
+        if (MATH == MATH_IEEE) { r2 = T(0); return dev_hypot(xs, ys) > a_stop; }
+        const T a2 = a_stop < T(0) ? T(-1) : a_stop * a_stop;        // a negative radius passes nothing
+        r2 = t_fma<T>(xs, xs, ys * ys);
+        bool out = r2 > a2;
+        if (near_zero<T>(r2 - a2, (T)Near<T>::thr * a2)) out = dev_hypot(xs, ys) > a_stop;
+        return out;
+    };
+
     if (SUMM) {
         if (live[0]) {
             if (p.xf) store_pair<T>(p.xf, gbase, two, ray[0].x, ray[kRPT - 1].x);
@@ -386,8 +426,8 @@ void k_trace(TraceParams<T> p)   // both outputs, look-back epilogue, polynomial
                     if (!live[r]) continue;
                     int32_t s = st[r];
                     if (stopi >= 0) {
-                        const T ri = dev_hypot(xs_[r], ys_[r]);
-                        if (ri > a_stop) s |= (1 << 16);
+                        T r2;
+                        if (outside_stop(xs_[r], ys_[r], r2)) s |= (1 << 16);
                     }
                     p.status[gbase + r] = s;
                 }
@@ -405,9 +445,14 @@ void k_trace(TraceParams<T> p)   // both outputs, look-back epilogue, polynomial
 #pragma unroll
         for (int r = 0; r < kRPT; ++r) {
             const T xf = ray[r].x, yf = ray[r].y;
-            const T ri = dev_hypot(xs_[r], ys_[r]);                  // :131
-            const bool drop = (ri > a_stop) || t_isnan(xf) || t_isnan(yf) || !live[r] ||   // :132
-                              (st[r] & kStatusVignetted);
+            T r2;
+            const bool outside = outside_stop(xs_[r], ys_[r], r2);                        // :131-132
+            // r itself (rho, :136,142): the reference sequence keeps its hypot; MATH_FAST takes the root of r^2 (seeded from
+            // r^2 + tiny: an on-axis ray gives 0, not 0 * inf), and the statistics-only route needs no r at all
+            T ri = T(0);
+            if (MATH == MATH_IEEE) ri = dev_hypot(xs_[r], ys_[r]);
+            else if (kCompact) ri = r2 * fast_rsqrt(r2 + (sizeof(T) == 8 ? (T)1e-300 : (T)1e-36));
+            const bool drop = outside || t_isnan(xf) || t_isnan(yf) || !live[r] || (st[r] & kStatusVignetted);
             keep[r] = !drop;
             if (kCompact) thv[r] = dev_atan2(ys_[r], xs_[r]);          // :133
             eyv[r] = yf - hprime;                                    // :134
@@ -433,7 +478,7 @@ void k_trace(TraceParams<T> p)   // both outputs, look-back epilogue, polynomial
         if (lane == 0) { s_wcnt[wave] = cnt; s_wsx[wave] = sx; s_wsy[wave] = sy; s_wmax[wave] = rmax; }
         __syncthreads();
         if (kCompact) {
-            __shared__ T s_cx[kCompact ? kTile : 1], s_cy[kCompact ? kTile : 1], s_cr[kCompact ? kTile : 1], s_ct[kCompact ? kTile : 1];
+            __shared__ __attribute__((aligned(16))) T s_cx[kCompact ? kTile : 1], s_cy[kCompact ? kTile : 1], s_cr[kCompact ? kTile : 1], s_ct[kCompact ? kTile : 1];
             __shared__ long long s_base;
             int woff = 0, c = 0;
             for (int w = 0; w < kBlock / 64; ++w) { woff += (w < wave) ? s_wcnt[w] : 0; c += s_wcnt[w]; }
@@ -471,7 +516,7 @@ void k_trace(TraceParams<T> p)   // both outputs, look-back epilogue, polynomial
                 while (hi >= 0) {
                     // lane l looks at tiles hi - kLook l - j, j = 0 .. kLook-1 (nearest first); every tile with a lower
                     // ticket is running or done, so the waits end; the cap is a guard against a host-side bookkeeping
-                    // error only (the wave then leaves with a zero prefix)
+                    // error only: it raises the fault word and the whole call returns an error
                     long long part = 0;                          // sum of this lane's words up to its first inclusive one
                     bool found = false;
 #pragma unroll
@@ -479,12 +524,17 @@ void k_trace(TraceParams<T> p)   // both outputs, look-back epilogue, polynomial
                         const int t = hi - kLook * lane - j;
                         unsigned long long wd = 2ull << 62 | ep; // beyond the first tile: an inclusive prefix of 0
                         if (t >= 0) {
-                            for (int spin = 0; spin < (1 << 22); ++spin) {
+                            bool got = false;
+                            for (int spin = 0; spin < (1 << 22) && !got; ++spin) {
                                 wd = __hip_atomic_load(stw + t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                                if ((wd >> 62) != 0 && (wd & (0x3fffffffull << 32)) == ep) break;
-                                wd = 2ull << 62 | ep;
-                                __builtin_amdgcn_s_sleep(1);
+                                got = (wd >> 62) != 0 && (wd & (0x3fffffffull << 32)) == ep;
+                                if (!got) {
+                                    // a fault already recorded (tickets outside the grid: predecessors that never run): stop waiting
+                                    if ((spin & 255) == 255 && __hip_atomic_load(p.ft_err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) break;
+                                    __builtin_amdgcn_s_sleep(1);
+                                }
                             }
+                            if (!got) { atomicOr(p.ft_err, 1); wd = 2ull << 62 | ep; }   // cap hit: the call fails (run_full_trace)
                         }
                         if (!found) part += (long long)(wd & 0xffffffffull);
                         found = found || ((wd >> 62) == 2);
@@ -505,10 +555,24 @@ void k_trace(TraceParams<T> p)   // both outputs, look-back epilogue, polynomial
                 }
             }
             __syncthreads();
-            // FT_FULL: the tile's slot of the workspace [N]; FT_LOOKBACK: its place in the bundle's output slab [2 rpb]
-            const int64_t o0 = (FT == FT_FULL) ? (int64_t)b * p.rpb + (int64_t)tile * kTile : (int64_t)b * 2 * p.rpb + s_base;
-            for (int j = tid; j < c; j += kBlock) {
-                p.out_ex[o0 + j] = s_cx[j]; p.out_ey[o0 + j] = s_cy[j]; p.out_r[o0 + j] = s_cr[j]; p.out_th[o0 + j] = s_ct[j];
+            if (FT == FT_FULL) {
+                // the tile's own slot of the workspace [tiles][kTile]: 16-byte aligned, so whole vectors go out (the
+                // entries past c inside the slot are never read)
+                constexpr int V = 16 / (int)sizeof(T);
+                typedef T vec_t __attribute__((ext_vector_type(V)));
+                const int64_t o0 = (int64_t)bid * kTile;
+                for (int j = tid * V; j < c; j += kBlock * V) {
+                    *reinterpret_cast<vec_t*>(p.out_ex + o0 + j) = *reinterpret_cast<const vec_t*>(s_cx + j);
+                    *reinterpret_cast<vec_t*>(p.out_ey + o0 + j) = *reinterpret_cast<const vec_t*>(s_cy + j);
+                    *reinterpret_cast<vec_t*>(p.out_r + o0 + j) = *reinterpret_cast<const vec_t*>(s_cr + j);
+                    *reinterpret_cast<vec_t*>(p.out_th + o0 + j) = *reinterpret_cast<const vec_t*>(s_ct + j);
+                }
+            } else {
+                // FT_LOOKBACK: its place in the bundle's output slab [2 rpb], any alignment
+                const int64_t o0 = (int64_t)b * 2 * p.rpb + s_base;
+                auto same = [](T v) { return v; };
+                stream_out<T>(p.out_ex + o0, s_cx, c, tid, same); stream_out<T>(p.out_ey + o0, s_cy, c, tid, same);
+                stream_out<T>(p.out_r + o0, s_cr, c, tid, same);  stream_out<T>(p.out_th + o0, s_ct, c, tid, same);
             }
         } else {
             // FT_STATS: two-pass INSIDE the tile (the tile's survivors are still in registers): tile means,
@@ -614,43 +678,42 @@ __global__ __launch_bounds__(kBlock) void k_ft_scan(const int32_t* __restrict__ 
                                                     int64_t* __restrict__ tile_off,
                                                     FtBundleAgg* __restrict__ agg)
 {
+    // thread t owns the contiguous chunk of `per` tiles [t per, (t+1) per): a serial pass for its total, ONE block
+    // scan of the 256 totals, a serial pass writing the offsets — two passes and one scan whatever the tile count
+    // (8192 tiles per bundle at 2048^2: 32 per thread), where a block-wide scan per 256 tiles took 32 rounds
     __shared__ int64_t s_w[kBlock / 64];
-    __shared__ int64_t s_carry;
     __shared__ double s_rx[kBlock], s_ry[kBlock], s_rm[kBlock];
     const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int64_t base = (int64_t)b * tiles_per_bundle;
-    if (tid == 0) s_carry = 0;
+    const int per = (tiles_per_bundle + kBlock - 1) / kBlock;
+    const int t0 = tid * per, t1 = min(tiles_per_bundle, t0 + per);
+    int64_t mine = 0;
     double ax = 0.0, ay = 0.0, mx = -1.0;
-    __syncthreads();
-    for (int t0 = 0; t0 < tiles_per_bundle; t0 += kBlock) {
-        const int t = t0 + tid;
-        const int64_t c = (t < tiles_per_bundle) ? tile_cnt[base + t] : 0;
-        if (t < tiles_per_bundle) { ax += tile_sx[base + t]; ay += tile_sy[base + t]; mx = fmax(mx, tile_rmax[base + t]); }
-        // inclusive wave scan
-        int64_t v = c;
-        for (int off = 1; off < 64; off <<= 1) {
-            const int64_t nb = __shfl_up(v, off);
-            if (lane >= off) v += nb;
-        }
-        if (lane == 63) s_w[wave] = v;
-        __syncthreads();
-        int64_t woff = 0;
-        for (int w = 0; w < wave; ++w) woff += s_w[w];
-        const int64_t carry = s_carry;
-        if (tile_off && t < tiles_per_bundle) tile_off[base + t] = carry + woff + v - c;
-        __syncthreads();
-        if (tid == kBlock - 1) s_carry = carry + woff + v;
-        __syncthreads();
+    for (int t = t0; t < t1; ++t) {
+        mine += tile_cnt[base + t];
+        ax += tile_sx[base + t]; ay += tile_sy[base + t]; mx = fmax(mx, tile_rmax[base + t]);
     }
-    // deterministic tree over the 256 per-thread partials
+    int64_t v = mine;                                            // inclusive wave scan of the per-thread totals
+    for (int off = 1; off < 64; off <<= 1) {
+        const int64_t nbv = __shfl_up(v, off);
+        if (lane >= off) v += nbv;
+    }
+    if (lane == 63) s_w[wave] = v;
     s_rx[tid] = ax; s_ry[tid] = ay; s_rm[tid] = mx;
     __syncthreads();
+    int64_t woff = 0, total = 0;
+    for (int w = 0; w < kBlock / 64; ++w) { woff += (w < wave) ? s_w[w] : 0; total += s_w[w]; }
+    if (tile_off) {
+        int64_t o = woff + v - mine;                             // exclusive offset of this thread's first tile
+        for (int t = t0; t < t1; ++t) { tile_off[base + t] = o; o += tile_cnt[base + t]; }
+    }
+    // deterministic tree over the 256 per-thread partials
     for (int off = kBlock / 2; off > 0; off >>= 1) {
         if (tid < off) { s_rx[tid] += s_rx[tid + off]; s_ry[tid] += s_ry[tid + off]; s_rm[tid] = fmax(s_rm[tid], s_rm[tid + off]); }
         __syncthreads();
     }
     if (tid == 0) {
-        const int64_t m = s_carry;
+        const int64_t m = total;
         FtBundleAgg a;
         a.m = m;
         // mean of [ex; -ex] and of [ey; ey] over n = 2m entries
@@ -666,7 +729,9 @@ __global__ __launch_bounds__(kBlock) void k_ft_scan(const int32_t* __restrict__ 
 // full_trace, stage C of the FT_FULL route: one workgroup per tile moves the tile's compacted survivors from its
 // workspace slot to both halves of the bundle's output slab — first half at the tile's exclusive offset (ray
 // order, :134-137), mirror [-ex; ey; rho; pi - theta] at offset m (:139-144), rho = r / maximum(r) (:142) — and
-// sums the squared deviations about the centroid (two-pass sigma, :169-173).  25 B/ray read, 50 B/ray written.
+// sums the squared deviations about the centroid (two-pass sigma, :169-173).  32 B per survivor read (16-byte loads
+// from the 16-byte-aligned slot), staged in LDS, 64 B written as aligned 16-byte streaming stores whatever the parity of
+// the tile's offset and of m (stream_out): the kernel is bound by HBM, and 8-byte accesses ran it at half the store rate.
 // ------------------------------------------------------------------------------------
 template <typename T>
 __global__ __launch_bounds__(kBlock) void k_ft_place(const T* __restrict__ w_ex, const T* __restrict__ w_ey,
@@ -678,28 +743,43 @@ __global__ __launch_bounds__(kBlock) void k_ft_place(const T* __restrict__ w_ex,
                                                      T* __restrict__ rho, T* __restrict__ theta,
                                                      double* __restrict__ tile_sq)
 {
+    constexpr int V = 16 / (int)sizeof(T);
+    typedef T vec_t __attribute__((ext_vector_type(V)));
+    __shared__ __attribute__((aligned(16))) T s_v[4][kTile];
     __shared__ double s_wsq[kBlock / 64];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int b = blockIdx.x / tiles_per_bundle;
-    const int tile = blockIdx.x - b * tiles_per_bundle;
     const int c = tile_cnt[blockIdx.x];
     const FtBundleAgg a = agg[b];
-    const int64_t src = (int64_t)b * rpb + (int64_t)tile * kTile;
+    const int64_t src = (int64_t)blockIdx.x * kTile;                              // the tile's slot: 16-byte aligned, kTile entries
     const int64_t dst = (int64_t)b * 2 * rpb + tile_off[blockIdx.x];
     double sq = 0.0;
-    for (int j = tid; j < c; j += kBlock) {
-        const T vx = w_ex[src + j], vy = w_ey[src + j], vt = w_th[src + j];
-        const T vr = w_r[src + j] / (T)a.rmax;                            // :142
-        const int64_t o = dst + j;
-        ex[o] = vx;  ey[o] = vy;  rho[o] = vr;  theta[o] = vt;
-        ex[o + a.m] = -vx;                                                // :141
-        ey[o + a.m] = vy;                                                 // :140
-        rho[o + a.m] = vr;                                                // :143
-        theta[o + a.m] = (T)3.141592653589793 - vt;                       // :144
-        const double dx1 = (double)vx - a.mux, dx2 = -(double)vx - a.mux;
-        const double dy = (double)vy - a.muy;
-        sq += (dx1 * dx1 + dx2 * dx2) + (dy * dy + dy * dy);
+    for (int j = tid * V; j < c; j += kBlock * V) {                               // the slot holds kTile entries: reads past c stay inside it
+        const vec_t vx = *reinterpret_cast<const vec_t*>(w_ex + src + j), vy = *reinterpret_cast<const vec_t*>(w_ey + src + j);
+        const vec_t vr = *reinterpret_cast<const vec_t*>(w_r + src + j), vt = *reinterpret_cast<const vec_t*>(w_th + src + j);
+        vec_t rr;
+#pragma unroll
+        for (int q = 0; q < V; ++q) {
+            rr[q] = vr[q] / (T)a.rmax;                                            // :142
+            if (j + q < c) {
+                const double dx1 = (double)vx[q] - a.mux, dx2 = -(double)vx[q] - a.mux;
+                const double dy = (double)vy[q] - a.muy;
+                sq += (dx1 * dx1 + dx2 * dx2) + (dy * dy + dy * dy);
+            }
+        }
+        *reinterpret_cast<vec_t*>(&s_v[0][j]) = vx; *reinterpret_cast<vec_t*>(&s_v[1][j]) = vy;
+        *reinterpret_cast<vec_t*>(&s_v[2][j]) = rr; *reinterpret_cast<vec_t*>(&s_v[3][j]) = vt;
     }
+    __syncthreads();
+    auto same = [](T v) { return v; };
+    stream_out<T>(ex + dst, s_v[0], c, tid, same);
+    stream_out<T>(ey + dst, s_v[1], c, tid, same);
+    stream_out<T>(rho + dst, s_v[2], c, tid, same);
+    stream_out<T>(theta + dst, s_v[3], c, tid, same);
+    stream_out<T>(ex + dst + a.m, s_v[0], c, tid, [](T v) { return -v; });                                   // :141
+    stream_out<T>(ey + dst + a.m, s_v[1], c, tid, same);                                                      // :140
+    stream_out<T>(rho + dst + a.m, s_v[2], c, tid, same);                                                     // :143
+    stream_out<T>(theta + dst + a.m, s_v[3], c, tid, [](T v) { return (T)3.141592653589793 - v; });          // :144
     for (int off = 32; off > 0; off >>= 1) sq += __shfl_down(sq, off);
     if (lane == 0) s_wsq[wave] = sq;
     __syncthreads();
@@ -711,9 +791,10 @@ __global__ __launch_bounds__(kBlock) void k_ft_place(const T* __restrict__ w_ex,
 }
 
 // ------------------------------------------------------------------------------------
-// full_trace, stage C of the FT_LOOKBACK route: survivors only.  The first half (written by the trace kernel) is read once; rho is
-// normalised in place (r ./ maximum(r), :142), the mirrored half [-ex; ey; rho; pi - theta] goes to offset m
-// (:139-144), and the squared deviations about the centroid are summed per chunk (two-pass sigma, :169-173).
+// full_trace, stage C of the FT_LOOKBACK route: survivors only.  The first half (written by the trace kernel) is read once
+// (16-byte loads: chunks start on multiples of kTile inside the slab); rho is normalised in place (r ./ maximum(r), :142),
+// the mirrored half [-ex; ey; rho; pi - theta] goes to offset m (:139-144) through LDS as aligned 16-byte stores
+// (stream_out), and the squared deviations about the centroid are summed per chunk (two-pass sigma, :169-173).
 // Grid: nb * chunks_per_bundle blocks of kTile entries; chunks beyond the bundle's m survivors leave at once.
 // ------------------------------------------------------------------------------------
 template <typename T>
@@ -721,30 +802,56 @@ __global__ __launch_bounds__(kBlock) void k_ft_mirror(int64_t rpb, int chunks_pe
                                                       const FtBundleAgg* __restrict__ agg,
                                                       T* __restrict__ ex, T* __restrict__ ey,
                                                       T* __restrict__ rho, T* __restrict__ theta,
-                                                      double* __restrict__ chunk_sq)
+                                                      double* __restrict__ chunk_sq, const int* __restrict__ ft_err)
 {
+    constexpr int V = 16 / (int)sizeof(T);
+    typedef T vec_t __attribute__((ext_vector_type(V)));
+    __shared__ __attribute__((aligned(16))) T s_v[4][kTile];
     __shared__ double s_wsq[kBlock / 64];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int b = blockIdx.x / chunks_per_bundle;
     const int chunk = blockIdx.x - b * chunks_per_bundle;
     const FtBundleAgg a = agg[b];
     const int64_t j0 = (int64_t)chunk * kTile;
-    if (j0 >= a.m) { if (tid == 0) chunk_sq[blockIdx.x] = 0.0; return; }
-    const int64_t o0 = (int64_t)b * 2 * rpb;
+    // a faulted look-back left counts that mean nothing: touch no output (k_ft_finalize reports it)
+    if (j0 >= a.m || a.m > rpb || *ft_err) { if (tid == 0) chunk_sq[blockIdx.x] = 0.0; return; }
+    const int c = (int)min((int64_t)kTile, a.m - j0);
+    const int64_t o0 = (int64_t)b * 2 * rpb + j0;                                 // 2 rpb and j0 are even, multiples of 4 for kTile
+    const bool al = ((reinterpret_cast<uintptr_t>(ex + o0) | reinterpret_cast<uintptr_t>(ey + o0) |
+                      reinterpret_cast<uintptr_t>(rho + o0) | reinterpret_cast<uintptr_t>(theta + o0)) & 15) == 0;
     double sq = 0.0;
-    for (int64_t j = j0 + tid; j < j0 + kTile && j < a.m; j += kBlock) {
-        const int64_t o = o0 + j;
-        const T vx = ex[o], vy = ey[o], vt = theta[o];
-        const T vr = rho[o] / (T)a.rmax;                                  // :142
-        rho[o] = vr;
-        ex[o + a.m] = -vx;                                                // :141
-        ey[o + a.m] = vy;                                                 // :140
-        rho[o + a.m] = vr;                                                // :143
-        theta[o + a.m] = (T)3.141592653589793 - vt;                       // :144
-        const double dx1 = (double)vx - a.mux, dx2 = -(double)vx - a.mux;
-        const double dy = (double)vy - a.muy;
-        sq += (dx1 * dx1 + dx2 * dx2) + (dy * dy + dy * dy);
+    for (int j = tid * V; j < c; j += kBlock * V) {
+        vec_t vx, vy, vr, vt;
+        if (al && j0 + j + V <= 2 * rpb) {                                       // whole vectors stay inside the slab
+            vx = *reinterpret_cast<const vec_t*>(ex + o0 + j); vy = *reinterpret_cast<const vec_t*>(ey + o0 + j);
+            vr = *reinterpret_cast<const vec_t*>(rho + o0 + j); vt = *reinterpret_cast<const vec_t*>(theta + o0 + j);
+        } else {
+#pragma unroll
+            for (int q = 0; q < V; ++q) {
+                const bool in = j + q < c;
+                vx[q] = in ? ex[o0 + j + q] : T(0); vy[q] = in ? ey[o0 + j + q] : T(0);
+                vr[q] = in ? rho[o0 + j + q] : T(0); vt[q] = in ? theta[o0 + j + q] : T(0);
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < V; ++q) {
+            vr[q] = vr[q] / (T)a.rmax;                                            // :142
+            if (j + q < c) {
+                const double dx1 = (double)vx[q] - a.mux, dx2 = -(double)vx[q] - a.mux;
+                const double dy = (double)vy[q] - a.muy;
+                sq += (dx1 * dx1 + dx2 * dx2) + (dy * dy + dy * dy);
+            }
+        }
+        *reinterpret_cast<vec_t*>(&s_v[0][j]) = vx; *reinterpret_cast<vec_t*>(&s_v[1][j]) = vy;
+        *reinterpret_cast<vec_t*>(&s_v[2][j]) = vr; *reinterpret_cast<vec_t*>(&s_v[3][j]) = vt;
     }
+    __syncthreads();
+    auto same = [](T v) { return v; };
+    stream_out<T>(rho + o0, s_v[2], c, tid, same);                                                            // rho in place
+    stream_out<T>(ex + o0 + a.m, s_v[0], c, tid, [](T v) { return -v; });                                    // :141
+    stream_out<T>(ey + o0 + a.m, s_v[1], c, tid, same);                                                       // :140
+    stream_out<T>(rho + o0 + a.m, s_v[2], c, tid, same);                                                      // :143
+    stream_out<T>(theta + o0 + a.m, s_v[3], c, tid, [](T v) { return (T)3.141592653589793 - v; });           // :144
     for (int off = 32; off > 0; off >>= 1) sq += __shfl_down(sq, off);
     if (lane == 0) s_wsq[wave] = sq;
     __syncthreads();
@@ -756,9 +863,11 @@ __global__ __launch_bounds__(kBlock) void k_ft_mirror(int64_t rpb, int chunks_pe
 }
 
 // full_trace, stage D: sigma per bundle (PupilSampling.jl:169-173).
+// ft_err (look-back route, else null): a faulted look-back leaves count = -1, rms = NaN — what a device-pointer caller sees.
 __global__ __launch_bounds__(kBlock) void k_ft_finalize(const double* __restrict__ tile_sq, int tiles_per_bundle,
                                                         const FtBundleAgg* __restrict__ agg,
-                                                        int64_t* __restrict__ count, double* __restrict__ rms)
+                                                        int64_t* __restrict__ count, double* __restrict__ rms,
+                                                        const int* __restrict__ ft_err)
 {
     __shared__ double s_r[kBlock];
     const int b = blockIdx.x, tid = threadIdx.x;
@@ -772,8 +881,9 @@ __global__ __launch_bounds__(kBlock) void k_ft_finalize(const double* __restrict
     }
     if (tid == 0) {
         const int64_t m = agg[b].m;
-        count[b] = 2 * m;
-        rms[b] = m ? sqrt(s_r[0] / (double)(2 * m)) : __builtin_nan("");
+        const bool fault = ft_err && *ft_err;
+        count[b] = fault ? -1 : 2 * m;
+        rms[b] = (m && !fault) ? sqrt(s_r[0] / (double)(2 * m)) : __builtin_nan("");
     }
 }
 
@@ -1005,7 +1115,8 @@ __global__ __launch_bounds__(64) void k_aim(int n, const AimIn* __restrict__ in,
 //     y_XP = ray.y[end] + tan(ray.u[end]) * XP_t                                 (:131; transfer :107-115)
 //     eps  = ray.y[end] + tan(ray.u[end]) * (BFD - sag(ray)),  sag(ray) = ray.z[end-1] - ray.z[end]   (:130,132; :91)
 // The last ray (y = y_m) is the real marginal ray itself: the reference takes it from trace_marginal_ray (:127-128)
-// instead of tracing it again — the same trace of the same launch data, so the same numbers.
+// instead of tracing it again — the same trace of the same launch data, so the same numbers — and measures ITS sag from
+// the paraxial vertex (see below).
 // ------------------------------------------------------------------------------------
 __device__ __forceinline__ double dd_range_elem(double a, double b, int n, int i);   // below (pupil axes)
 
@@ -1033,7 +1144,12 @@ __global__ __launch_bounds__(kBlock) void k_fan(int n, int k_rays, int descendin
     const double tl = t_last[f.system];
     const MerEnd e = mer_trace_to(F, cF, S, ncoef, f.layout_mode, tl, y0, 0.0, -1);
     const double tu = ::tan(e.U_last);
-    const double sag = e.s_last - tl;                                             // ray.z[end-1] - ray.z[end] = -ts[end]
+    // sag(ray) = ray.z[end-1] - ray.z[end] = -ts[end] = s_last - t[end] for a traced ray (:130,132; RayTracing.jl:91); the
+    // marginal ray (y = y_m) takes sag(real, paraxial) = real.z[end-1] - paraxial.z[end-1] = s_last, no thickness (:125-127,
+    // RayTracing.jl:93-95).  The two agree when the prescription ends in image space (t[end] = 0), as the reference's do.
+    // The caustic set (descending) re-traces the marginal ray like every other (ext/MakieExtension.jl:369-371).
+    const bool marginal = !descending && i == k_rays - 1;
+    const double sag = marginal ? e.s_last : e.s_last - tl;
     y_XP[g] = e.y_last + tu * f.XP_t;
     eps[g] = e.y_last + tu * (f.BFD - sag);
 }
@@ -1357,6 +1473,27 @@ __global__ __launch_bounds__(kBlock) void k_build_bundles(int na, int k_rays, in
     d.yoff = (int64_t)g * (k_rays + k2); d.xoff = d.yoff + k_rays;
     bd[g] = d;
     ends[4 * (int64_t)g + 0] = o.y1; ends[4 * (int64_t)g + 1] = o.y2; ends[4 * (int64_t)g + 2] = 0.0; ends[4 * (int64_t)g + 3] = o.y_EP;
+}
+
+// ------------------------------------------------------------------------------------
+// wavegrad(eps, lambda) = (eps.x nu / lambda, eps.y nu / lambda)  (src/PupilSampling.jl:165-167) for device-resident
+// full_trace results: bundle b's count[b] valid entries of its slab [cap].  Out of place, like the reference's map.
+// Grid: nb * chunks blocks of kTile entries.
+// ------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(kBlock) void k_wavegrad(int64_t cap, int chunks, const int64_t* __restrict__ count,
+                                                     const double* __restrict__ nu, double lambda,
+                                                     const T* __restrict__ ex, const T* __restrict__ ey,
+                                                     T* __restrict__ gx, T* __restrict__ gy)
+{
+    const int b = blockIdx.x / chunks, chunk = blockIdx.x - b * chunks;
+    const int64_t n = count[b] < cap ? count[b] : cap;
+    const T nub = (T)nu[b], lam = (T)lambda;
+    const int64_t o = (int64_t)b * cap;
+    for (int64_t j = (int64_t)chunk * kTile + threadIdx.x; j < n && j < (int64_t)(chunk + 1) * kTile; j += kBlock) {
+        gx[o + j] = (ex[o + j] * nub) / lam;                    // getfield(eps, f) * eps.nu / lambda: product, then quotient,
+        gy[o + j] = (ey[o + j] * nub) / lam;                    // one IEEE operation each as in the reference's broadcast
+    }
 }
 
 // ------------------------------------------------------------------------------------

@@ -168,6 +168,26 @@ class HipEngine:
                         "theta": th[b, :c].copy(), "rms": float(rms[b]), "count": c})
         return out
 
+    # ---- wavegrad(eps, lambda): PupilSampling.jl:165-167 ------------------------------------
+    def wavegrad(self, ex, ey, count, nu, lam: float, gx=None, gy=None):
+        """`ort_wavegrad_f64`: (ex nu / lambda, ey nu / lambda) of nb full_trace slabs [nb][cap].  numpy arrays go through
+        host buffers; torch CUDA tensors (ex, ey, count, nu and the outputs) stay on the device — nothing is copied."""
+        on_dev = hasattr(ex, "data_ptr")
+        nb, cap = ex.shape
+        if on_dev:
+            import torch
+            gx = torch.empty_like(ex) if gx is None else gx
+            gy = torch.empty_like(ey) if gy is None else gy
+            flags = self.base_flags | _capi.ORT_DEVICE_PTRS
+        else:
+            ex, ey = f64(ex), f64(ey)
+            count = np.ascontiguousarray(count, dtype=np.int64); nu = np.ascontiguousarray(np.broadcast_to(f64(nu), (nb,)))
+            gx = np.empty_like(ex); gy = np.empty_like(ey)
+            flags = self.base_flags
+        check(self.ctx.lib.ort_wavegrad_f64(self.ctx.h, int(nb), int(cap), ptr(count), ptr(nu), float(lam), ptr(ex), ptr(ey),
+                                            ptr(gx), ptr(gy), flags))
+        return gx, gy
+
     # ---- meridional: raytrace(surfaces, y, U, RealRay)  RayTracing.jl:145-169 -----------
     def meridional(self, pres: Prescription, y, U, layout_mode: bool = False, isys: int = 0):
         y, U = (np.atleast_1d(f64(a)) for a in (y, U))

@@ -256,7 +256,8 @@ class OracleEngine:
         """The ray loop of TSA (src/SeidelAberrations.jl:121-133): y = range(y_m / k, y_m, k), U = 0,
         raytrace(surfaces, y, 0.0, RealRay) (orc_trace_meridional), then
         y_XP = ray.y[end] + tan(ray.u[end]) XP_t (:131) and eps = ray.y[end] + tan(ray.u[end]) (BFD - sag(ray)),
-        sag(ray) = ray.z[end-1] - ray.z[end] = -ts[end] (:130,132; RayTracing.jl:91,105-115)."""
+        sag(ray) = ray.z[end-1] - ray.z[end] = -ts[end] (:130,132; RayTracing.jl:91,105-115); the last ray is the real
+        marginal ray, whose sag is taken against the paraxial vertex (:125-127)."""
         import math
         n = len(specs)
         y_xp = np.empty((n, k_rays)); eps = np.empty((n, k_rays))
@@ -264,10 +265,15 @@ class OracleEngine:
             ym = float(sp["y_marg"])
             ys = linrange(ym, ym / k_rays, k_rays) if descending else linrange(ym / k_rays, ym, k_rays)
             yo, Uo, ts = self.meridional(pres, ys, np.zeros(k_rays), bool(sp.get("layout_mode", 0)), int(sp.get("system", 0)))
+            t_last = float(np.atleast_2d(pres.t)[int(sp.get("system", 0))][-1])
             for i in range(k_rays):
                 tu = math.tan(Uo[-1, i])
                 y_xp[q, i] = yo[-1, i] + tu * sp["XP_t"]
-                eps[q, i] = yo[-1, i] + tu * (sp["BFD"] - (-ts[-1, i]))
+                sag = -ts[-1, i]                                  # sag(ray) = ray.z[end-1] - ray.z[end]  (RayTracing.jl:91)
+                if not descending and i == k_rays - 1:            # TSA's marginal ray: sag(real, paraxial) = real.z[end-1] -
+                    sag = sag + t_last                            # paraxial.z[end-1] = s_last, no last thickness (:93-95, :125-127);
+                                                                  # the caustic set re-traces it like the others (MakieExtension.jl:369-371)
+                eps[q, i] = yo[-1, i] + tu * (sp["BFD"] - sag)
         return y_xp, eps
 
     def paraxial(self, tau, phi, y, w, a=None, clip: bool = False):

@@ -131,3 +131,27 @@ def test_two_rank_shard_and_allgather():
         p.join(timeout=180)
         assert p.exitcode == 0
     assert q.get(timeout=5) == (True, True, True)
+
+
+def test_bench_launches_its_own_ranks():
+    """`python bench.py --gpus 2` with no launcher and no WORLD_SIZE — the way the driver calls `--gpus 1` — starts its
+    two ranks itself (a child `torch.distributed.run` on 127.0.0.1, never an exec), relays rank 0's JSON line and exits
+    with the children's return code.  The ranks here only rendezvous over gloo on the CPU (--selftest-ranks): the launch
+    path is what is under test, and it needs no GPU."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--selftest-ranks"],
+                       capture_output=True, text=True, timeout=300, env=env)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d == {"selftest": True, "world": 2, "rank_sum": 3, "spawned": True}
+    # a failing rank's return code comes back through the launcher: --gpus 2 under a launcher that started ONE rank
+    env1 = dict(env, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0")
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--selftest-ranks"],
+                       capture_output=True, text=True, timeout=120, env=env1)
+    assert r.returncode != 0 and "launcher started 1 rank" in (r.stderr + r.stdout)

@@ -125,3 +125,19 @@ def test_paraxial_primitives_and_raypoints(oracle_engine):
     lens = ort.Lens(cm.cooke())
     phi = lens.M[:, 1].copy()
     assert rc.scale(lens) is lens and np.allclose(lens.M[:, 1], phi * 1e-3)
+
+
+def test_wavegrad_is_the_references_two_operations(oracle_engine):
+    """wavegrad(eps, lambda) = map(f -> getfield(eps, f) * eps.nu / lambda, (:x, :y)) (src/PupilSampling.jl:165-167): the
+    transverse errors in waves, product first, then quotient; default lambda = 587.5618e-6 (SeidelAberrations.jl:2)."""
+    import numpy as np
+    import opticalraytracing_jl_amd as ort
+    from tests import common as cm
+    s = ort.solve(cm.cooke(), cm.COOKE_A, cm.COOKE_H, engine=oracle_engine)
+    e = ort.full_trace(s, 1.0, engine=oracle_engine)
+    wx, wy = ort.wavegrad(e)
+    assert np.array_equal(wx, (e.x * e.nu) / 587.5618e-6) and np.array_equal(wy, (e.y * e.nu) / 587.5618e-6)
+    wx2, _ = ort.wavegrad(e, 500e-6)
+    assert np.allclose(wx2 * 500e-6, wx * 587.5618e-6, rtol=1e-15)
+    # a 1 um transverse error at n'u' = -0.2 is 0.34 waves at the d line
+    assert abs(1e-3 * -0.2 / 587.5618e-6 + 0.340390) < 1e-6
