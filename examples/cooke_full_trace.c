@@ -8,11 +8,17 @@
 #include <math.h>
 #include <stdio.h>
 #include <stdlib.h>
+#include <string.h>
+#include <time.h>
 #include "ort.h"
 
 #define ROWS 8
 
-int main(void)
+static int cmp_double(const void *a, const void *b) { return (*(const double *)a > *(const double *)b) - (*(const double *)a < *(const double *)b); }
+
+/* `cooke_full_trace --time [H]`: wall time of the reference's own call, full_trace(system, H, 64) (test/runtests.jl:364-372 shape:
+ * one system, one field, 64 x 32 half pupil), through the C ABI — error vectors back in host memory — 300 times. */
+int main(int argc, char **argv)
 {
     /* surfaces = [R t n] (test/runtests.jl:19-29), clear semi-diameters a (:31-33), image height h' (:35) */
     const double R[ROWS] = { INFINITY, 37.40, -341.48, -42.65, 36.40, INFINITY, 204.52, -37.05 };
@@ -36,6 +42,26 @@ int main(void)
         for (int64_t i = 0; i < count[b]; ++i) { const double dx = ex[b * CAP + i] - sx, dy = ey[b * CAP + i] - sy; q += dx * dx + dy * dy; }
         printf("H = %.1f  rays = %lld  RMS = %.9f  (recomputed from the vectors: %.9f)\n", fields[b], (long long)count[b], rms[b],
                sqrt(q / (double)count[b]));
+    }
+    if (argc > 1 && strcmp(argv[1], "--time") == 0) {
+        const double H = argc > 2 ? atof(argv[2]) : 1.0;
+        enum { REPS = 300 };
+        static double us[REPS];
+        for (int full = 1; full >= 0; --full) {
+            for (int i = -20; i < REPS; ++i) {
+                struct timespec t0, t1;
+                clock_gettime(CLOCK_MONOTONIC, &t0);
+                rc = full ? ort_full_trace_batch_f64(ctx, 1, ROWS, R, t, n, a, &hprime, 1, &H, K, &fo, ex, ey, rho, theta, count, rms, 0)
+                          : ort_spot_batch_f64(ctx, 1, ROWS, R, t, n, a, &hprime, 1, &H, K, &fo, count, rms, 0);
+                clock_gettime(CLOCK_MONOTONIC, &t1);
+                if (rc != ORT_OK) { fprintf(stderr, "timed call: %s\n", ort_last_error()); return 3; }
+                if (i >= 0) us[i] = (t1.tv_sec - t0.tv_sec) * 1e6 + (t1.tv_nsec - t0.tv_nsec) * 1e-3;
+            }
+            qsort(us, REPS, sizeof(double), cmp_double);
+            printf("{\"call\": \"%s\", \"H\": %.2f, \"rays\": %lld, \"rms\": %.9f, \"wall_us_median\": %.1f, \"wall_us_min\": %.1f, \"wall_us_p90\": %.1f}\n",
+                   full ? "ort_full_trace_batch_f64 (vectors back)" : "ort_spot_batch_f64 (count, RMS)", H, (long long)count[0], rms[0],
+                   us[REPS / 2], us[0], us[REPS * 9 / 10]);
+        }
     }
     /* the reference's own known answers for this prescription: f = 101.181, stop == 5 (test/runtests.jl:53-60) */
     const int ok = fabs(fo.f - 101.181) < 1e-3 && fo.stop == 5 && count[0] > 0 && count[1] > 0;

@@ -60,6 +60,10 @@ extern "C" {
                                        the geometry (hit beyond a sphere's equator, direction refracted backward, polynomial
                                        row outside its conic) retraces with the reference sequence.  Default: the op-for-op
                                        IEEE sequence of the reference loop, bit-identical to a non-fused CPU evaluation */
+#define ORT_NO_SMALL_PATH (1u << 8) /* testing aid: small problems (<= 256 (system, field) pairs; full_trace bundles of <= 32 tiles)
+                                       normally run their setup and their finish as ONE launch each (k_small_prepare,
+                                       k_ft_small_finish); this takes the general multi-launch route instead — same device
+                                       functions, bit-identical results (tests/test_gpu_parity.py) */
 /* bit 6 reserved (was ORT_NO_LDS, the scalar-load variant of the surface table: measured, not faster, dropped) */
 #define ORT_FT_LOOKBACK   (1u << 7) /* full_trace: the trace kernel writes the survivors' first half at its final place
                                        (decoupled look-back over the bundle's tiles) instead of staging compacted tiles in

@@ -24,6 +24,7 @@ ORT_LAYOUT_INPUT = 1 << 3
 ORT_CLIP = 1 << 4
 ORT_FAST_MATH = 1 << 5
 ORT_FT_LOOKBACK = 1 << 7
+ORT_NO_SMALL_PATH = 1 << 8
 ORT_STATUS_STOPPED = 1 << 16
 ORT_STATUS_VIGNETTED = 1 << 17
 ORT_MAX_ROWS = 64

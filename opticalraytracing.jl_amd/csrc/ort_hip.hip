@@ -64,6 +64,10 @@ struct Scratch {
     void release() { if (p) { hipError_t e = hipFree(p); (void)e; } p = nullptr; cap = 0; }
 };
 
+constexpr int kSmallTiles = 32;     // full_trace bundles of at most this many 512-ray tiles finish in one launch (k_ft_small_finish)
+constexpr int kSmallPairs = 256;    // spot pipelines of at most this many (system, field) pairs prepare in one launch (k_small_prepare)
+constexpr size_t kPackedVectorBytes = 32u << 20;   // host callers: error vectors up to this size come back in ONE copy
+
 enum { SL_IN0 = 0, SL_IN1, SL_IN2, SL_IN3, SL_OUT0, SL_OUT1, SL_OUT2, SL_OUT3, SL_OUT4,
        SL_BUNDLES, SL_AXES, SL_WEX, SL_WEY, SL_WR, SL_WTH, SL_TCNT, SL_TSX, SL_TSY, SL_TRM,
        SL_TOFF, SL_TSQ, SL_AGG, SL_RES0, SL_RES1, SL_TAB0, SL_TAB1, SL_TAB2, SL_TAB3,
@@ -434,7 +438,7 @@ int run_full_trace(ort_ctx* ctx, TraceParams<T>& p, int nb, T* ex, T* ey, T* rho
         }
         return ORT_OK;
     }
-    double* chunk_sq; FtBundleAgg* agg; int* ft_err = nullptr;
+    double* chunk_sq; FtBundleAgg* agg; int* ft_err = nullptr; bool fused_finish = false;
     rc = dev_out<double>(ctx, SL_TSQ, (size_t)tiles, &chunk_sq); if (rc) return rc;
     rc = dev_out<FtBundleAgg>(ctx, SL_AGG, (size_t)nb, &agg); if (rc) return rc;
     T *dex = ex, *dey = ey, *drho = rho, *dth = theta;
@@ -456,12 +460,22 @@ int run_full_trace(ort_ctx* ctx, TraceParams<T>& p, int nb, T* ex, T* ey, T* rho
         rc = dev_out<int64_t>(ctx, SL_TOFF, (size_t)tiles, &tile_off); if (rc) return rc;
         p.out_ex = wex; p.out_ey = wey; p.out_r = wr; p.out_th = wth;
         rc = launch_trace<T, true, false, false, FT_FULL>(ctx, p, tiles, flags); if (rc) return rc;
-        hipLaunchKernelGGL(k_ft_scan, dim3((unsigned)nb), dim3(kBlock), 0, ctx->stream,
-                           p.tile_cnt, p.tile_sx, p.tile_sy, p.tile_rmax, p.tiles_per_bundle, tile_off, agg);
-        HIP_TRY(hipGetLastError());
-        hipLaunchKernelGGL((k_ft_place<T>), dim3((unsigned)tiles), dim3(kBlock), 0, ctx->stream,
-                           wex, wey, wr, wth, rpb, p.tiles_per_bundle, p.tile_cnt, tile_off, agg, dex, dey, drho, dth, chunk_sq);
-        HIP_TRY(hipGetLastError());
+        if (p.tiles_per_bundle <= kSmallTiles && !(flags & ORT_NO_SMALL_PATH)) {
+            // bundles of a few tiles (the reference's own call: 4): offsets, placement and sigma by one workgroup per bundle
+            // in ONE launch, through the same bodies (k_ft_small_finish)
+            hipLaunchKernelGGL((k_ft_small_finish<T>), dim3((unsigned)nb), dim3(kBlock * kFinishGroups), 0, ctx->stream,
+                               wex, wey, wr, wth, rpb, p.tiles_per_bundle, p.tile_cnt, p.tile_sx, p.tile_sy, p.tile_rmax, tile_off, agg,
+                               dex, dey, drho, dth, chunk_sq, dcount, drms);
+            HIP_TRY(hipGetLastError());
+            fused_finish = true;
+        } else {
+            hipLaunchKernelGGL(k_ft_scan, dim3((unsigned)nb), dim3(kBlock), 0, ctx->stream,
+                               p.tile_cnt, p.tile_sx, p.tile_sy, p.tile_rmax, p.tiles_per_bundle, tile_off, agg);
+            HIP_TRY(hipGetLastError());
+            hipLaunchKernelGGL((k_ft_place<T>), dim3((unsigned)tiles), dim3(kBlock), 0, ctx->stream,
+                               wex, wey, wr, wth, rpb, p.tiles_per_bundle, p.tile_cnt, tile_off, agg, dex, dey, drho, dth, chunk_sq);
+            HIP_TRY(hipGetLastError());
+        }
     } else {
         // ORT_FT_LOOKBACK: the trace kernel writes the first half itself.  Look-back state: one 8-byte word per tile +
         // the ticket counter; zero-filled when (re)allocated only — the epoch tells the words of this launch from
@@ -494,9 +508,11 @@ int run_full_trace(ort_ctx* ctx, TraceParams<T>& p, int nb, T* ex, T* ey, T* rho
                            rpb, p.tiles_per_bundle, agg, dex, dey, drho, dth, chunk_sq, (const int*)ft_err);
         HIP_TRY(hipGetLastError());
     }
-    hipLaunchKernelGGL(k_ft_finalize, dim3((unsigned)nb), dim3(kBlock), 0, ctx->stream,
-                       chunk_sq, p.tiles_per_bundle, agg, dcount, drms, (const int*)ft_err);
-    HIP_TRY(hipGetLastError());
+    if (!fused_finish) {
+        hipLaunchKernelGGL(k_ft_finalize, dim3((unsigned)nb), dim3(kBlock), 0, ctx->stream,
+                           chunk_sq, p.tiles_per_bundle, agg, dcount, drms, (const int*)ft_err);
+        HIP_TRY(hipGetLastError());
+    }
     if (!devp) {
         int herr = 0;
         rc = from_device<int64_t>(ctx, count, dcount, (size_t)nb); if (rc) return rc;
@@ -578,13 +594,19 @@ int spot_batch_impl(ort_ctx* ctx, int nsys, int rows, const double* R, const dou
     const double *dR = R, *dt = t, *dn = n, *dK = K, *dcoef = coef, *da = a, *dh = hprime, *dfields = fields;
     const size_t n_a = (size_t)nsys * (rows - 1), n_c = (size_t)nsys * rows * (size_t)ncoef;
     const size_t in_cnt = 3 * nr + (K ? nr : 0) + n_c + n_a + (size_t)nsys + (size_t)nfields;   // doubles, packed: one H2D copy
-    // packed results of the statistics-only host call: [count | rms | first-order | flag], one D2H copy
-    const size_t o_cnt = 0, o_rms = o_cnt + (size_t)na * sizeof(int64_t), o_fo = o_rms + (size_t)na * sizeof(double),
-                 o_flag = o_fo + (size_t)nsys * sizeof(FirstOrderOut), out_bytes = o_flag + 8;
+    // One device block [inputs | flag | results]: the H2D copy brings the inputs and a zeroed convergence flag, ONE D2H copy
+    // takes [flag | count | rms | first-order | error vectors (when asked for and small enough)] back through pinned memory
+    const size_t cap = (size_t)2 * (size_t)rpb;
+    const size_t vec_bytes = ex ? 4 * (size_t)na * cap * sizeof(T) : 0;
+    const bool packed_vec = ex && !devp && vec_bytes <= kPackedVectorBytes;
+    const size_t in_bytes = in_cnt * sizeof(double);
+    const size_t o_flag = in_bytes, o_cnt = o_flag + 16, o_rms = o_cnt + (size_t)na * sizeof(int64_t),
+                 o_fo = o_rms + (size_t)na * sizeof(double), o_vec = (o_fo + (size_t)nsys * sizeof(FirstOrderOut) + 255) & ~(size_t)255,
+                 pack_bytes = o_vec + (packed_vec ? vec_bytes : 0);
     unsigned char* hpin = nullptr; unsigned char* dpack = nullptr;
     if (!devp) {
-        rc = ctx->pinned(in_cnt * sizeof(double) + out_bytes, &hpin); if (rc) return rc;   // [inputs | results]: no reuse, no mid-call sync
-        rc = dev_out<unsigned char>(ctx, SL_SB_PACK, in_cnt * sizeof(double) + out_bytes, &dpack); if (rc) return rc;
+        rc = ctx->pinned(pack_bytes, &hpin); if (rc) return rc;      // no reuse inside the call, no mid-call sync
+        rc = dev_out<unsigned char>(ctx, SL_SB_PACK, pack_bytes, &dpack); if (rc) return rc;
         double* hp = reinterpret_cast<double*>(hpin); double* dp = reinterpret_cast<double*>(dpack);
         size_t o = 0;
         auto put = [&](const double* src, size_t cnt, const double** dev) { memcpy(hp + o, src, cnt * sizeof(double)); *dev = dp + o; o += cnt; };
@@ -592,31 +614,23 @@ int spot_batch_impl(ort_ctx* ctx, int nsys, int rows, const double* R, const dou
         if (K) put(K, nr, &dK);
         if (ncoef > 0) put(coef, n_c, &dcoef);
         put(a, n_a, &da); put(hprime, (size_t)nsys, &dh); put(fields, (size_t)nfields, &dfields);
-        HIP_TRY(hipMemcpyAsync(dpack, hpin, in_cnt * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+        memset(hpin + o_flag, 0, 16);                                // the flag travels with the inputs: no fill launch
+        HIP_TRY(hipMemcpyAsync(dpack, hpin, in_bytes + 16, hipMemcpyHostToDevice, ctx->stream));
     }
-    unsigned char* hres = hpin ? hpin + in_cnt * sizeof(double) : nullptr;   // results land behind the inputs
-    unsigned char* dres = dpack ? dpack + in_cnt * sizeof(double) : nullptr;
-    FirstOrderOut* d_fo; SurfRec<T>* d_rec; MerSurf *d_mf, *d_mr; double *d_tlf, *d_tlr, *d_ends; T* d_axes;
-    AimIn* d_ain; AimOut* d_aout; DevBundle<T>* d_bd; int* d_flag; T* d_poly = nullptr; double* d_crev = nullptr;
-    if (dres) d_fo = reinterpret_cast<FirstOrderOut*>(dres + o_fo);
+    FirstOrderOut* d_fo; SurfRec<T>* d_rec; DevBundle<T>* d_bd; T* d_axes; int* d_flag; T* d_poly = nullptr;
+    if (dpack) d_fo = reinterpret_cast<FirstOrderOut*>(dpack + o_fo);
     else { rc = dev_out<FirstOrderOut>(ctx, SL_SB_FO, (size_t)nsys, &d_fo); if (rc) return rc; }
     rc = dev_out<SurfRec<T>>(ctx, SL_SB_REC, nr, &d_rec); if (rc) return rc;
-    if (ncoef > 0) {
-        rc = dev_out<T>(ctx, SL_SB_CEXT, nr * kPolyRec, &d_poly); if (rc) return rc;
-        rc = dev_out<double>(ctx, SL_SB_CREV, n_c, &d_crev); if (rc) return rc;
-    }
-    rc = dev_out<MerSurf>(ctx, SL_SB_MF, (size_t)nsys * (rows - 1), &d_mf); if (rc) return rc;
-    rc = dev_out<MerSurf>(ctx, SL_SB_MR, (size_t)nsys * (rows - 1), &d_mr); if (rc) return rc;
-    rc = dev_out<double>(ctx, SL_SB_TLF, (size_t)nsys, &d_tlf); if (rc) return rc;
-    rc = dev_out<double>(ctx, SL_SB_TLR, (size_t)nsys, &d_tlr); if (rc) return rc;
-    rc = dev_out<AimIn>(ctx, SL_SB_AIN, (size_t)na, &d_ain); if (rc) return rc;
-    rc = dev_out<AimOut>(ctx, SL_SB_AOUT, (size_t)na, &d_aout); if (rc) return rc;
+    if (ncoef > 0) { rc = dev_out<T>(ctx, SL_SB_CEXT, nr * kPolyRec, &d_poly); if (rc) return rc; }
     rc = dev_out<DevBundle<T>>(ctx, SL_BUNDLES, (size_t)na, &d_bd); if (rc) return rc;
     ctx->bundle_cache.clear();                                  // SL_BUNDLES no longer mirrors a host array
-    rc = dev_out<double>(ctx, SL_SB_ENDS, (size_t)na * 4, &d_ends); if (rc) return rc;
     rc = dev_out<T>(ctx, SL_AXES, (size_t)na * (k_rays + k2), &d_axes); if (rc) return rc;
-    if (dres) d_flag = reinterpret_cast<int*>(dres + o_flag);
-    else { rc = dev_out<int>(ctx, SL_SB_FLAG, 1, &d_flag); if (rc) return rc; }
+    hipStream_t st = ctx->stream;
+    if (dpack) d_flag = reinterpret_cast<int*>(dpack + o_flag);
+    else {
+        rc = dev_out<int>(ctx, SL_SB_FLAG, 1, &d_flag); if (rc) return rc;
+        HIP_TRY(hipMemsetAsync(d_flag, 0, sizeof(int), st));
+    }
     TraceParams<T> p;
     memset(&p, 0, sizeof p);
     p.recs = d_rec; p.polys = d_poly; p.S = S; p.bundles = d_bd; p.axes = d_axes;
@@ -630,45 +644,69 @@ int spot_batch_impl(ort_ctx* ctx, int nsys, int rows, const double* R, const dou
         if (general) p.arms = ARMS_GENERAL;
     }
     p.ny = k_rays; p.nx = k2; p.rpb = rpb; p.tiles_per_bundle = (int)((rpb + kTile - 1) / kTile);
-    hipStream_t st = ctx->stream;
     auto nblk = [](int64_t n, int b) { return dim3((unsigned)((n + b - 1) / b)); };
-    HIP_TRY(hipMemsetAsync(d_flag, 0, sizeof(int), st));
+    const double* coefp = ncoef > 0 ? dcoef : (const double*)nullptr;
     // solve (RayTracing.jl:302-323) -> tables -> aiming requests -> aiming (:223-296) -> bundles + axis end
     // points (PupilSampling.jl:94-122) -> axes -> trace + stop filter + tile moments -> per-bundle RMS
-    hipLaunchKernelGGL(k_first_order, nblk(nsys, 64), dim3(64), 0, st, nsys, rows, dR, dt, dn, da, (const double*)nullptr, dh,
-                       587.5618e-6, d_fo, (double*)nullptr, (double*)nullptr);
-    hipLaunchKernelGGL((k_build_tables<T>), nblk((int64_t)nr, kBlock), dim3(kBlock), 0, st, nsys, rows, dR, dt, dn, dK,
-                       ncoef > 0 ? dcoef : (const double*)nullptr, ncoef, d_fo, d_rec, d_poly, d_mf, d_mr, d_crev, d_tlf, d_tlr);
-    hipLaunchKernelGGL(k_build_aim, nblk(na, kBlock), dim3(kBlock), 0, st, nsys, nfields, rows, d_fo, da, dfields, layout ? 1 : 0, d_ain);
-    hipLaunchKernelGGL(k_aim, nblk((int64_t)na * 4, 64), dim3(64), 0, st, na, d_ain, d_mf, ncoef > 0 ? dcoef : (const double*)nullptr, d_tlf,
-                       d_mr, (const double*)d_crev, d_tlr, rows - 1, ncoef, d_aout);
-    hipLaunchKernelGGL((k_build_bundles<T>), nblk(na, kBlock), dim3(kBlock), 0, st, na, k_rays, k2, d_ain, d_aout, d_bd, d_ends, d_flag);
-    hipLaunchKernelGGL((k_make_axes<T>), nblk((int64_t)na * (k_rays + k2), kBlock), dim3(kBlock), 0, st, na, k_rays, k2, d_ends, d_axes);
+    if (na <= kSmallPairs && !(flags & ORT_NO_SMALL_PATH)) {
+        // a few pairs: all of it in ONE launch, one wave per pair (k_small_prepare; the same device functions)
+        hipLaunchKernelGGL((k_small_prepare<T>), dim3((unsigned)na), dim3(64), 0, st, nsys, nfields, rows, dR, dt, dn, dK, coefp, ncoef,
+                           da, dh, dfields, k_rays, k2, layout ? 1 : 0, 587.5618e-6, d_fo, d_rec, d_poly, d_bd, d_axes, d_flag);
+    } else {
+        MerSurf *d_mf, *d_mr; double *d_tlf, *d_tlr, *d_ends, *d_crev = nullptr; AimIn* d_ain; AimOut* d_aout;
+        if (ncoef > 0) { rc = dev_out<double>(ctx, SL_SB_CREV, n_c, &d_crev); if (rc) return rc; }
+        rc = dev_out<MerSurf>(ctx, SL_SB_MF, (size_t)nsys * (rows - 1), &d_mf); if (rc) return rc;
+        rc = dev_out<MerSurf>(ctx, SL_SB_MR, (size_t)nsys * (rows - 1), &d_mr); if (rc) return rc;
+        rc = dev_out<double>(ctx, SL_SB_TLF, (size_t)nsys, &d_tlf); if (rc) return rc;
+        rc = dev_out<double>(ctx, SL_SB_TLR, (size_t)nsys, &d_tlr); if (rc) return rc;
+        rc = dev_out<AimIn>(ctx, SL_SB_AIN, (size_t)na, &d_ain); if (rc) return rc;
+        rc = dev_out<AimOut>(ctx, SL_SB_AOUT, (size_t)na, &d_aout); if (rc) return rc;
+        rc = dev_out<double>(ctx, SL_SB_ENDS, (size_t)na * 4, &d_ends); if (rc) return rc;
+        hipLaunchKernelGGL(k_first_order, nblk(nsys, 64), dim3(64), 0, st, nsys, rows, dR, dt, dn, da, (const double*)nullptr, dh,
+                           587.5618e-6, d_fo, (double*)nullptr, (double*)nullptr);
+        hipLaunchKernelGGL((k_build_tables<T>), nblk((int64_t)nr, kBlock), dim3(kBlock), 0, st, nsys, rows, dR, dt, dn, dK,
+                           coefp, ncoef, d_fo, d_rec, d_poly, d_mf, d_mr, d_crev, d_tlf, d_tlr);
+        hipLaunchKernelGGL(k_build_aim, nblk(na, kBlock), dim3(kBlock), 0, st, nsys, nfields, rows, d_fo, da, dfields, layout ? 1 : 0, d_ain);
+        hipLaunchKernelGGL(k_aim, nblk((int64_t)na * 4, 64), dim3(64), 0, st, na, d_ain, d_mf, coefp, d_tlf,
+                           d_mr, (const double*)d_crev, d_tlr, rows - 1, ncoef, d_aout);
+        hipLaunchKernelGGL((k_build_bundles<T>), nblk(na, kBlock), dim3(kBlock), 0, st, na, k_rays, k2, d_ain, d_aout, d_bd, d_ends, d_flag);
+        hipLaunchKernelGGL((k_make_axes<T>), nblk((int64_t)na * (k_rays + k2), kBlock), dim3(kBlock), 0, st, na, k_rays, k2, d_ends, d_axes);
+    }
     HIP_TRY(hipGetLastError());
     if (devp) {
         rc = run_full_trace<T>(ctx, p, na, ex, ey, rho, theta, count, rms, flags); if (rc) return rc;
         if (fo_out) HIP_TRY(hipMemcpyAsync(fo_out, d_fo, (size_t)nsys * sizeof(FirstOrderOut), hipMemcpyDeviceToDevice, st));
         return ORT_OK;       // asynchronous; a failed aiming shows as NaN RMS of that bundle
     }
-    if (!ex) {
-        // statistics only: (count, rms) land in the packed result block on the device; ONE copy brings
-        // them, the first-order structs and the convergence flag back through the pinned buffer
-        rc = run_full_trace<T>(ctx, p, na, (T*)nullptr, (T*)nullptr, (T*)nullptr, (T*)nullptr,
-                               reinterpret_cast<int64_t*>(dres + o_cnt), reinterpret_cast<double*>(dres + o_rms),
-                               flags | ORT_DEVICE_PTRS);
+    int64_t* d_cnt = reinterpret_cast<int64_t*>(dpack + o_cnt); double* d_rms = reinterpret_cast<double*>(dpack + o_rms);
+    if (!ex || packed_vec) {
+        // (count, rms) — and the error vectors, when they fit the packed block — land behind the inputs on the device; ONE
+        // copy brings them, the first-order structs and the convergence flag back through the pinned buffer
+        T* dv = reinterpret_cast<T*>(dpack + o_vec);
+        const size_t slab = (size_t)na * cap;
+        rc = run_full_trace<T>(ctx, p, na, ex ? dv : (T*)nullptr, ex ? dv + slab : (T*)nullptr, ex ? dv + 2 * slab : (T*)nullptr,
+                               ex ? dv + 3 * slab : (T*)nullptr, d_cnt, d_rms, flags | ORT_DEVICE_PTRS);
         if (rc) return rc;
-        HIP_TRY(hipMemcpyAsync(hres, dres, out_bytes, hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipMemcpyAsync(hpin + o_flag, dpack + o_flag, pack_bytes - o_flag, hipMemcpyDeviceToHost, st));
         HIP_TRY(hipStreamSynchronize(st));
-        memcpy(count, hres + o_cnt, (size_t)na * sizeof(int64_t));
-        memcpy(rms, hres + o_rms, (size_t)na * sizeof(double));
+        memcpy(count, hpin + o_cnt, (size_t)na * sizeof(int64_t));
+        memcpy(rms, hpin + o_rms, (size_t)na * sizeof(double));
+        if (ex) {
+            const T* hv = reinterpret_cast<const T*>(hpin + o_vec);
+            for (int b = 0; b < na; ++b) {                           // the valid entries of every slab
+                const size_t off = (size_t)b * cap, cnt_b = (size_t)std::max<int64_t>(0, count[b]);
+                memcpy(ex + off, hv + off, cnt_b * sizeof(T));            memcpy(ey + off, hv + slab + off, cnt_b * sizeof(T));
+                memcpy(rho + off, hv + 2 * slab + off, cnt_b * sizeof(T)); memcpy(theta + off, hv + 3 * slab + off, cnt_b * sizeof(T));
+            }
+        }
     } else {
         rc = run_full_trace<T>(ctx, p, na, ex, ey, rho, theta, count, rms, flags); if (rc) return rc;
-        HIP_TRY(hipMemcpyAsync(hres + o_fo, dres + o_fo, out_bytes - o_fo, hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipMemcpyAsync(hpin + o_flag, dpack + o_flag, o_vec - o_flag, hipMemcpyDeviceToHost, st));
         HIP_TRY(hipStreamSynchronize(st));
     }
-    if (fo_out) memcpy(fo_out, hres + o_fo, (size_t)nsys * sizeof(FirstOrderOut));
+    if (fo_out) memcpy(fo_out, hpin + o_fo, (size_t)nsys * sizeof(FirstOrderOut));
     int flag = 0;
-    memcpy(&flag, hres + o_flag, sizeof(int));
+    memcpy(&flag, hpin + o_flag, sizeof(int));
     if (flag) return fail(ORT_EHIP, "ray aiming did not converge for at least one (system, field) pair");
     return ORT_OK;
 }
@@ -883,6 +921,7 @@ int ort_system_create(ort_ctx* ctx, int nsys, int rows, const double* R, const d
             memset(&m, 0, sizeof m);
             m.t = r.t; m.R = r.R; m.sgn = r.sgn; m.K = K ? K[(size_t)s * rows + i + 1] : 0.0;
             m.n1 = n[(size_t)s * rows + i]; m.n2 = n[(size_t)s * rows + i + 1];
+            m.eta = m.n1 / m.n2; m.invR = r.finite ? 1.0 / m.R : 0.0;
             m.finite = r.finite; m.ncoef = r.ncoef;
             mer[(size_t)s * S + i] = m;
         }

@@ -670,23 +670,26 @@ struct FtBundleAgg {
     double sq;        // sum of squared deviations (filled by k_ft_finalize)
 };
 
-__global__ __launch_bounds__(kBlock) void k_ft_scan(const int32_t* __restrict__ tile_cnt,
-                                                    const double* __restrict__ tile_sx,
-                                                    const double* __restrict__ tile_sy,
-                                                    const double* __restrict__ tile_rmax,
-                                                    int tiles_per_bundle,
-                                                    int64_t* __restrict__ tile_off,
-                                                    FtBundleAgg* __restrict__ agg)
+struct FtScanShared { int64_t w[kBlock / 64]; double rx[kBlock], ry[kBlock], rm[kBlock]; };
+
+// bundle b, by kBlock threads tid = 0 .. kBlock-1 of a workgroup (also the first stage of k_ft_small_finish, where the
+// workgroup holds more threads: those pass active = false and only keep the barriers company)
+__device__ __forceinline__ void ft_scan_body(int b, const int32_t* __restrict__ tile_cnt,
+                                             const double* __restrict__ tile_sx,
+                                             const double* __restrict__ tile_sy,
+                                             const double* __restrict__ tile_rmax,
+                                             int tiles_per_bundle,
+                                             int64_t* __restrict__ tile_off,
+                                             FtBundleAgg* __restrict__ agg, FtScanShared& sh, int tid, bool active)
 {
     // thread t owns the contiguous chunk of `per` tiles [t per, (t+1) per): a serial pass for its total, ONE block
     // scan of the 256 totals, a serial pass writing the offsets — two passes and one scan whatever the tile count
     // (8192 tiles per bundle at 2048^2: 32 per thread), where a block-wide scan per 256 tiles took 32 rounds
-    __shared__ int64_t s_w[kBlock / 64];
-    __shared__ double s_rx[kBlock], s_ry[kBlock], s_rm[kBlock];
-    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    int64_t* s_w = sh.w; double* s_rx = sh.rx; double* s_ry = sh.ry; double* s_rm = sh.rm;
+    const int lane = tid & 63, wave = tid >> 6;
     const int64_t base = (int64_t)b * tiles_per_bundle;
     const int per = (tiles_per_bundle + kBlock - 1) / kBlock;
-    const int t0 = tid * per, t1 = min(tiles_per_bundle, t0 + per);
+    const int t0 = tid * per, t1 = active ? min(tiles_per_bundle, t0 + per) : t0;
     int64_t mine = 0;
     double ax = 0.0, ay = 0.0, mx = -1.0;
     for (int t = t0; t < t1; ++t) {
@@ -698,8 +701,10 @@ __global__ __launch_bounds__(kBlock) void k_ft_scan(const int32_t* __restrict__ 
         const int64_t nbv = __shfl_up(v, off);
         if (lane >= off) v += nbv;
     }
-    if (lane == 63) s_w[wave] = v;
-    s_rx[tid] = ax; s_ry[tid] = ay; s_rm[tid] = mx;
+    if (active) {
+        if (lane == 63) s_w[wave] = v;
+        s_rx[tid] = ax; s_ry[tid] = ay; s_rm[tid] = mx;
+    }
     __syncthreads();
     int64_t woff = 0, total = 0;
     for (int w = 0; w < kBlock / 64; ++w) { woff += (w < wave) ? s_w[w] : 0; total += s_w[w]; }
@@ -709,10 +714,10 @@ __global__ __launch_bounds__(kBlock) void k_ft_scan(const int32_t* __restrict__ 
     }
     // deterministic tree over the 256 per-thread partials
     for (int off = kBlock / 2; off > 0; off >>= 1) {
-        if (tid < off) { s_rx[tid] += s_rx[tid + off]; s_ry[tid] += s_ry[tid + off]; s_rm[tid] = fmax(s_rm[tid], s_rm[tid + off]); }
+        if (active && tid < off) { s_rx[tid] += s_rx[tid + off]; s_ry[tid] += s_ry[tid + off]; s_rm[tid] = fmax(s_rm[tid], s_rm[tid + off]); }
         __syncthreads();
     }
-    if (tid == 0) {
+    if (active && tid == 0) {
         const int64_t m = total;
         FtBundleAgg a;
         a.m = m;
@@ -725,6 +730,14 @@ __global__ __launch_bounds__(kBlock) void k_ft_scan(const int32_t* __restrict__ 
     }
 }
 
+__global__ __launch_bounds__(kBlock) void k_ft_scan(const int32_t* __restrict__ tile_cnt, const double* __restrict__ tile_sx,
+                                                    const double* __restrict__ tile_sy, const double* __restrict__ tile_rmax,
+                                                    int tiles_per_bundle, int64_t* __restrict__ tile_off, FtBundleAgg* __restrict__ agg)
+{
+    __shared__ FtScanShared sh;
+    ft_scan_body(blockIdx.x, tile_cnt, tile_sx, tile_sy, tile_rmax, tiles_per_bundle, tile_off, agg, sh, threadIdx.x, true);
+}
+
 // ------------------------------------------------------------------------------------
 // full_trace, stage C of the FT_FULL route: one workgroup per tile moves the tile's compacted survivors from its
 // workspace slot to both halves of the bundle's output slab — first half at the tile's exclusive offset (ray
@@ -733,26 +746,30 @@ __global__ __launch_bounds__(kBlock) void k_ft_scan(const int32_t* __restrict__ 
 // from the 16-byte-aligned slot), staged in LDS, 64 B written as aligned 16-byte streaming stores whatever the parity of
 // the tile's offset and of m (stream_out): the kernel is bound by HBM, and 8-byte accesses ran it at half the store rate.
 // ------------------------------------------------------------------------------------
+template <typename T> struct FtPlaceShared { __attribute__((aligned(16))) T v[4][kTile]; double wsq[kBlock / 64]; };
+
+// tile `bid` (= bundle * tiles_per_bundle + tile), by kBlock threads tid = 0 .. kBlock-1 of a workgroup (also the second
+// stage of k_ft_small_finish, whose workgroup places four tiles at a time; active = false: no tile for this group)
 template <typename T>
-__global__ __launch_bounds__(kBlock) void k_ft_place(const T* __restrict__ w_ex, const T* __restrict__ w_ey,
-                                                     const T* __restrict__ w_r, const T* __restrict__ w_th,
-                                                     int64_t rpb, int tiles_per_bundle,
-                                                     const int32_t* __restrict__ tile_cnt, const int64_t* __restrict__ tile_off,
-                                                     const FtBundleAgg* __restrict__ agg,
-                                                     T* __restrict__ ex, T* __restrict__ ey,
-                                                     T* __restrict__ rho, T* __restrict__ theta,
-                                                     double* __restrict__ tile_sq)
+__device__ __forceinline__ void ft_place_body(int bid, const T* __restrict__ w_ex, const T* __restrict__ w_ey,
+                                              const T* __restrict__ w_r, const T* __restrict__ w_th,
+                                              int64_t rpb, int tiles_per_bundle,
+                                              const int32_t* __restrict__ tile_cnt, const int64_t* __restrict__ tile_off,
+                                              const FtBundleAgg* __restrict__ agg,
+                                              T* __restrict__ ex, T* __restrict__ ey,
+                                              T* __restrict__ rho, T* __restrict__ theta,
+                                              double* __restrict__ tile_sq, FtPlaceShared<T>& sh, int tid, bool active)
 {
     constexpr int V = 16 / (int)sizeof(T);
     typedef T vec_t __attribute__((ext_vector_type(V)));
-    __shared__ __attribute__((aligned(16))) T s_v[4][kTile];
-    __shared__ double s_wsq[kBlock / 64];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int b = blockIdx.x / tiles_per_bundle;
-    const int c = tile_cnt[blockIdx.x];
+    T (*s_v)[kTile] = sh.v;
+    double* s_wsq = sh.wsq;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int b = active ? bid / tiles_per_bundle : 0;
+    const int c = active ? tile_cnt[bid] : 0;
     const FtBundleAgg a = agg[b];
-    const int64_t src = (int64_t)blockIdx.x * kTile;                              // the tile's slot: 16-byte aligned, kTile entries
-    const int64_t dst = (int64_t)b * 2 * rpb + tile_off[blockIdx.x];
+    const int64_t src = (int64_t)bid * kTile;                                     // the tile's slot: 16-byte aligned, kTile entries
+    const int64_t dst = (int64_t)b * 2 * rpb + (active ? tile_off[bid] : 0);
     double sq = 0.0;
     for (int j = tid * V; j < c; j += kBlock * V) {                               // the slot holds kTile entries: reads past c stay inside it
         const vec_t vx = *reinterpret_cast<const vec_t*>(w_ex + src + j), vy = *reinterpret_cast<const vec_t*>(w_ey + src + j);
@@ -783,11 +800,26 @@ __global__ __launch_bounds__(kBlock) void k_ft_place(const T* __restrict__ w_ex,
     for (int off = 32; off > 0; off >>= 1) sq += __shfl_down(sq, off);
     if (lane == 0) s_wsq[wave] = sq;
     __syncthreads();
-    if (tid == 0) {
+    if (active && tid == 0) {
         double t = 0.0;
         for (int w = 0; w < kBlock / 64; ++w) t += s_wsq[w];
-        tile_sq[blockIdx.x] = t;
+        tile_sq[bid] = t;
     }
+}
+
+template <typename T>
+__global__ __launch_bounds__(kBlock) void k_ft_place(const T* __restrict__ w_ex, const T* __restrict__ w_ey,
+                                                     const T* __restrict__ w_r, const T* __restrict__ w_th,
+                                                     int64_t rpb, int tiles_per_bundle,
+                                                     const int32_t* __restrict__ tile_cnt, const int64_t* __restrict__ tile_off,
+                                                     const FtBundleAgg* __restrict__ agg,
+                                                     T* __restrict__ ex, T* __restrict__ ey,
+                                                     T* __restrict__ rho, T* __restrict__ theta,
+                                                     double* __restrict__ tile_sq)
+{
+    __shared__ FtPlaceShared<T> sh;
+    ft_place_body<T>(blockIdx.x, w_ex, w_ey, w_r, w_th, rpb, tiles_per_bundle, tile_cnt, tile_off, agg, ex, ey, rho, theta, tile_sq, sh,
+                     threadIdx.x, true);
 }
 
 // ------------------------------------------------------------------------------------
@@ -864,27 +896,69 @@ __global__ __launch_bounds__(kBlock) void k_ft_mirror(int64_t rpb, int chunks_pe
 
 // full_trace, stage D: sigma per bundle (PupilSampling.jl:169-173).
 // ft_err (look-back route, else null): a faulted look-back leaves count = -1, rms = NaN — what a device-pointer caller sees.
+// bundle b, by kBlock threads tid = 0 .. kBlock-1 of a workgroup (also the last stage of k_ft_small_finish); s_r: kBlock doubles of LDS.
+__device__ __forceinline__ void ft_finalize_body(int b, const double* __restrict__ tile_sq, int tiles_per_bundle,
+                                                 const FtBundleAgg* __restrict__ agg,
+                                                 int64_t* __restrict__ count, double* __restrict__ rms,
+                                                 const int* __restrict__ ft_err, double* __restrict__ s_r, int tid, bool active)
+{
+    double acc = 0.0;
+    if (active) {
+        for (int t = tid; t < tiles_per_bundle; t += kBlock) acc += tile_sq[(int64_t)b * tiles_per_bundle + t];
+        s_r[tid] = acc;
+    }
+    __syncthreads();
+    for (int off = kBlock / 2; off > 0; off >>= 1) {
+        if (active && tid < off) s_r[tid] += s_r[tid + off];
+        __syncthreads();
+    }
+    if (active && tid == 0) {
+        const int64_t m = agg[b].m;
+        const bool fault = ft_err && *ft_err;
+        count[b] = fault ? -1 : 2 * m;
+        rms[b] = (m && !fault) ? sqrt(s_r[0] / (double)(2 * m)) : __builtin_nan("");
+    }
+}
+
 __global__ __launch_bounds__(kBlock) void k_ft_finalize(const double* __restrict__ tile_sq, int tiles_per_bundle,
                                                         const FtBundleAgg* __restrict__ agg,
                                                         int64_t* __restrict__ count, double* __restrict__ rms,
                                                         const int* __restrict__ ft_err)
 {
     __shared__ double s_r[kBlock];
-    const int b = blockIdx.x, tid = threadIdx.x;
-    double acc = 0.0;
-    for (int t = tid; t < tiles_per_bundle; t += kBlock) acc += tile_sq[(int64_t)b * tiles_per_bundle + t];
-    s_r[tid] = acc;
-    __syncthreads();
-    for (int off = kBlock / 2; off > 0; off >>= 1) {
-        if (tid < off) s_r[tid] += s_r[tid + off];
-        __syncthreads();
+    ft_finalize_body(blockIdx.x, tile_sq, tiles_per_bundle, agg, count, rms, ft_err, s_r, threadIdx.x, true);
+}
+
+// full_trace of SMALL bundles (a few tiles each: the reference's own call is 4): stages B, C and D — tile offsets and bundle
+// aggregates, placement of both halves, sigma — by ONE workgroup per bundle in one launch, through the bodies of
+// k_ft_scan, k_ft_place and k_ft_finalize (same operations in the same order: same numbers).  Three dependent launches
+// of a few microseconds of work each cost more in launch boundaries than in work.  The workgroup holds kFinishGroups
+// groups of kBlock threads: the first runs the scan and sigma stages, each places one tile at a time (their global
+// round trips overlap instead of queueing).
+constexpr int kFinishGroups = 4;
+template <typename T>
+__global__ __launch_bounds__(kBlock * kFinishGroups) void k_ft_small_finish(const T* __restrict__ w_ex, const T* __restrict__ w_ey,
+                                                            const T* __restrict__ w_r, const T* __restrict__ w_th,
+                                                            int64_t rpb, int tiles_per_bundle,
+                                                            const int32_t* __restrict__ tile_cnt, const double* __restrict__ tile_sx,
+                                                            const double* __restrict__ tile_sy, const double* __restrict__ tile_rmax,
+                                                            int64_t* __restrict__ tile_off, FtBundleAgg* __restrict__ agg,
+                                                            T* __restrict__ ex, T* __restrict__ ey, T* __restrict__ rho, T* __restrict__ theta,
+                                                            double* __restrict__ tile_sq, int64_t* __restrict__ count, double* __restrict__ rms)
+{
+    __shared__ FtScanShared ss;
+    __shared__ FtPlaceShared<T> ps[kFinishGroups];
+    __shared__ double s_r[kBlock];
+    const int b = blockIdx.x, tid = threadIdx.x & (kBlock - 1), grp = threadIdx.x / kBlock;
+    ft_scan_body(b, tile_cnt, tile_sx, tile_sy, tile_rmax, tiles_per_bundle, tile_off, agg, ss, tid, grp == 0);
+    __syncthreads();                                             // tile_off, agg[b]: written above, read below by this workgroup
+    for (int tile0 = 0; tile0 < tiles_per_bundle; tile0 += kFinishGroups) {
+        const int tile = tile0 + grp;
+        ft_place_body<T>(b * tiles_per_bundle + tile, w_ex, w_ey, w_r, w_th, rpb, tiles_per_bundle, tile_cnt, tile_off, agg,
+                         ex, ey, rho, theta, tile_sq, ps[grp], tid, tile < tiles_per_bundle);
+        __syncthreads();                                         // the staging buffers are reused; tile_sq is read below
     }
-    if (tid == 0) {
-        const int64_t m = agg[b].m;
-        const bool fault = ft_err && *ft_err;
-        count[b] = fault ? -1 : 2 * m;
-        rms[b] = (m && !fault) ? sqrt(s_r[0] / (double)(2 * m)) : __builtin_nan("");
-    }
+    ft_finalize_body(b, tile_sq, tiles_per_bundle, agg, count, rms, nullptr, s_r, tid, grp == 0);
 }
 
 // ------------------------------------------------------------------------------------
@@ -893,6 +967,7 @@ __global__ __launch_bounds__(kBlock) void k_ft_finalize(const double* __restrict
 // ------------------------------------------------------------------------------------
 struct MerSurf {   // row i+1 of the prescription as seen by loop iteration i
     double t, R, sgn, K, n1, n2;
+    double eta, invR;      // n1 / n2 and 1 / R (0 on a plane), once per row: the aiming traces (mer_plain_trace_to) run hundreds of times
     int32_t finite, ncoef;
 };
 
@@ -988,7 +1063,8 @@ struct AimOut {
     int32_t ok;            // 1 = every loop converged
 };
 
-struct MerEnd { double y_stop, y_last, U_last, z_last, z_prev, y_first, s_last; };
+struct MerEnd { double y_stop, y_last, U_last, z_last, z_prev, y_first, s_last;
+                double sU, cU; };   // plain systems (mer_plain_trace_to): sin / cos of the last angle; U_last is taken from them once, after the loop
 
 __device__ inline MerEnd mer_trace_to(const MerSurf* __restrict__ surf, const double* __restrict__ coefs, int S, int ncoef,
                                       int layout_mode, double t_last, double y, double U, int stop_idx)
@@ -1006,6 +1082,96 @@ __device__ inline MerEnd mer_trace_to(const MerSurf* __restrict__ surf, const do
     e.s_last = sprev;                                            // sag at the last surface
     zp = z; z = z + (t_last - sprev);                            // last ts entry
     e.y_last = y; e.U_last = U; e.z_last = z; e.z_prev = zp;
+    return e;
+}
+
+// The same trace for a PLAIN prescription (every row a sphere or a plane, K = 0, p = zero) without a single
+// trigonometric call: the ray carries (sin U, cos U); a sphere is met in centre form — with Q = P - C the path length is
+// d = -b - sign(R) sqrt(b^2 - |Q0|^2 + R^2), b = Q0 . k —, the normal is -Q / R and Snell's law is applied to the
+// direction vector, k' = eta k + (cos I' - eta cos I) n.  Algebraically the reference's loop (RayTracing.jl:151-167:
+// y += tan U t; sag; theta = asin(y / R); U' = asin(n sin(U + theta) / n') - theta), evaluated with two square roots per
+// surface where that one takes five libm calls.  The aiming loops are SERIAL chains of such traces (:223-296,
+// PupilSampling.jl:67-83) and stop at |loss| <= sqrt(eps) (RayTracing.jl:1): their latency, not their last bits, is what
+// a single full_trace call feels (config 1: 77 us of 140 us device time were these chains).  Rows with a conic constant
+// or a polynomial keep mer_step.  A miss (disc < 0) or total internal reflection gives NaN from there on, as there (:83,164).
+// sqrt to ~1 ulp from the hardware seed and two corrections (the residual form of ieee_sqrt without its last step);
+// 0 -> 0, negative -> NaN.  The loops it feeds stop at 1.5e-8.
+__device__ __forceinline__ double aim_sqrt(double x)
+{
+    const double y = __builtin_amdgcn_rsq(x + 1e-300);
+    double g = x * y, h = 0.5 * y;
+    const double r = __builtin_fma(-h, g, 0.5);
+    g = __builtin_fma(g, r, g); h = __builtin_fma(h, r, h);
+    return __builtin_fma(__builtin_fma(-g, g, x), h, g);
+}
+
+// sin and cos of a launch angle of the aiming loops: |w| <= pi / 4 (field angles) by their Taylor series to x^17 / x^16
+// (remainders below 2^-60 there), larger angles through libm.  The chief-ray loop takes one pair per iteration (:280-285).
+__device__ __forceinline__ void aim_sincos(double w, double& sw, double& cw)
+{
+    if (__builtin_fabs(w) > 0.7853981633974483) { sw = ::sin(w); cw = ::cos(w); return; }
+    const double x2 = w * w;
+    double s = 2.8114572543455206e-15;                                // 1 / 17!
+    s = __builtin_fma(s, x2, -7.6471637318198164e-13);                // -1 / 15!
+    s = __builtin_fma(s, x2, 1.6059043836821613e-10);                 // 1 / 13!
+    s = __builtin_fma(s, x2, -2.5052108385441720e-08);                // -1 / 11!
+    s = __builtin_fma(s, x2, 2.7557319223985893e-06);                 // 1 / 9!
+    s = __builtin_fma(s, x2, -1.9841269841269841e-04);                // -1 / 7!
+    s = __builtin_fma(s, x2, 8.3333333333333332e-03);                 // 1 / 5!
+    s = __builtin_fma(s, x2, -1.6666666666666666e-01);                // -1 / 3!
+    sw = __builtin_fma(s * x2, w, w);
+    double c = 4.7794773323873853e-14;                                // 1 / 16!
+    c = __builtin_fma(c, x2, -1.1470745597729725e-11);                // -1 / 14!
+    c = __builtin_fma(c, x2, 2.0876756987868100e-09);                 // 1 / 12!
+    c = __builtin_fma(c, x2, -2.7557319223985888e-07);                // -1 / 10!
+    c = __builtin_fma(c, x2, 2.4801587301587302e-05);                 // 1 / 8!
+    c = __builtin_fma(c, x2, -1.3888888888888889e-03);                // -1 / 6!
+    c = __builtin_fma(c, x2, 4.1666666666666664e-02);                 // 1 / 4!
+    c = __builtin_fma(c, x2, -0.5);
+    cw = __builtin_fma(c, x2, 1.0);
+}
+
+__device__ inline MerEnd mer_plain_trace_to(const MerSurf* __restrict__ surf, int S, double t_last, double y, double sU, double cU,
+                                            int stop_idx)
+{
+    MerEnd e;
+    e.y_stop = __builtin_nan(""); e.y_first = y; e.U_last = 0.0;
+    double sprev = 0.0, z = 0.0, zp = 0.0;
+    for (int i = 0; i < S; ++i) {
+        const MerSurf s = surf[i];
+        const double tcur = s.t - sprev;                              // ts[i] after :161
+        const double eta = s.eta;
+        double sg;
+        if (s.finite) {
+            const double Qz0 = -tcur - s.R;                           // the ray point relative to the centre of curvature
+            const double b = Qz0 * cU + y * sU;
+            const double disc = b * b - (Qz0 * Qz0 + y * y) + s.R * s.R;
+            const double sq = aim_sqrt(disc);                         // NaN: the ray misses (:83)
+            const double d = -b - s.sgn * sq;
+            y = y + d * sU;
+            const double Qz = Qz0 + d * cU;
+            sg = Qz + s.R;                                            // sag (:155)
+            const double cosi = __builtin_fabs(s.invR) * sq;          // cos I = |Q . k| / |R|
+            const double D2 = (1.0 - eta * eta) + eta * eta * cosi * cosi;
+            const double gc = (aim_sqrt(D2) - eta * cosi) * s.invR;   // D2 < 0: total internal reflection -> NaN (:164)
+            sU = eta * sU - gc * y;
+            cU = eta * cU - gc * Qz;
+        } else {
+            y = y + (sU * fast_rcp(cU)) * tcur;                       // :152
+            sg = 0.0;                                                 // :86
+            const double D2 = (1.0 - eta * eta) + eta * eta * cU * cU;
+            sU = eta * sU;                                            // normal (0, 1): only the axial component refracts
+            cU = aim_sqrt(D2);
+        }
+        sprev = sg;
+        const double tsi = tcur + sg;                                 // ts[i] += s (:160)
+        zp = z; z = (i == 0) ? tsi : z + tsi;                         // cumsum(ts)  (Types.jl:61-63)
+        if (i + 1 == stop_idx) e.y_stop = y;                          // ray.y[begin+stop]
+        if (i == 0) e.y_first = y;                                    // ray.y[2]
+    }
+    e.s_last = sprev;
+    zp = z; z = z + (t_last - sprev);
+    e.y_last = y; e.z_last = z; e.z_prev = zp; e.sU = sU; e.cU = cU;
     return e;
 }
 
@@ -1051,60 +1217,86 @@ __device__ __forceinline__ void pair_newton(F&& trace, double& v, double target,
 
 // Four lanes per (system, field): lanes 0-1 = chief pair, lanes 2-3 = marginal pair, then lanes 0-1 / 2-3 =
 // the two edge rays.  Same operations on the same values as the serial drivers, a quarter of the latency.
-__global__ __launch_bounds__(64) void k_aim(int n, const AimIn* __restrict__ in,
-                                            const MerSurf* __restrict__ fwd, const double* __restrict__ cfwd, const double* __restrict__ tl_fwd,
-                                            const MerSurf* __restrict__ rev, const double* __restrict__ crev, const double* __restrict__ tl_rev,
-                                            int S, int ncoef, AimOut* __restrict__ out)
+// `role` = lane index inside its group of four (the group's lanes must be consecutive lanes of one wave); F / Rv = the
+// request's forward / reversed tables, cF / cR their coefficient rows (or null).  Returns the result on every lane.
+__device__ inline AimOut aim_group(const AimIn& a, int role, const MerSurf* __restrict__ F, const double* __restrict__ cF, double tlF,
+                                   const MerSurf* __restrict__ Rv, const double* __restrict__ cR, double tlR, int S, int ncoef)
 {
-    const int g = blockIdx.x * 64 + threadIdx.x;
-    const int aim = g >> 2, role = g & 3, pair = role >> 1, pairbase = pair * 2;
-    const bool valid = aim < n;
-    const AimIn a = in[valid ? aim : n - 1];                     // tail lanes shadow the last request: uniform shuffles
+    const int pair = role >> 1, pairbase = pair * 2;
     const int rows = S + 1;
-    const MerSurf* F = fwd + (int64_t)a.system * S;
-    const MerSurf* Rv = rev + (int64_t)a.system * S;
-    const double* cF = cfwd ? cfwd + (int64_t)a.system * rows * ncoef : nullptr;
-    const double* cR = crev ? crev + (int64_t)a.system * rows * ncoef : nullptr;
-    const double tlF = tl_fwd[a.system], tlR = tl_rev[a.system];
+    // plain prescription (spheres and planes only, both ways): the trig-free trace (mer_plain_trace_to)
+    bool plain = true;
+    for (int i = 0; i < S; ++i) plain = plain && F[i].K == 0.0 && F[i].ncoef == 0 && Rv[i].K == 0.0 && Rv[i].ncoef == 0;
     int iters = 0, ok = 1;
     // ---- phase 1: real chief ray on the reversed system (RayTracing.jl:278-286) | real marginal ray (:225-233)
     const int stop_rev = rows - a.stop;                          // :278
     const double ybp = a.chief_y_end;                            // :279
     double v = pair == 0 ? -a.chief_u_end : a.y_marg;            // :280 | :225
     MerEnd e; double loss = 0.0;
+    double sv = 0.0, cv = 1.0;                                   // sin / cos of the chief pair's last launch angle (plain path)
     pair_newton([&](double w) {
+                    if (plain) {
+                        if (pair != 0) return mer_plain_trace_to(F, S, tlF, w, 0.0, 1.0, a.stop);
+                        aim_sincos(w, sv, cv);
+                        return mer_plain_trace_to(Rv, S, tlR, ybp, sv, cv, stop_rev);
+                    }
                     return pair == 0 ? mer_trace_to(Rv, cR, S, ncoef, a.layout_rev, tlR, ybp, w, stop_rev)
                                      : mer_trace_to(F, cF, S, ncoef, a.layout_fwd, tlF, w, 0.0, a.stop);
                 }, v, pair == 0 ? 0.0 : a.a_stop, a.atol, 200, true, pairbase, role, e, loss, iters, ok);
     // results live on the base lanes: chief on lane 0, marginal on lane 2
+    double ub1, t_ub1, t_v0;                                     // ū[1], tan(ū[1]), tan(-launch angle of the reversed trace)
+    if (plain) {                                                 // the tangents are quotients of what the trace carries; the angle
+        const double sl = __shfl(e.sU, 0, 4), cl = __shfl(e.cU, 0, 4);   // itself is needed once (U = H ū[1] below)
+        ub1 = -::atan2(sl, cl);                                  // ū[1] = -reverse(ray.u)[1]          :289
+        t_ub1 = -sl / cl;
+        t_v0 = -__shfl(sv, 0, 4) / __shfl(cv, 0, 4);
+    } else {
+        ub1 = -__shfl(e.U_last, 0, 4);
+        t_ub1 = ::tan(ub1);
+        t_v0 = ::tan(-__shfl(v, 0, 4));
+    }
     const double yb2 = __shfl(e.y_last, 0, 4);                   // ȳ[2] = reverse(ray.y)[1]           :287
-    const double ub1 = -__shfl(e.U_last, 0, 4);                  // ū[1] = -reverse(ray.u)[1]          :289
     const double z2 = __shfl(e.z_last, 0, 4) - __shfl(e.z_prev, 0, 4);   // z[2] = ray.z[end] - ray.z[end-1]   :292
-    const double EP_t = -yb2 / ::tan(ub1) + z2;                  // :293
+    const double EP_t = -yb2 / t_ub1 + z2;                       // :293
     // z[end] - z[end-1] = -ȳ[end-1] / tan(ū[end-1])  (:294):  ȳ[end-1] = ray.y[2] (the last real surface),
     // ū[end-1] = -ray.u[1] (the converged launch angle of the reversed trace)
-    const double XP_t = -__shfl(e.y_first, 0, 4) / ::tan(-__shfl(v, 0, 4));
+    const double XP_t = -__shfl(e.y_first, 0, 4) / t_v0;
     const double y_EP = fabs(__shfl(v, 2, 4));                   // PupilSampling.jl:98 (real_marginal.y[1])
     // ---- phase 2: field, edge rays (PupilSampling.jl:94-100)
     const double U = a.H * ub1;                                  // :96
-    const double u = ::tan(U);                                   // :97
+    double sinU, cosU;
+    aim_sincos(U, sinU, cosU);
+    const double u = plain ? sinU / cosU : ::tan(U);             // :97
     const double astop = fabs(a.a_stop);                         // :91
     const double target = pair == 0 ? astop : -astop;
     const double y0 = (pair == 0 ? y_EP : -y_EP) - u * EP_t;     // :99
     double yy = y0;
     int ok2 = 1;
-    pair_newton([&](double w) { return mer_trace_to(F, cF, S, ncoef, a.layout_fwd, tlF, w, U, a.stop); },
+    pair_newton([&](double w) { return plain ? mer_plain_trace_to(F, S, tlF, w, sinU, cosU, a.stop)
+                                             : mer_trace_to(F, cF, S, ncoef, a.layout_fwd, tlF, w, U, a.stop); },
                 yy, target, a.atol, 100, false, pairbase, role, e, loss, iters, ok2, true);
     if (!(fabs(loss) <= 1e300)) yy = y0;                         // isnan(Δ) ? Inf : Δ keeps the start point (:72,78)
-    const double y2e = __shfl(yy, 2, 4);
-    const int it_all = iters + __shfl(iters, 2, 4);              // lanes 0 and 2 carry their pairs' counts
-    const int ok_all = ok & __shfl(ok, 2, 4);
-    if (valid && role == 0) {
-        AimOut o;
-        o.U = U; o.y1 = yy; o.y2 = y2e; o.y_EP = y_EP; o.hprime = u * a.f; o.EP_t = EP_t; o.Ubar = ub1; o.XP_t = XP_t;
-        o.iters = it_all; o.ok = ok_all;
-        out[aim] = o;
-    }
+    AimOut o;
+    o.U = U; o.y1 = __shfl(yy, 0, 4); o.y2 = __shfl(yy, 2, 4); o.y_EP = y_EP; o.hprime = u * a.f; o.EP_t = EP_t; o.Ubar = ub1; o.XP_t = XP_t;
+    o.iters = __shfl(iters, 0, 4) + __shfl(iters, 2, 4);         // lanes 0 and 2 carry their pairs' counts
+    o.ok = __shfl(ok, 0, 4) & __shfl(ok, 2, 4);
+    return o;
+}
+
+__global__ __launch_bounds__(64) void k_aim(int n, const AimIn* __restrict__ in,
+                                            const MerSurf* __restrict__ fwd, const double* __restrict__ cfwd, const double* __restrict__ tl_fwd,
+                                            const MerSurf* __restrict__ rev, const double* __restrict__ crev, const double* __restrict__ tl_rev,
+                                            int S, int ncoef, AimOut* __restrict__ out)
+{
+    const int g = blockIdx.x * 64 + threadIdx.x;
+    const int aim = g >> 2, role = g & 3;
+    const bool valid = aim < n;
+    const AimIn a = in[valid ? aim : n - 1];                     // tail lanes shadow the last request: uniform shuffles
+    const int rows = S + 1;
+    const AimOut o = aim_group(a, role, fwd + (int64_t)a.system * S, cfwd ? cfwd + (int64_t)a.system * rows * ncoef : nullptr,
+                               tl_fwd[a.system], rev + (int64_t)a.system * S, crev ? crev + (int64_t)a.system * rows * ncoef : nullptr,
+                               tl_rev[a.system], S, ncoef);
+    if (valid && role == 0) out[aim] = o;
 }
 
 // ------------------------------------------------------------------------------------
@@ -1251,22 +1443,18 @@ struct FirstOrderOut {
 enum { SURF_SPHERICAL = 0, SURF_COMA, SURF_ASTIGMATISM, SURF_SAGITTAL, SURF_DISTORTION, SURF_AXIAL, SURF_LATERAL,
        SURF_PETZVAL, SURF_MEDIAL, SURF_TANGENTIAL, SURF_COUNT };   // = ORT_SURF_* of ort.h
 
-__global__ __launch_bounds__(64) void k_first_order(int nsys, int rows, const double* __restrict__ Rg, const double* __restrict__ tg,
-                                                    const double* __restrict__ ng, const double* __restrict__ ag,
-                                                    const double* __restrict__ dng, const double* __restrict__ hp,
-                                                    double lam, FirstOrderOut* __restrict__ out,
-                                                    double* __restrict__ surf, double* __restrict__ inc)
+// Work arrays of one first-order solve: private (scratch) arrays in the batched kernel, LDS in the one-wave small-problem
+// kernel (k_small_prepare), where their latency is on the critical path.
+struct FirstOrderWork { double *tau, *phi, *y1, *w1, *y2, *w2, *yc, *wc; };
+
+// solve(surfaces, a, h') + aberrations(...) of ONE system g of the batch (see k_first_order below).
+__device__ __forceinline__ void first_order_core(int g, int nsys, int rows, const double* __restrict__ R, const double* __restrict__ t,
+                                                 const double* __restrict__ n, const double* __restrict__ a,
+                                                 const double* __restrict__ dn, double h, double lam, const FirstOrderWork& W,
+                                                 FirstOrderOut& o, double* __restrict__ surf, double* __restrict__ inc)
 {
-    const int g = blockIdx.x * 64 + threadIdx.x;
-    if (g >= nsys) return;
-    const double* R = Rg + (int64_t)g * rows;
-    const double* t = tg + (int64_t)g * rows;
-    const double* n = ng + (int64_t)g * rows;
-    const double* a = ag + (int64_t)g * (rows - 1);
-    const double* dn = dng ? dng + (int64_t)g * rows : nullptr;
-    const double h = hp[g];
-    double tau[kMaxRows], phi[kMaxRows];
-    double y1[kMaxRows + 2], w1[kMaxRows + 2], y2[kMaxRows + 1], w2[kMaxRows + 1];
+    double* tau = W.tau; double* phi = W.phi; double* y1 = W.y1; double* w1 = W.w1; double* y2 = W.y2; double* w2 = W.w2;
+    double* yc = W.yc; double* wc = W.wc;
     // Lens(surfaces)  RayTracing.jl:38-53
     for (int i = 0; i < rows; ++i) {
         const double ti = (i == 0 && !__builtin_isfinite(t[0])) ? 0.0 : t[i];      // :42
@@ -1286,7 +1474,6 @@ __global__ __launch_bounds__(64) void k_first_order(int nsys, int rows, const do
             y1[i + 1] = ya; w1[i + 1] = wa; y2[i + 1] = yb; w2[i + 1] = wb;
         }
     }
-    FirstOrderOut o;
     o.k = k;
     o.f = -(1.0 / w1[k]);                                                            // :213
     o.EBFD = y1[k] * o.f;                                                            // :214
@@ -1302,7 +1489,6 @@ __global__ __launch_bounds__(64) void k_first_order(int nsys, int rows, const do
     // chief  :246-263
     const double y_stop = y1[stop + 1], y2_stop = y2[stop + 1];
     const double nub = -w1[k + 1] * h / y1[1];                                       // :256
-    double yc[kMaxRows + 2], wc[kMaxRows + 2];
     yc[0] = 0.0; wc[0] = nub;                                                        // :259
     for (int i = 1; i <= k; ++i) {                                                   // :258
         yc[i] = nub * (y2[i] - y1[i] * y2_stop / y_stop);
@@ -1359,6 +1545,22 @@ __global__ __launch_bounds__(64) void k_first_order(int nsys, int rows, const do
     }
     o.W040 = W040; o.W131 = W131; o.W222 = W222; o.W311 = W311; o.W220P = W220P;
     o.W220 = W220P + 0.5 * W222; o.W020 = W020; o.W111 = W111;
+}
+
+__global__ __launch_bounds__(64) void k_first_order(int nsys, int rows, const double* __restrict__ Rg, const double* __restrict__ tg,
+                                                    const double* __restrict__ ng, const double* __restrict__ ag,
+                                                    const double* __restrict__ dng, const double* __restrict__ hp,
+                                                    double lam, FirstOrderOut* __restrict__ out,
+                                                    double* __restrict__ surf, double* __restrict__ inc)
+{
+    const int g = blockIdx.x * 64 + threadIdx.x;
+    if (g >= nsys) return;
+    double tau[kMaxRows], phi[kMaxRows];
+    double y1[kMaxRows + 2], w1[kMaxRows + 2], y2[kMaxRows + 1], w2[kMaxRows + 1], yc[kMaxRows + 2], wc[kMaxRows + 2];
+    const FirstOrderWork W = {tau, phi, y1, w1, y2, w2, yc, wc};
+    FirstOrderOut o;
+    first_order_core(g, nsys, rows, Rg + (int64_t)g * rows, tg + (int64_t)g * rows, ng + (int64_t)g * rows, ag + (int64_t)g * (rows - 1),
+                     dng ? dng + (int64_t)g * rows : nullptr, hp[g], lam, W, o, surf, inc);
     out[g] = o;
 }
 
@@ -1383,6 +1585,59 @@ __device__ __forceinline__ int row_ncoef(const double* __restrict__ c, int ncoef
 // one thread per (system, loop index i): extended skew table [nsys][rows] (+ its polynomial records
 // [nsys][rows][kPolyRec]), forward and reversed meridional tables [nsys][rows-1] (+ the reversed coefficient
 // rows [nsys][rows][ncoef]; the forward ones are the input), last thicknesses.  K, coef may be null.
+// Row i of system s: the extended skew record (+ polynomial record) of loop iteration i and, for i < rows-1, the
+// forward and reversed meridional rows (+ the reversed coefficient row).  Any output pointer may be null (not wanted).
+// Rs, ts, ns, Ks, cs: the system's own columns (Ks, cs may be null).  rec / poly: this row's slots; mf / mr: this row's
+// slots; cr: the reversed coefficient table of the system [rows][ncoef].
+template <typename T>
+__device__ __forceinline__ void build_table_row(int i, int rows, const double* __restrict__ Rs, const double* __restrict__ ts,
+                                                const double* __restrict__ ns, const double* __restrict__ Ks,
+                                                const double* __restrict__ cs, int ncoef, double BFD,
+                                                SurfRec<T>* __restrict__ rec, T* __restrict__ poly, bool want_poly,
+                                                MerSurf* __restrict__ mf, MerSurf* __restrict__ mr, double* __restrict__ cr)
+{
+    auto tt = [&](int j) { return (j == 0 && !__builtin_isfinite(ts[0])) ? 0.0 : ts[j]; };          // Lens() mutation (Q19)
+    // extended system (PupilSampling.jl:111-114): rows+1 rows, loop index i = 0..rows-1 is row i+1
+    if (rec) {
+        const bool real = i + 1 < rows;                                  // the last iteration is the appended image plane
+        const double te = (i == rows - 1) ? BFD : tt(i);                 // t[end-1] = focus
+        const double Re = real ? Rs[i + 1] : __builtin_inf();
+        const double n1 = ns[i], n2 = real ? ns[i + 1] : 1.0;
+        const double Ke = (real && Ks) ? Ks[i + 1] : 0.0;                // K = [surfaces.K; 0.0]  (:112)
+        int nc = 0, pcls = 0;
+        if (want_poly)                                                   // p = [surfaces.p; zero]  (:113)
+            pcls = make_poly_rec<T>(poly, (real && cs) ? cs + (int64_t)(i + 1) * ncoef : nullptr, ncoef, &nc);
+        SurfRec<T> r;
+        make_rec<T>(r, (T)te, (T)Re, (T)n1, (T)n2, (T)Ke, nc, pcls);
+        *rec = r;
+    }
+    if (i < rows - 1 && mf) {
+        MerSurf m;
+        m.t = tt(i); m.R = Rs[i + 1]; m.sgn = m.R > 0 ? 1.0 : (m.R < 0 ? -1.0 : m.R); m.K = Ks ? Ks[i + 1] : 0.0;
+        m.n1 = ns[i]; m.n2 = ns[i + 1]; m.finite = __builtin_isfinite(m.R) ? 1 : 0;
+        m.eta = m.n1 / m.n2; m.invR = m.finite ? 1.0 / m.R : 0.0;
+        m.ncoef = cs ? row_ncoef<double>(cs + (int64_t)(i + 1) * ncoef, ncoef) : 0;
+        *mf = m;
+        // reversed (RayTracing.jl:267-274): rev_R = -[Inf; R[end:-1:2]], rev_t = reverse(t) with rev_t[1] = BFD,
+        // K and p plainly reversed (Q17): row j = i + 1 of the reversed system carries K[rows-1-j], p[rows-1-j]
+        MerSurf q;
+        q.t = (i == 0) ? BFD : tt(rows - 1 - i);
+        q.R = -Rs[rows - 1 - i];                                         // rev_R[i+1] = -R[rows-1-i]
+        q.sgn = q.R > 0 ? 1.0 : (q.R < 0 ? -1.0 : q.R); q.K = Ks ? Ks[rows - 2 - i] : 0.0;
+        q.n1 = ns[rows - 1 - i]; q.n2 = ns[rows - 2 - i]; q.finite = __builtin_isfinite(q.R) ? 1 : 0;
+        q.eta = q.n1 / q.n2; q.invR = q.finite ? 1.0 / q.R : 0.0;
+        q.ncoef = cs ? row_ncoef<double>(cs + (int64_t)(rows - 2 - i) * ncoef, ncoef) : 0;
+        *mr = q;
+        if (cr) {
+            for (int j = 0; j < ncoef; ++j) cr[(int64_t)(i + 1) * ncoef + j] = cs[(int64_t)(rows - 2 - i) * ncoef + j];
+            if (i == 0) for (int j = 0; j < ncoef; ++j) cr[j] = cs[(int64_t)(rows - 1) * ncoef + j];
+        }
+    }
+}
+
+// one thread per (system, loop index i): extended skew table [nsys][rows] (+ its polynomial records
+// [nsys][rows][kPolyRec]), forward and reversed meridional tables [nsys][rows-1] (+ the reversed coefficient
+// rows [nsys][rows][ncoef]; the forward ones are the input), last thicknesses.  K, coef may be null.
 template <typename T>
 __global__ __launch_bounds__(kBlock) void k_build_tables(int nsys, int rows, const double* __restrict__ R, const double* __restrict__ t,
                                                          const double* __restrict__ n, const double* __restrict__ K,
@@ -1396,48 +1651,27 @@ __global__ __launch_bounds__(kBlock) void k_build_tables(int nsys, int rows, con
     const int64_t g = (int64_t)blockIdx.x * kBlock + threadIdx.x;
     if (g >= (int64_t)nsys * rows) return;
     const int s = (int)(g / rows), i = (int)(g - (int64_t)s * rows);
-    const double* Rs = R + (int64_t)s * rows; const double* ts = t + (int64_t)s * rows; const double* ns = n + (int64_t)s * rows;
-    const double* Ks = K ? K + (int64_t)s * rows : nullptr;
-    const double* cs = (coef && ncoef > 0) ? coef + (int64_t)s * rows * ncoef : nullptr;
-    const double BFD = fo[s].BFD;
-    auto tt = [&](int j) { return (j == 0 && !__builtin_isfinite(ts[0])) ? 0.0 : ts[j]; };          // Lens() mutation (Q19)
-    // extended system (PupilSampling.jl:111-114): rows+1 rows, loop index i = 0..rows-1 is row i+1
-    {
-        const bool real = i + 1 < rows;                                  // the last iteration is the appended image plane
-        const double te = (i == rows - 1) ? BFD : tt(i);                 // t[end-1] = focus
-        const double Re = real ? Rs[i + 1] : __builtin_inf();
-        const double n1 = ns[i], n2 = real ? ns[i + 1] : 1.0;
-        const double Ke = (real && Ks) ? Ks[i + 1] : 0.0;                // K = [surfaces.K; 0.0]  (:112)
-        int nc = 0, pcls = 0;
-        if (poly_ext)                                                    // p = [surfaces.p; zero]  (:113)
-            pcls = make_poly_rec<T>(poly_ext + ((int64_t)s * rows + i) * kPolyRec, (real && cs) ? cs + (int64_t)(i + 1) * ncoef : nullptr,
-                                    ncoef, &nc);
-        SurfRec<T> r;
-        make_rec<T>(r, (T)te, (T)Re, (T)n1, (T)n2, (T)Ke, nc, pcls);
-        rec_ext[(int64_t)s * rows + i] = r;
+    const double* ts = t + (int64_t)s * rows;
+    const bool mer = i < rows - 1;
+    build_table_row<T>(i, rows, R + (int64_t)s * rows, ts, n + (int64_t)s * rows, K ? K + (int64_t)s * rows : nullptr,
+                       (coef && ncoef > 0) ? coef + (int64_t)s * rows * ncoef : nullptr, ncoef, fo[s].BFD,
+                       rec_ext + (int64_t)s * rows + i, poly_ext ? poly_ext + ((int64_t)s * rows + i) * kPolyRec : nullptr, poly_ext != nullptr,
+                       mer ? mer_fwd + (int64_t)s * (rows - 1) + i : nullptr, mer ? mer_rev + (int64_t)s * (rows - 1) + i : nullptr,
+                       crev ? crev + (int64_t)s * rows * ncoef : nullptr);
+    if (i == 0) {
+        tl_fwd[s] = (rows - 1 == 0 && !__builtin_isfinite(ts[0])) ? 0.0 : ts[rows - 1];
+        tl_rev[s] = !__builtin_isfinite(ts[0]) ? 0.0 : ts[0];
     }
-    if (i < rows - 1) {
-        MerSurf m;
-        m.t = tt(i); m.R = Rs[i + 1]; m.sgn = m.R > 0 ? 1.0 : (m.R < 0 ? -1.0 : m.R); m.K = Ks ? Ks[i + 1] : 0.0;
-        m.n1 = ns[i]; m.n2 = ns[i + 1]; m.finite = __builtin_isfinite(m.R) ? 1 : 0;
-        m.ncoef = cs ? row_ncoef<double>(cs + (int64_t)(i + 1) * ncoef, ncoef) : 0;
-        mer_fwd[(int64_t)s * (rows - 1) + i] = m;
-        // reversed (RayTracing.jl:267-274): rev_R = -[Inf; R[end:-1:2]], rev_t = reverse(t) with rev_t[1] = BFD,
-        // K and p plainly reversed (Q17): row j = i + 1 of the reversed system carries K[rows-1-j], p[rows-1-j]
-        MerSurf q;
-        q.t = (i == 0) ? BFD : tt(rows - 1 - i);
-        q.R = -Rs[rows - 1 - i];                                         // rev_R[i+1] = -R[rows-1-i]
-        q.sgn = q.R > 0 ? 1.0 : (q.R < 0 ? -1.0 : q.R); q.K = Ks ? Ks[rows - 2 - i] : 0.0;
-        q.n1 = ns[rows - 1 - i]; q.n2 = ns[rows - 2 - i]; q.finite = __builtin_isfinite(q.R) ? 1 : 0;
-        q.ncoef = cs ? row_ncoef<double>(cs + (int64_t)(rows - 2 - i) * ncoef, ncoef) : 0;
-        mer_rev[(int64_t)s * (rows - 1) + i] = q;
-        if (crev) {
-            double* cr = crev + (int64_t)s * rows * ncoef;
-            for (int j = 0; j < ncoef; ++j) cr[(int64_t)(i + 1) * ncoef + j] = cs[(int64_t)(rows - 2 - i) * ncoef + j];
-            if (i == 0) for (int j = 0; j < ncoef; ++j) cr[j] = cs[(int64_t)(rows - 1) * ncoef + j];
-        }
-    }
-    if (i == 0) { tl_fwd[s] = tt(rows - 1); tl_rev[s] = tt(0); }
+}
+
+// The aiming request of (system s, field H) from the first-order results (PupilSampling.jl:88-93).
+__device__ __forceinline__ AimIn make_aim_in(int s, const FirstOrderOut& o, double a_stop, double H, int layout_fwd)
+{
+    AimIn q;
+    q.system = s; q.stop = o.stop; q.layout_fwd = layout_fwd; q.layout_rev = 1;   // the reversed system is always a Layout (:272-276)
+    q.H = fabs(H); q.y_marg = o.y_marg; q.a_stop = a_stop;
+    q.chief_y_end = o.chief_y_end; q.chief_u_end = o.chief_u_end; q.f = o.f; q.atol = 1.4901161193847656e-08;
+    return q;
 }
 
 __global__ __launch_bounds__(kBlock) void k_build_aim(int nsys, int nf, int rows, const FirstOrderOut* __restrict__ fo,
@@ -1448,11 +1682,21 @@ __global__ __launch_bounds__(kBlock) void k_build_aim(int nsys, int nf, int rows
     if (g >= nsys * nf) return;
     const int s = g / nf, f = g - s * nf;
     const FirstOrderOut o = fo[s];
-    AimIn q;
-    q.system = s; q.stop = o.stop; q.layout_fwd = layout_fwd; q.layout_rev = 1;   // the reversed system is always a Layout (:272-276)
-    q.H = fabs(fields[f]); q.y_marg = o.y_marg; q.a_stop = a[(int64_t)s * (rows - 1) + o.stop - 1];
-    q.chief_y_end = o.chief_y_end; q.chief_u_end = o.chief_u_end; q.f = o.f; q.atol = 1.4901161193847656e-08;
-    ain[g] = q;
+    ain[g] = make_aim_in(s, o, a[(int64_t)s * (rows - 1) + o.stop - 1], fields[f], layout_fwd);
+}
+
+// The bundle descriptor of aiming result g (PupilSampling.jl:94-99,115): axes of bundle g at g (k_rays + k2).
+template <typename T>
+__device__ __forceinline__ DevBundle<T> make_dev_bundle(const AimIn& q, const AimOut& o, int g, int k_rays, int k2)
+{
+    DevBundle<T> d;
+    d.system = q.system; d.stop = q.stop - 1;
+    d.u = (T)::tan(o.U); d.v = T(0);                                     // PupilSampling.jl:38-39 (V = 0, :115)
+    const T nrm = (T)__builtin_sqrt((double)((d.v * d.v + d.u * d.u) + T(1))), inv = T(1) / nrm;
+    d.k0 = d.v * inv; d.k1 = d.u * inv; d.k2 = inv;
+    d.a_stop = (T)fabs(q.a_stop); d.hprime = (T)o.hprime; d.ybar = T(0); d.z0 = T(1);
+    d.yoff = (int64_t)g * (k_rays + k2); d.xoff = d.yoff + k_rays;
+    return d;
 }
 
 template <typename T>
@@ -1464,15 +1708,64 @@ __global__ __launch_bounds__(kBlock) void k_build_bundles(int na, int k_rays, in
     if (g >= na) return;
     const AimIn q = ain[g]; const AimOut o = aout[g];
     if (!o.ok) atomicOr(fail_flag, 1);
-    DevBundle<T> d;
-    d.system = q.system; d.stop = q.stop - 1;
-    d.u = (T)::tan(o.U); d.v = T(0);                                     // PupilSampling.jl:38-39 (V = 0, :115)
-    const T nrm = (T)__builtin_sqrt((double)((d.v * d.v + d.u * d.u) + T(1))), inv = T(1) / nrm;
-    d.k0 = d.v * inv; d.k1 = d.u * inv; d.k2 = inv;
-    d.a_stop = (T)fabs(q.a_stop); d.hprime = (T)o.hprime; d.ybar = T(0); d.z0 = T(1);
-    d.yoff = (int64_t)g * (k_rays + k2); d.xoff = d.yoff + k_rays;
-    bd[g] = d;
+    bd[g] = make_dev_bundle<T>(q, o, g, k_rays, k2);
     ends[4 * (int64_t)g + 0] = o.y1; ends[4 * (int64_t)g + 1] = o.y2; ends[4 * (int64_t)g + 2] = 0.0; ends[4 * (int64_t)g + 3] = o.y_EP;
+}
+
+// ------------------------------------------------------------------------------------
+// Small problems (a handful of (system, field) pairs: the reference's own call, full_trace(system, H, 64) = 2,048 rays):
+// everything in front of the grid trace in ONE launch, one wave per pair — first-order solve (lane 0, work arrays in
+// LDS), tables (lanes over rows; the meridional ones stay in LDS), aiming (aim_group, four lanes), bundle descriptor
+// and pupil axes — the work of k_first_order, k_build_tables, k_build_aim, k_aim, k_build_bundles and k_make_axes
+// through the same device functions, so the numbers are theirs.  The launches, not the arithmetic, were the cost:
+// six dependent launches + a fill ahead of the trace kernel, ~110 us of a 140 us call.
+// `fail_flag` must be zero on entry.  rec_ext / poly_ext / fo are written by the pair's first field only.
+// ------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(64) void k_small_prepare(int nsys, int nf, int rows, const double* __restrict__ R, const double* __restrict__ t,
+                                                      const double* __restrict__ n, const double* __restrict__ K,
+                                                      const double* __restrict__ coef, int ncoef, const double* __restrict__ a,
+                                                      const double* __restrict__ hp, const double* __restrict__ fields,
+                                                      int k_rays, int k2, int layout_fwd, double lam,
+                                                      FirstOrderOut* __restrict__ fo, SurfRec<T>* __restrict__ rec_ext,
+                                                      T* __restrict__ poly_ext, DevBundle<T>* __restrict__ bd, T* __restrict__ axes,
+                                                      int* __restrict__ fail_flag)
+{
+    __shared__ double s_work[8][kMaxRows + 2];
+    __shared__ MerSurf s_mf[kMaxRows], s_mr[kMaxRows];
+    __shared__ double s_crev[kMaxRows * kMaxCoef];
+    __shared__ FirstOrderOut s_fo;
+    const int g = blockIdx.x, s = g / nf, f = g - s * nf, lane = threadIdx.x;
+    const double* Rs = R + (int64_t)s * rows; const double* ts = t + (int64_t)s * rows; const double* ns = n + (int64_t)s * rows;
+    const double* Ks = K ? K + (int64_t)s * rows : nullptr;
+    const double* cs = (coef && ncoef > 0) ? coef + (int64_t)s * rows * ncoef : nullptr;
+    if (lane == 0) {
+        const FirstOrderWork W = {s_work[0], s_work[1], s_work[2], s_work[3], s_work[4], s_work[5], s_work[6], s_work[7]};
+        FirstOrderOut o;
+        first_order_core(s, nsys, rows, Rs, ts, ns, a + (int64_t)s * (rows - 1), nullptr, hp[s], lam, W, o, nullptr, nullptr);
+        s_fo = o;
+        if (f == 0) fo[s] = o;
+    }
+    __syncthreads();
+    const FirstOrderOut o1 = s_fo;
+    for (int i = lane; i < rows; i += 64) {
+        const bool mer = i < rows - 1;
+        build_table_row<T>(i, rows, Rs, ts, ns, Ks, cs, ncoef, o1.BFD,
+                           f == 0 ? rec_ext + (int64_t)s * rows + i : nullptr,
+                           (f == 0 && poly_ext) ? poly_ext + ((int64_t)s * rows + i) * kPolyRec : nullptr, poly_ext != nullptr,
+                           mer ? s_mf + i : nullptr, mer ? s_mr + i : nullptr, cs ? s_crev : nullptr);
+    }
+    __syncthreads();
+    const double tlF = ts[rows - 1], tlR = !__builtin_isfinite(ts[0]) ? 0.0 : ts[0];
+    const AimIn q = make_aim_in(s, o1, a[(int64_t)s * (rows - 1) + o1.stop - 1], fields[f], layout_fwd);
+    const AimOut o = aim_group(q, lane & 3, s_mf, cs, tlF, s_mr, cs ? s_crev : nullptr, tlR, rows - 1, ncoef);
+    if (lane == 0) {
+        if (!o.ok) atomicOr(fail_flag, 1);
+        bd[g] = make_dev_bundle<T>(q, o, g, k_rays, k2);
+    }
+    const int per = k_rays + k2;
+    for (int j = lane; j < per; j += 64)                                 // range(y1, y2, k), range(0, y_EP, k / 2)  (:121-122), as k_make_axes
+        axes[(int64_t)g * per + j] = (T)((j < k_rays) ? dd_range_elem(o.y1, o.y2, k_rays, j) : dd_range_elem(0.0, o.y_EP, k2, j - k_rays));
 }
 
 // ------------------------------------------------------------------------------------

@@ -212,8 +212,11 @@ def test_full_trace_end_to_end_on_gpu(hip_engine, oracle_engine):
     eg = ort.full_trace(sg, 0.7, engine=hip_engine)
     eo = ort.full_trace(so, 0.7, engine=oracle_engine)
     assert len(eg.x) == len(eo.x)
-    assert cm.rel_err(eg.x, eo.x, 1.0).max() <= 1e-9        # aiming iterates through device trig
-    assert abs(eg.RMS - eo.RMS) <= 1e-9 * eo.RMS
+    # the aiming loops stop at |residual| <= sqrt(eps) (RayTracing.jl:1,229,282): the device's loops (trig-free trace of a
+    # plain prescription) and the oracle's (the reference's libm form) are the same Newton iteration on the same function to
+    # rounding, and may leave their last iterate a few 1e-9 apart
+    assert cm.rel_err(eg.x, eo.x, 1.0).max() <= 1e-7
+    assert abs(eg.RMS - eo.RMS) <= 1e-7 * eo.RMS
 
 
 def test_full_trace_multi_bundle_and_raybasis(hip_engine, oracle_engine):
@@ -562,10 +565,12 @@ def test_device_aiming_matches_host_driven(hip_engine, oracle_engine):
             host = ort.full_trace_aim(s.layout, s, H, engine=hip_engine)
             orc = ort.full_trace_aim(s.layout, s, H, engine=oracle_engine)
             d = dev[si][fi]
-            # U, y_EP: same device arithmetic on both routes -> identical.  tan(U) is ocml in the kernel
-            # and libm on the host route, so h' may differ in the last ulp and the edge-ray Newton
-            # (stopped at |residual| <= sqrt(eps)) may stop on a neighbouring iterate.
-            assert d.U == host.U and d.y_EP == host.y_EP, (si, H)
+            # U, y_EP: the same Newton loops on both routes; the device kernel traces a plain (spherical) prescription
+            # without trigonometric calls (mer_plain_trace_to), the host-driven route goes through the meridional kernel's
+            # libm form — the same function of the launch data to rounding.  tan(U) is ocml in the kernel and libm on the
+            # host route, so h' may differ in the last ulp and the edge-ray Newton (stopped at |residual| <= sqrt(eps))
+            # may stop on a neighbouring iterate.
+            assert abs(d.U - host.U) <= 1e-13 * max(1.0, abs(host.U)) and abs(d.y_EP - host.y_EP) <= 1e-9, (si, H)
             assert abs(d.hprime - host.hprime) <= 1e-14 * max(1.0, abs(host.hprime))
             for key in ("y1", "y2"):
                 assert abs(getattr(d, key) - getattr(host, key)) <= 1e-7, (si, H, key)
@@ -1634,3 +1639,45 @@ def test_fan_with_a_last_thickness(hip_engine, oracle_engine):
     _, dsc = oracle_engine.fan(pres, spec, 22, descending=True)
     # same rays except the marginal one, whose focal-plane height differs by tan(u') * t[end]
     assert np.abs(asc[0, :-1] - dsc[0, :0:-1]).max() <= 1e-12 and abs(asc[0, -1] - dsc[0, 0]) > 1e-3
+
+
+def test_small_problem_path_is_bit_identical_to_the_general_route(hip_engine):
+    """Config 1 — the reference's own call, full_trace(system, H, 64) on the Cooke triplet — takes the small-problem
+    route: ONE launch for solve + tables + aiming + bundle + axes (k_small_prepare), the grid trace, ONE launch for
+    offsets + placement + sigma (k_ft_small_finish), one copy each way.  The general route (six setup launches, three
+    finishing ones: ORT_NO_SMALL_PATH) runs the same device functions: first-order structs, counts, RMS and every error
+    vector entry must be IDENTICAL, for spherical and aspheric prescriptions, vectors and statistics only."""
+    import ctypes as C
+    from opticalraytracing_jl_amd import _capi, workloads
+    lib, h = hip_engine.ctx.lib, hip_engine.ctx.h
+    M4, coef = workloads.double_gauss_aspheric(0)
+    cases = [(cm.cooke()[None], None, None, cm.COOKE_A, cm.COOKE_H, (0.0, 0.7, 1.0), 64),
+             (cm.tessar()[None], None, None, cm.TESSAR_A, cm.TESSAR_H, (0.0, 1.0), 64),
+             (np.stack([workloads.double_gauss(l) for l in (0, 1, 2)]), None, None, cm.DG_A, cm.DG_H, (0.0, 1.0), 48),
+             (M4[None, :, :3], M4[None, :, 3], coef[None], cm.DG_A, cm.DG_H, (0.0, 1.0), 64)]
+    for mats, K, cf, a, hp, fields, k in cases:
+        nsys, rows, _ = mats.shape
+        R, t, n = (np.ascontiguousarray(mats[:, :, j]) for j in range(3))
+        aa = np.ascontiguousarray(np.broadcast_to(np.asarray(a, dtype=np.float64), (nsys, rows - 1)))
+        hh = np.full(nsys, float(hp)); ff = np.asarray(fields, dtype=np.float64)
+        na, cap = nsys * len(fields), 2 * k * (k // 2)
+        Kp = None if K is None else np.ascontiguousarray(K); cp = None if cf is None else np.ascontiguousarray(cf)
+        res = {}
+        for tag, extra in (("small", 0), ("general", _capi.ORT_NO_SMALL_PATH)):
+            fo = (_capi.ort_first_order * nsys)()
+            ex, ey, rho, th = (np.zeros((na, cap)) for _ in range(4))
+            cnt = np.zeros(na, dtype=np.int64); rms = np.zeros(na)
+            _capi.check(lib.ort_full_trace_layout_batch_f64(h, nsys, rows, _capi.ptr(R), _capi.ptr(t), _capi.ptr(n), _capi.ptr(Kp),
+                                                            _capi.ptr(cp), 0 if cp is None else cp.shape[2], _capi.ptr(aa), _capi.ptr(hh),
+                                                            len(ff), _capi.ptr(ff), k, fo, _capi.ptr(ex), _capi.ptr(ey), _capi.ptr(rho),
+                                                            _capi.ptr(th), _capi.ptr(cnt), _capi.ptr(rms), hip_engine.base_flags | extra))
+            c2 = np.zeros(na, dtype=np.int64); r2 = np.zeros(na)
+            if K is None:
+                _capi.check(lib.ort_spot_batch_f64(h, nsys, rows, _capi.ptr(R), _capi.ptr(t), _capi.ptr(n), _capi.ptr(aa), _capi.ptr(hh),
+                                                   len(ff), _capi.ptr(ff), k, None, _capi.ptr(c2), _capi.ptr(r2), hip_engine.base_flags | extra))
+            res[tag] = (bytes(fo), ex, ey, rho, th, cnt, rms, c2, r2)
+        s_, g_ = res["small"], res["general"]
+        assert s_[0] == g_[0]                                                    # first-order structs, byte for byte
+        assert np.array_equal(s_[5], g_[5]) and (s_[5] > 0).all()
+        for j in (1, 2, 3, 4, 6, 7, 8):
+            assert np.array_equal(s_[j], g_[j]), j
