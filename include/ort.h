@@ -55,16 +55,22 @@ extern "C" {
 #define ORT_LAYOUT_INPUT  (1u << 3) /* meridional: input was a Layout -> always atan (Q16) */
 #define ORT_CLIP          (1u << 4) /* paraxial: clip = true (RayTracing.jl:135) */
 #define ORT_FAST_MATH     (1u << 5) /* direction-cosine / fused arithmetic: coordinates within 1e-10 relative of the
-                                       reference sequence (measured <= 5e-12), status identical except within rounding of a
-                                       miss / TIR boundary; a wave holding a ray on which the reference's formulas are not
-                                       the geometry (hit beyond a sphere's equator, direction refracted backward, polynomial
-                                       row outside its conic) retraces with the reference sequence.  Default: the op-for-op
-                                       IEEE sequence of the reference loop, bit-identical to a non-fused CPU evaluation */
+                                       reference sequence (measured <= 5e-12), status IDENTICAL on every ray by construction:
+                                       a wave holding a ray within 1e-9 (normalised) of a branch of the reference loop (surface
+                                       miss, total reflection, a sphere's equator, the stop filter's or a clear aperture's edge),
+                                       a totally reflected ray, or a ray on which the reference's formulas are not the geometry
+                                       (hit beyond the equator, direction refracted backward, polynomial row outside its conic)
+                                       retraces with the reference sequence and is bit-identical there.  Default: the op-for-op
+                                       IEEE sequence of the reference loop, bit-identical to a non-fused CPU evaluation.  Both
+                                       policies run the same entry points (tests/test_gpu_parity.py) */
 #define ORT_NO_SMALL_PATH (1u << 8) /* testing aid: small problems (<= 256 (system, field) pairs; full_trace bundles of <= 32 tiles)
                                        normally run their setup and their finish as ONE launch each (k_small_prepare,
                                        k_ft_small_finish); this takes the general multi-launch route instead — same device
                                        functions, bit-identical results (tests/test_gpu_parity.py) */
 /* bit 6 reserved (was ORT_NO_LDS, the scalar-load variant of the surface table: measured, not faster, dropped) */
+#define ORT_AIM_EDGE_AS_FOUND (1u << 9) /* ort_aim_f64, diagnostic: leave the two edge-ray searches where the FD-Newton ends (either side
+                                        of the stop's edge) instead of applying the fitted "end inside the edge" rule described at
+                                        ort_aim_f64 */
 #define ORT_FT_LOOKBACK   (1u << 7) /* full_trace: the trace kernel writes the survivors' first half at its final place
                                        (decoupled look-back over the bundle's tiles) instead of staging compacted tiles in
                                        a workspace: 82 instead of 100 B/ray of HBM traffic, but tiles wait for their
@@ -234,10 +240,14 @@ int ort_ctx_domain_error(ort_ctx *ctx, int64_t *ray, int *surface, int64_t *coun
  * One (system, field) pair per entry: the FD-Newton drivers of src/RayTracing.jl:223-240 (real
  * marginal) and :265-296 (real chief, traced through the REVERSED prescription, which the
  * caller uploads as `rev`, built as :267-277 incl. quirk Q17) and the edge-ray search of
- * src/PupilSampling.jl:67-83 (Optim.BFGS in the reference; restated as the same FD-Newton, ended INSIDE the
- * stop's edge: y1, y2 are such that the grid's two edge rays pass the filter r > a_stop of :132, as the
- * reference's do — its published Tessar spot size 0.11975 depends on them),
- * giving the aiming scalars of src/PupilSampling.jl:94-103 that ort_full_trace_f64 consumes.
+ * src/PupilSampling.jl:67-83 (Optim.BFGS in the reference — a third-party optimiser, parity unpinned; restated as
+ * the same FD-Newton), giving the aiming scalars of src/PupilSampling.jl:94-103 that ort_full_trace_f64 consumes.
+ * FITTED TO ONE DOCS FIGURE, not a restatement: an edge-ray search that ends outside the stop's edge takes one more
+ * step to atol inside, so y1 / y2 are biased inward by <= atol and the grid's two edge rays pass the filter
+ * r > a_stop of :132.  The reference's published Tessar spot size (0.11975, real_spot_diagram.png) comes out with
+ * this rule and 0.64 % low without it; on other systems the side the reference's BFGS ends on is unknown, so the
+ * survivor count can differ from the reference's by the x = 0 rays of the first and last pupil row (at most 2 rays,
+ * 4 with their mirror images).  ORT_AIM_EDGE_AS_FOUND turns the rule off.
  * `in`, `out`: host arrays [n] (device arrays with ORT_DEVICE_PTRS).                        */
 typedef struct ort_aim_in {
     int32_t system;        /* index into fwd and rev */

@@ -25,6 +25,7 @@ ORT_CLIP = 1 << 4
 ORT_FAST_MATH = 1 << 5
 ORT_FT_LOOKBACK = 1 << 7
 ORT_NO_SMALL_PATH = 1 << 8
+ORT_AIM_EDGE_AS_FOUND = 1 << 9
 ORT_STATUS_STOPPED = 1 << 16
 ORT_STATUS_VIGNETTED = 1 << 17
 ORT_MAX_ROWS = 64

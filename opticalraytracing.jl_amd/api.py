@@ -627,7 +627,8 @@ def _trace_edge_rays(surfaces, y1, y2, U, stop, a_stop, engine=None, atol: float
     other aiming loops, on the signed residual — parity unpinned: no reference
     test checks y1, y2; the only downstream check is the RMS to ±0.07.
 
-    One thing IS known about the reference's end points: its two edge rays pass the stop filter
+    FITTED TO ONE DOCS FIGURE (not a restatement; ORT_AIM_EDGE_AS_FOUND / edge_as_found on the device route turns it
+    off): one thing is known about the reference's end points — its two edge rays pass the stop filter
     `rᵢ > a_stop` (:132) — the RMS printed in docs/src/assets/images/real_spot_diagram.png
     (0.11975, Tessar, H = 0) is reproduced to its five digits with them and is 0.64 % lower without
     (DESIGN §2).  A search that stops within sqrt(eps) of the edge lands on either side, so an end

@@ -668,7 +668,7 @@ int spot_batch_impl(ort_ctx* ctx, int nsys, int rows, const double* R, const dou
                            coefp, ncoef, d_fo, d_rec, d_poly, d_mf, d_mr, d_crev, d_tlf, d_tlr);
         hipLaunchKernelGGL(k_build_aim, nblk(na, kBlock), dim3(kBlock), 0, st, nsys, nfields, rows, d_fo, da, dfields, layout ? 1 : 0, d_ain);
         hipLaunchKernelGGL(k_aim, nblk((int64_t)na * 4, 64), dim3(64), 0, st, na, d_ain, d_mf, coefp, d_tlf,
-                           d_mr, (const double*)d_crev, d_tlr, rows - 1, ncoef, d_aout);
+                           d_mr, (const double*)d_crev, d_tlr, rows - 1, ncoef, d_aout, 1);
         hipLaunchKernelGGL((k_build_bundles<T>), nblk(na, kBlock), dim3(kBlock), 0, st, na, k_rays, k2, d_ain, d_aout, d_bd, d_ends, d_flag);
         hipLaunchKernelGGL((k_make_axes<T>), nblk((int64_t)na * (k_rays + k2), kBlock), dim3(kBlock), 0, st, na, k_rays, k2, d_ends, d_axes);
     }
@@ -1207,7 +1207,8 @@ int ort_aim_f64(ort_ctx* ctx, const ort_system* fwd, const ort_system* rev, int 
         rc = dev_out<AimOut>(ctx, SL_OUT0, (size_t)n, &dout); if (rc) return rc;
     }
     hipLaunchKernelGGL(k_aim, dim3((unsigned)(((int64_t)n * 4 + 63) / 64)), dim3(64), 0, ctx->stream, n, din,
-                       fwd->mer, fwd->coef64, fwd->d_tlast, rev->mer, rev->coef64, rev->d_tlast, S, fwd->ncoef, dout);
+                       fwd->mer, fwd->coef64, fwd->d_tlast, rev->mer, rev->coef64, rev->d_tlast, S, fwd->ncoef, dout,
+                       (flags & ORT_AIM_EDGE_AS_FOUND) ? 0 : 1);
     HIP_TRY(hipGetLastError());
     if (!devp) {
         rc = from_device<AimOut>(ctx, reinterpret_cast<AimOut*>(out), dout, (size_t)n); if (rc) return rc;

@@ -1180,9 +1180,12 @@ __device__ inline MerEnd mer_plain_trace_to(const MerSurf* __restrict__ surf, in
 // loop's arithmetic, two traces per round side by side.  `trace(v)` returns the MerEnd of a ray launched
 // with the pair's free variable set to v; loss = y_stop - target.  The two pairs of a 4-lane group run
 // different problems concurrently; the loop is group-uniform so the shuffles always see live lanes.
-// inside_edge (the edge rays of the pupil grid): a search that ends OUTSIDE its target |y_stop| = a_stop takes one more
-// Newton step, to atol inside — the grid's edge rays must pass the stop filter r > a_stop (PupilSampling.jl:132) as
-// the reference's do (its published Tessar spot size is reproduced with them and 0.64 % off without).
+// inside_edge (the edge rays of the pupil grid) — a rule FITTED to one published figure, not a restatement of
+// Optim.BFGS: a search that ends OUTSIDE its target |y_stop| = a_stop takes one more Newton step, to atol inside, so
+// the grid's two edge rays pass the stop filter r > a_stop (PupilSampling.jl:132).  The reference's Tessar spot size
+// (docs figure, 0.11975) is reproduced with them and is 0.64 % off without; on any other system which side the
+// reference's BFGS ends on is unpinned, so the survivor count may differ from it by the x = 0 rays of the first and
+// last pupil row (tests/test_gpu_parity.py::test_edge_rule_only_moves_the_two_edge_rays).
 template <typename F>
 __device__ __forceinline__ void pair_newton(F&& trace, double& v, double target, double atol, int cap, bool cap_fails,
                                             int pairbase, int role, MerEnd& e, double& loss, int& iters, int& ok,
@@ -1220,7 +1223,8 @@ __device__ __forceinline__ void pair_newton(F&& trace, double& v, double target,
 // `role` = lane index inside its group of four (the group's lanes must be consecutive lanes of one wave); F / Rv = the
 // request's forward / reversed tables, cF / cR their coefficient rows (or null).  Returns the result on every lane.
 __device__ inline AimOut aim_group(const AimIn& a, int role, const MerSurf* __restrict__ F, const double* __restrict__ cF, double tlF,
-                                   const MerSurf* __restrict__ Rv, const double* __restrict__ cR, double tlR, int S, int ncoef)
+                                   const MerSurf* __restrict__ Rv, const double* __restrict__ cR, double tlR, int S, int ncoef,
+                                   bool edge_inside = true)
 {
     const int pair = role >> 1, pairbase = pair * 2;
     const int rows = S + 1;
@@ -1274,7 +1278,7 @@ __device__ inline AimOut aim_group(const AimIn& a, int role, const MerSurf* __re
     int ok2 = 1;
     pair_newton([&](double w) { return plain ? mer_plain_trace_to(F, S, tlF, w, sinU, cosU, a.stop)
                                              : mer_trace_to(F, cF, S, ncoef, a.layout_fwd, tlF, w, U, a.stop); },
-                yy, target, a.atol, 100, false, pairbase, role, e, loss, iters, ok2, true);
+                yy, target, a.atol, 100, false, pairbase, role, e, loss, iters, ok2, edge_inside);
     if (!(fabs(loss) <= 1e300)) yy = y0;                         // isnan(Δ) ? Inf : Δ keeps the start point (:72,78)
     AimOut o;
     o.U = U; o.y1 = __shfl(yy, 0, 4); o.y2 = __shfl(yy, 2, 4); o.y_EP = y_EP; o.hprime = u * a.f; o.EP_t = EP_t; o.Ubar = ub1; o.XP_t = XP_t;
@@ -1286,7 +1290,7 @@ __device__ inline AimOut aim_group(const AimIn& a, int role, const MerSurf* __re
 __global__ __launch_bounds__(64) void k_aim(int n, const AimIn* __restrict__ in,
                                             const MerSurf* __restrict__ fwd, const double* __restrict__ cfwd, const double* __restrict__ tl_fwd,
                                             const MerSurf* __restrict__ rev, const double* __restrict__ crev, const double* __restrict__ tl_rev,
-                                            int S, int ncoef, AimOut* __restrict__ out)
+                                            int S, int ncoef, AimOut* __restrict__ out, int edge_inside)
 {
     const int g = blockIdx.x * 64 + threadIdx.x;
     const int aim = g >> 2, role = g & 3;
@@ -1295,7 +1299,7 @@ __global__ __launch_bounds__(64) void k_aim(int n, const AimIn* __restrict__ in,
     const int rows = S + 1;
     const AimOut o = aim_group(a, role, fwd + (int64_t)a.system * S, cfwd ? cfwd + (int64_t)a.system * rows * ncoef : nullptr,
                                tl_fwd[a.system], rev + (int64_t)a.system * S, crev ? crev + (int64_t)a.system * rows * ncoef : nullptr,
-                               tl_rev[a.system], S, ncoef);
+                               tl_rev[a.system], S, ncoef, edge_inside != 0);
     if (valid && role == 0) out[aim] = o;
 }
 

@@ -210,7 +210,9 @@ class HipEngine:
         return yo, Uo, ts
 
     # ---- batched aiming: RayTracing.jl:223-296 + PupilSampling.jl:67-83,94-103 ------------
-    def aim(self, fwd: Prescription, rev: Prescription, specs: Sequence[dict]) -> List[dict]:
+    def aim(self, fwd: Prescription, rev: Prescription, specs: Sequence[dict], edge_as_found: bool = False) -> List[dict]:
+        """ort_aim_f64.  edge_as_found: leave the edge-ray searches where the FD-Newton ends (diagnostic: the default
+        ends them inside the stop's edge, a rule fitted to the reference's published Tessar figure, include/ort.h)."""
         n = len(specs)
         ain = (_capi.ort_aim_in * n)()
         for i, sp in enumerate(specs):
@@ -222,7 +224,8 @@ class HipEngine:
             a.f, a.atol = float(sp["f"]), float(sp.get("atol", 1.4901161193847656e-08))
         aout = (_capi.ort_aim_out * n)()
         sf, sr = self.system(fwd), self.system(rev)      # both objects held across the call (see system())
-        check(self.ctx.lib.ort_aim_f64(self.ctx.h, sf.h, sr.h, n, ain, aout, self.base_flags))
+        check(self.ctx.lib.ort_aim_f64(self.ctx.h, sf.h, sr.h, n, ain, aout,
+                                       self.base_flags | (_capi.ORT_AIM_EDGE_AS_FOUND if edge_as_found else 0)))
         return [dict(U=o.U, y1=o.y1, y2=o.y2, y_EP=o.y_EP, hprime=o.hprime, EP_t=o.EP_t, Ubar=o.Ubar, XP_t=o.XP_t,
                      iters=o.iters, ok=bool(o.ok)) for o in aout]
 

@@ -581,6 +581,56 @@ def test_device_aiming_matches_host_driven(hip_engine, oracle_engine):
             assert d.stop == host.stop and d.a_stop == host.a_stop and d.focus == host.focus
 
 
+def test_edge_rule_only_moves_the_two_edge_rays(hip_engine, oracle_engine):
+    """The edge-ray rule (an end point found outside the stop's edge steps to sqrt(eps) inside) is FITTED to the
+    reference's published Tessar figure, not a restatement of its Optim.BFGS search (src/PupilSampling.jl:67-83,
+    parity unpinned).  What it can change against a search left where it ends (ORT_AIM_EDGE_AS_FOUND): y1 / y2 by
+    <= 2 sqrt(eps)-ish, hence only whether the x = 0 rays of the first and the last pupil row pass r > a_stop (:132).
+    Checked on perturbed Double-Gauss instances, the Cooke triplet and the Tessar, three fields each; the traced grid is
+    the reference-sequence policy and is also checked against the oracle's status."""
+    from opticalraytracing_jl_amd import api, workloads
+    mats = list(workloads.config5(None, ninst=24, seed=777)) + [cm.cooke(), cm.tessar()]
+    aps = [(cm.DG_A, cm.DG_H)] * 24 + [(cm.COOKE_A, cm.COOKE_H), (cm.TESSAR_A, cm.TESSAR_H)]
+    fields = (0.0, 0.7, 1.0)
+    k, k2 = 32, 16
+    moved = diff_rays = 0
+    for M, (A, Hh) in zip(mats, aps):
+        s = ort.solve(M, A, Hh, engine=oracle_engine)
+        pf, lf, _ = api._as_layout(s.layout)
+        pr, lr, _ = api._as_layout(api.reversed_layout(s.layout, s))
+        specs = [dict(system=0, stop=s.stop, layout_fwd=lf, layout_rev=lr, H=H, y_marg=s.marginal.y[0], a_stop=s.a[s.stop - 1],
+                      chief_y_end=s.chief.y[-1], chief_u_end=s.chief.u[-1], f=s.f) for H in fields]
+        on = hip_engine.aim(pf, pr, specs)
+        off = hip_engine.aim(pf, pr, specs, edge_as_found=True)
+        foc = s.marginal.z[-1] - s.marginal.z[-2]
+        pres = api.extended_prescription(s.layout, foc)
+        masks = []
+        for outs in (on, off):
+            axes, bundles, o = [], [], 0
+            for a in outs:
+                axes += [ort.linrange(a["y1"], a["y2"], k), ort.linrange(0.0, a["y_EP"], k2)]
+                bundles.append(dict(system=0, stop=s.stop, U=a["U"], V=0.0, a_stop=abs(s.a[s.stop - 1]), hprime=a["hprime"],
+                                    yaxis_off=o, xaxis_off=o + k))
+                o += k + k2
+            axes = np.concatenate(axes)
+            g = hip_engine.grid(pres, bundles, axes, k, k2, history=False)
+            og = oracle_engine.grid(pres, bundles, axes, k, k2, history=False)
+            assert np.array_equal(g["status"], og["status"])
+            masks.append((g["status"] == pres.rows).reshape(len(fields), k, k2))        # every surface hit, not stopped
+        for a, b in zip(on, off):
+            for key in ("U", "y_EP", "hprime"):
+                assert a[key] == b[key]                                                     # the rule touches y1, y2 only
+            for key in ("y1", "y2"):
+                assert abs(a[key] - b[key]) <= 1e-6
+                moved += a[key] != b[key]
+        d = masks[0] != masks[1]
+        allowed = np.zeros_like(d); allowed[:, 0, 0] = True; allowed[:, k - 1, 0] = True
+        assert not (d & ~allowed).any()
+        assert (masks[0] | ~d).all()                       # where they differ, the rule is the one that keeps the ray
+        diff_rays += int(d.sum())
+    assert moved > 0 and diff_rays > 0                     # the rule did act on this set
+
+
 def test_full_trace_batch_end_to_end(hip_engine, oracle_engine):
     """full_trace for (system x field) batches: aiming kernel + full_trace pipeline on the GPU
     == per-call full_trace through the oracle (aiming tolerance sqrt(eps) -> 1e-7 on errors)."""
