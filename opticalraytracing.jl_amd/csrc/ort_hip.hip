@@ -65,6 +65,10 @@ struct Scratch {
 };
 
 constexpr int kSmallTiles = 32;     // full_trace bundles of at most this many 512-ray tiles finish in one launch (k_ft_small_finish)
+constexpr int kSmallGridTiles = 256;  // full_trace launches of at most this many tiles (of <= kSmallTiles per bundle) trace one ray per lane:
+                                      // 8 waves per tile on 1024 SIMDs — beyond two waves per SIMD the two-ray form's lower instruction count wins
+constexpr size_t kZeroCopyBytes = (size_t)1 << 20;   // spot pipelines whose packed block [inputs | results] is at most this large run on the
+                                                     // pinned host block directly (no copy dispatches)
 constexpr int kSmallPairs = 256;    // spot pipelines of at most this many (system, field) pairs prepare in one launch (k_small_prepare)
 constexpr size_t kPackedVectorBytes = 32u << 20;   // host callers: error vectors up to this size come back in ONE copy
 
@@ -167,15 +171,15 @@ template <> struct Sel<float> {
 };
 
 // pick the kernel instantiation
-template <typename T, bool GRID, bool HIST, bool SUMM, int FT>
+template <typename T, bool GRID, bool HIST, bool SUMM, int FT, int RPT = kRPT>
 int launch_trace(ort_ctx* ctx, const TraceParams<T>& p, int64_t blocks, unsigned flags)
 {
     if (blocks <= 0) return ORT_OK;
     if (blocks > 0x7fffffffLL) return fail(ORT_EINVAL, "launch too large: %lld workgroups", (long long)blocks);
     const bool fast = flags & ORT_FAST_MATH;
-    dim3 g((unsigned)blocks), b(kBlock);
+    dim3 g((unsigned)blocks), b(kTile / RPT);
     // the build that carries the arms this batch's rows need (p.arms: ort_system::arms64 / arms32, surface_step_n)
-#define ORT_LAUNCH(M, A) hipLaunchKernelGGL((k_trace<T, M, A, GRID, HIST, SUMM, FT>), g, b, 0, ctx->stream, p)
+#define ORT_LAUNCH(M, A) hipLaunchKernelGGL((k_trace<T, M, A, GRID, HIST, SUMM, FT, RPT>), g, b, 0, ctx->stream, p)
     if (p.arms <= ARMS_BASIC)        { if (fast) ORT_LAUNCH(MATH_FAST, ARMS_BASIC);   else ORT_LAUNCH(MATH_IEEE, ARMS_BASIC); }
     else if (p.arms == ARMS_GENERAL) { if (fast) ORT_LAUNCH(MATH_FAST, ARMS_GENERAL); else ORT_LAUNCH(MATH_IEEE, ARMS_GENERAL); }
     else                             { if (fast) ORT_LAUNCH(MATH_FAST, ARMS_POLY);    else ORT_LAUNCH(MATH_IEEE, ARMS_POLY); }
@@ -413,6 +417,7 @@ int run_full_trace(ort_ctx* ctx, TraceParams<T>& p, int nb, T* ex, T* ey, T* rho
     const int64_t rpb = p.rpb, N = rpb * nb;
     const int64_t tiles = (int64_t)nb * p.tiles_per_bundle;
     if (tiles > 0x7fffffffLL) return fail(ORT_EINVAL, "launch too large");
+    const bool small_f64 = sizeof(T) == 8 && p.tiles_per_bundle <= kSmallTiles && tiles <= kSmallGridTiles && !(flags & ORT_NO_SMALL_PATH);
     int rc;
     rc = dev_out<int32_t>(ctx, SL_TCNT, (size_t)tiles, &p.tile_cnt); if (rc) return rc;
     rc = dev_out<double>(ctx, SL_TSX, (size_t)tiles, &p.tile_sx); if (rc) return rc;
@@ -427,7 +432,10 @@ int run_full_trace(ort_ctx* ctx, TraceParams<T>& p, int nb, T* ex, T* ey, T* rho
         // one pass: trace + stop filter + per-tile (n, mean, M2), merged per bundle — no ray-sized buffer at all
         rc = dev_out<double>(ctx, SL_TOFF, (size_t)tiles, &p.tile_m2x); if (rc) return rc;
         rc = dev_out<double>(ctx, SL_TSQ, (size_t)tiles, &p.tile_m2y); if (rc) return rc;
-        rc = launch_trace<T, true, false, false, FT_STATS>(ctx, p, tiles, flags); if (rc) return rc;
+        // bundles of a few tiles: a handful of waves, each alone on its SIMD — one ray per lane halves the time (k_trace)
+        if (small_f64) rc = launch_trace<T, true, false, false, FT_STATS, sizeof(T) == 8 ? 1 : kRPT>(ctx, p, tiles, flags);
+        else rc = launch_trace<T, true, false, false, FT_STATS>(ctx, p, tiles, flags);
+        if (rc) return rc;
         hipLaunchKernelGGL(k_ft_stats_reduce, dim3((unsigned)nb), dim3(kBlock), 0, ctx->stream,
                            p.tile_cnt, p.tile_sx, p.tile_sy, p.tile_m2x, p.tile_m2y, p.tile_rmax, p.tiles_per_bundle, dcount, drms);
         HIP_TRY(hipGetLastError());
@@ -459,7 +467,9 @@ int run_full_trace(ort_ctx* ctx, TraceParams<T>& p, int nb, T* ex, T* ey, T* rho
         rc = dev_out<T>(ctx, SL_WTH, nw, &wth); if (rc) return rc;
         rc = dev_out<int64_t>(ctx, SL_TOFF, (size_t)tiles, &tile_off); if (rc) return rc;
         p.out_ex = wex; p.out_ey = wey; p.out_r = wr; p.out_th = wth;
-        rc = launch_trace<T, true, false, false, FT_FULL>(ctx, p, tiles, flags); if (rc) return rc;
+        if (small_f64) rc = launch_trace<T, true, false, false, FT_FULL, sizeof(T) == 8 ? 1 : kRPT>(ctx, p, tiles, flags);
+        else rc = launch_trace<T, true, false, false, FT_FULL>(ctx, p, tiles, flags);
+        if (rc) return rc;
         if (p.tiles_per_bundle <= kSmallTiles && !(flags & ORT_NO_SMALL_PATH)) {
             // bundles of a few tiles (the reference's own call: 4): offsets, placement and sigma by one workgroup per bundle
             // in ONE launch, through the same bodies (k_ft_small_finish)
@@ -604,9 +614,14 @@ int spot_batch_impl(ort_ctx* ctx, int nsys, int rows, const double* R, const dou
                  o_fo = o_rms + (size_t)na * sizeof(double), o_vec = (o_fo + (size_t)nsys * sizeof(FirstOrderOut) + 255) & ~(size_t)255,
                  pack_bytes = o_vec + (packed_vec ? vec_bytes : 0);
     unsigned char* hpin = nullptr; unsigned char* dpack = nullptr;
+    // A small call (the reference's own: one system, one field, 2,048 rays) does not copy at all: its kernels read the
+    // inputs from, and write the results to, the pinned host block itself — two copy dispatches and their launch gaps
+    // (~2 x 4 us of a ~40 us device timeline, more on the host side) for a few PCIe round trips inside the kernels
+    const bool zero_copy = !devp && na <= kSmallPairs && !(flags & ORT_NO_SMALL_PATH) && pack_bytes <= kZeroCopyBytes;
     if (!devp) {
         rc = ctx->pinned(pack_bytes, &hpin); if (rc) return rc;      // no reuse inside the call, no mid-call sync
-        rc = dev_out<unsigned char>(ctx, SL_SB_PACK, pack_bytes, &dpack); if (rc) return rc;
+        if (zero_copy) { void* dp0 = nullptr; HIP_TRY(hipHostGetDevicePointer(&dp0, hpin, 0)); dpack = static_cast<unsigned char*>(dp0); }
+        else { rc = dev_out<unsigned char>(ctx, SL_SB_PACK, pack_bytes, &dpack); if (rc) return rc; }
         double* hp = reinterpret_cast<double*>(hpin); double* dp = reinterpret_cast<double*>(dpack);
         size_t o = 0;
         auto put = [&](const double* src, size_t cnt, const double** dev) { memcpy(hp + o, src, cnt * sizeof(double)); *dev = dp + o; o += cnt; };
@@ -615,7 +630,7 @@ int spot_batch_impl(ort_ctx* ctx, int nsys, int rows, const double* R, const dou
         if (ncoef > 0) put(coef, n_c, &dcoef);
         put(a, n_a, &da); put(hprime, (size_t)nsys, &dh); put(fields, (size_t)nfields, &dfields);
         memset(hpin + o_flag, 0, 16);                                // the flag travels with the inputs: no fill launch
-        HIP_TRY(hipMemcpyAsync(dpack, hpin, in_bytes + 16, hipMemcpyHostToDevice, ctx->stream));
+        if (!zero_copy) HIP_TRY(hipMemcpyAsync(dpack, hpin, in_bytes + 16, hipMemcpyHostToDevice, ctx->stream));
     }
     FirstOrderOut* d_fo; SurfRec<T>* d_rec; DevBundle<T>* d_bd; T* d_axes; int* d_flag; T* d_poly = nullptr;
     if (dpack) d_fo = reinterpret_cast<FirstOrderOut*>(dpack + o_fo);
@@ -687,7 +702,7 @@ int spot_batch_impl(ort_ctx* ctx, int nsys, int rows, const double* R, const dou
         rc = run_full_trace<T>(ctx, p, na, ex ? dv : (T*)nullptr, ex ? dv + slab : (T*)nullptr, ex ? dv + 2 * slab : (T*)nullptr,
                                ex ? dv + 3 * slab : (T*)nullptr, d_cnt, d_rms, flags | ORT_DEVICE_PTRS);
         if (rc) return rc;
-        HIP_TRY(hipMemcpyAsync(hpin + o_flag, dpack + o_flag, pack_bytes - o_flag, hipMemcpyDeviceToHost, st));
+        if (!zero_copy) HIP_TRY(hipMemcpyAsync(hpin + o_flag, dpack + o_flag, pack_bytes - o_flag, hipMemcpyDeviceToHost, st));
         HIP_TRY(hipStreamSynchronize(st));
         memcpy(count, hpin + o_cnt, (size_t)na * sizeof(int64_t));
         memcpy(rms, hpin + o_rms, (size_t)na * sizeof(double));
@@ -701,7 +716,7 @@ int spot_batch_impl(ort_ctx* ctx, int nsys, int rows, const double* R, const dou
         }
     } else {
         rc = run_full_trace<T>(ctx, p, na, ex, ey, rho, theta, count, rms, flags); if (rc) return rc;
-        HIP_TRY(hipMemcpyAsync(hpin + o_flag, dpack + o_flag, o_vec - o_flag, hipMemcpyDeviceToHost, st));
+        if (!zero_copy) HIP_TRY(hipMemcpyAsync(hpin + o_flag, dpack + o_flag, o_vec - o_flag, hipMemcpyDeviceToHost, st));
         HIP_TRY(hipStreamSynchronize(st));
     }
     if (fo_out) memcpy(fo_out, hpin + o_fo, (size_t)nsys * sizeof(FirstOrderOut));
@@ -832,6 +847,17 @@ int ort_device_free(ort_ctx* ctx, void* p)
     HIP_TRY(hipFree(p));
     return ORT_OK;
 }
+
+#ifdef ORT_PHASE_CLOCKS
+// measurement build only: the stamps of the last launches' block 0 (scripts/phase_clocks.py)
+extern "C" int ort_debug_phase_clocks(ort_ctx* ctx, unsigned long long* out32)
+{
+    int rc = check_ctx(ctx); if (rc) return rc;
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    HIP_TRY(hipMemcpyFromSymbol(out32, HIP_SYMBOL(ort::g_phase), 32 * sizeof(unsigned long long)));
+    return ORT_OK;
+}
+#endif
 
 // Testing aid (tests/test_gpu_parity.py): shift the context's look-back ticket base against the device counter — the
 // bookkeeping fault the look-back route must REPORT (ORT_EHIP) rather than misplace survivors.

@@ -23,6 +23,14 @@
 
 namespace ort {
 
+#ifdef ORT_PHASE_CLOCKS              // measurement build only (scripts/phase_clocks.py): shader-clock stamps of block 0
+__device__ unsigned long long g_phase[32];
+#define ORT_PHASE(i) do { if (blockIdx.x == 0 && threadIdx.x == 0) { g_phase[i] = __builtin_readcyclecounter(); g_phase[16 + (i)] = wall_clock64(); } } while (0)
+#else
+#define ORT_PHASE(i) do { } while (0)
+#endif
+
+
 // Tunables (compile-time; the defaults are the measured best).
 #ifndef ORT_RPT
 #define ORT_RPT 2            // rays per lane
@@ -185,18 +193,27 @@ enum { FT_NONE = 0, FT_FULL = 1, FT_STATS = 2, FT_LOOKBACK = 3 };
 constexpr int kStatusVignetted = 1 << 17, kStatusVigShift = 20;
 // ------------------------------------------------------------------------------------
 // ARMS: the row classes this build carries (surface_step_n): the batch's highest row decides (ort_system::arms).
-template <typename T, int MATH, int ARMS, bool GRID, bool HIST, bool SUMM, int FT>
-__global__ __launch_bounds__(kBlock, (ARMS == ARMS_POLY || (HIST && SUMM) || FT == 3 /* FT_LOOKBACK */) ? ORT_MIN_WAVES - 1 : HIST ? ORT_MIN_WAVES : ORT_WAVES_NOHIST)
+// RPT = rays per lane.  2 (kRPT) everywhere but the small-problem route (a bundle of a few tiles: the reference's own
+// call is 2,048 rays), whose launches are a handful of waves, each alone on its SIMD: there the time is the length of
+// one wave's instruction stream, and RPT = 1 — the same 512-ray tile on 512 threads — halves it.  Same results bit for
+// bit (the tile sums are taken in the RPT = 2 order, tile_sum2 below).
+template <typename T, int MATH, int ARMS, bool GRID, bool HIST, bool SUMM, int FT, int RPT = kRPT>
+__global__ __launch_bounds__(kTile / RPT, (ARMS == ARMS_POLY || (HIST && SUMM) || FT == 3 /* FT_LOOKBACK */) ? ORT_MIN_WAVES - 1 : HIST ? ORT_MIN_WAVES : ORT_WAVES_NOHIST)
 void k_trace(TraceParams<T> p)   // both outputs, look-back epilogue, polynomial arms: 128 VGPRs (at 96 they park tens of values per row in scratch)
 {
+    constexpr int NT = kTile / RPT;                              // threads per workgroup: one tile of kTile rays
+    constexpr int kSumWaves = kBlock / 64;                       // waves of the RPT = 2 shape: the order the tile sums are taken in
+    static_assert(RPT == 1 || RPT == 2, "one or two rays per lane");
     constexpr bool POLY = ARMS == ARMS_POLY;
     __shared__ SurfRec<T> s_rec[kMaxRows];
     __shared__ __attribute__((aligned(16))) T s_poly[POLY ? kMaxRows * kPolyLds : 1];
-    __shared__ int s_wcnt[kBlock / 64];
-    __shared__ double s_wsx[kBlock / 64], s_wsy[kBlock / 64], s_wmax[kBlock / 64];
+    __shared__ int s_wcnt[NT / 64];
+    __shared__ double s_wsx[kSumWaves], s_wsy[kSumWaves], s_wmax[NT / 64];
+    __shared__ double s_px[RPT == 1 ? NT / 64 : 1][32], s_py[RPT == 1 ? NT / 64 : 1][32];   // RPT = 1: pair sums (tile_sum2)
 
     const int tid = threadIdx.x;
     const int S = p.S;
+    ORT_PHASE(8);
     // FT_LOOKBACK: the tile index is a TICKET, not blockIdx — the look-back below waits on tiles with lower indices,
     // and a ticket order guarantees they are running or done whatever order the hardware dispatches blocks in
     constexpr bool kCompact = FT == FT_FULL || FT == FT_LOOKBACK;
@@ -231,12 +248,12 @@ void k_trace(TraceParams<T> p)   // both outputs, look-back epilogue, polynomial
         const int tile = bid - b * p.tiles_per_bundle;
         tile_base = (unsigned)tile * (unsigned)kTile;
         sysid = p.bundles[b].system;
-        j0 = (int64_t)tile * kTile + (int64_t)tid * kRPT;
+        j0 = (int64_t)tile * kTile + (int64_t)tid * RPT;
         limit = p.rpb;
         gbase = (int64_t)b * p.rpb + j0;
     } else {
         sysid = p.isys;
-        j0 = (int64_t)bid * kTile + (int64_t)tid * kRPT;
+        j0 = (int64_t)bid * kTile + (int64_t)tid * RPT;
         limit = p.nrays;
         gbase = j0;
     }
@@ -251,10 +268,10 @@ void k_trace(TraceParams<T> p)   // both outputs, look-back epilogue, polynomial
         constexpr int kW = sizeof(SurfRec<T>) / 16;
         const uint4* src = reinterpret_cast<const uint4*>(grec);
         uint4* dst = reinterpret_cast<uint4*>(s_rec);
-        for (int w = tid; w < S * kW; w += kBlock) dst[w] = src[w];
+        for (int w = tid; w < S * kW; w += NT) dst[w] = src[w];
         if (POLY && gpoly) {
             // kPolyLds values per row: the even form ev | qd for MATH_FAST on rows that have one, else pc | dc
-            for (int w = tid; w < S * kPolyLds; w += kBlock) {
+            for (int w = tid; w < S * kPolyLds; w += NT) {
                 const int row = w / kPolyLds, e = w - row * kPolyLds;
                 const bool even = MATH == MATH_FAST && (grec[row].cls & (CLS_PEVEN | CLS_FINITE)) == (CLS_PEVEN | CLS_FINITE);
                 s_poly[w] = gpoly[row * kPolyRec + ((even && e < 12) ? 24 + e : e)];
@@ -263,17 +280,18 @@ void k_trace(TraceParams<T> p)   // both outputs, look-back epilogue, polynomial
         __syncthreads();
     }
 
-    Ray<T> ray[kRPT];
-    bool live[kRPT];
-    int32_t st[kRPT];
-    T xs_[kRPT], ys_[kRPT];
+    ORT_PHASE(14);
+    Ray<T> ray[RPT];
+    bool live[RPT];
+    int32_t st[RPT];
+    T xs_[RPT], ys_[RPT];
     int stopi = -1;
     T hprime = T(0), a_stop = T(0);
     // (a lambda: a wave whose rays leave the domain of the fast forms launches them a second time, see below)
     auto launch_rays = [&](auto math) {
         constexpr int M = decltype(math)::value;
 #pragma unroll
-        for (int r = 0; r < kRPT; ++r) {
+        for (int r = 0; r < RPT; ++r) {
             const int64_t j = j0 + r;
             live[r] = j < limit;
             const int64_t jj = live[r] ? j : (limit - 1);   // clamp: dead lanes retrace a valid ray
@@ -285,7 +303,7 @@ void k_trace(TraceParams<T> p)   // both outputs, look-back epilogue, polynomial
                 unsigned iy, ix;
                 if (live[r] && p.nx >= 64) {
                     const unsigned iy0 = tile_base / (unsigned)p.nx;         // wave-uniform: scalar division
-                    ix = (tile_base - iy0 * (unsigned)p.nx) + (unsigned)(tid * kRPT + r);
+                    ix = (tile_base - iy0 * (unsigned)p.nx) + (unsigned)(tid * RPT + r);
                     iy = iy0;
                     while (ix >= (unsigned)p.nx) { ix -= (unsigned)p.nx; ++iy; }
                 } else {
@@ -315,14 +333,14 @@ void k_trace(TraceParams<T> p)   // both outputs, look-back epilogue, polynomial
         }
     };
     launch_rays(std::integral_constant<int, MATH>{});
-    const bool two = (kRPT > 1) && live[kRPT - 1];
+    const bool two = (RPT > 1) && live[RPT - 1];
     // History stores: one wave-uniform decision, taken once — every lane of the wave owns two live
     // rays and both row bases keep 16-byte alignment on every surface (ld even) -> plain
     // 16-byte stores off a scalar row base; otherwise the guarded per-lane path.
-    const int lane_off = tid * kRPT;
+    const int lane_off = tid * RPT;
     const int64_t blockbase = gbase - lane_off;                  // wave-uniform
     bool vec_all = false;
-    if (HIST && kRPT == 2) {
+    if (HIST && RPT == 2) {
         const bool al = ((reinterpret_cast<uintptr_t>(p.xv + gbase) | reinterpret_cast<uintptr_t>(p.yv + gbase)) &
                          (2 * sizeof(T) - 1)) == 0 && (p.ld & 1) == 0;
         vec_all = __all(two && al);
@@ -336,7 +354,7 @@ void k_trace(TraceParams<T> p)   // both outputs, look-back epilogue, polynomial
         bool odd = false;
         if (M == MATH_FAST) {                                    // Inf / NaN launch data: the reference just computes with
 #pragma unroll                                                   // them, and so does its own operation sequence (retrace)
-            for (int r = 0; r < kRPT; ++r)
+            for (int r = 0; r < RPT; ++r)
                 odd = odd || t_class(ray[r].x, kClassNonFinite) || t_class(ray[r].y, kClassNonFinite) ||
                       t_class(ray[r].k0 + ray[r].k1, kClassNonFinite);
         }
@@ -346,10 +364,10 @@ void k_trace(TraceParams<T> p)   // both outputs, look-back epilogue, polynomial
             // the staged block is laid out for the kernel's own policy; the (cold) MATH_IEEE retrace of a MATH_FAST kernel
             // reads its pc | dc block from the table itself
             const T* cf = (M == MATH) ? (s_poly + i * kPolyLds) : (gpoly ? gpoly + i * kPolyRec : nullptr);
-            surface_step_n<T, M, kRPT, ARMS>(ray, rec, cf, cls, i == S - 1, odd);
+            surface_step_n<T, M, RPT, ARMS>(ray, rec, cf, cls, i == S - 1, odd);
             if (SUMM || FT) {
 #pragma unroll
-                for (int r = 0; r < kRPT; ++r) {
+                for (int r = 0; r < RPT; ++r) {
                     // NaN is sticky (every later transfer propagates it), so the 1-based index of the first
                     // NaN surface is 1 + the number of surfaces with ordered (x, y): one v_cmp_o + one add.
                     st[r] += __builtin_isunordered(ray[r].x, ray[r].y) ? 0 : 1;
@@ -357,7 +375,7 @@ void k_trace(TraceParams<T> p)   // both outputs, look-back epilogue, polynomial
                 if (i == stop_u) {
                     const T a2 = a_stop * a_stop, alim = (T)Near<T>::thr * a2;
 #pragma unroll
-                    for (int r = 0; r < kRPT; ++r) {
+                    for (int r = 0; r < RPT; ++r) {
                         xs_[r] = ray[r].x; ys_[r] = ray[r].y;
                         // within kNear of the stop's edge the filter r > a_stop (:132) is decided by the reference sequence
                         if (M == MATH_FAST) odd = odd || near_zero<T>(t_fma<T>(xs_[r], xs_[r], t_fma<T>(ys_[r], ys_[r], -a2)), alim);
@@ -366,7 +384,7 @@ void k_trace(TraceParams<T> p)   // both outputs, look-back epilogue, polynomial
                 if (gap2) {                                          // scalar branch: one s_cbranch when off
                     const T a2 = gap2[i];
 #pragma unroll
-                    for (int r = 0; r < kRPT; ++r) {
+                    for (int r = 0; r < RPT; ++r) {
                         // bit 17: outside the clear aperture of some surface; bits 20..27 count the surfaces
                         // passed before that -> 1-based index of the first vignetting surface = count + 1
                         const T r2 = ray[r].x * ray[r].x + ray[r].y * ray[r].y;
@@ -380,11 +398,11 @@ void k_trace(TraceParams<T> p)   // both outputs, look-back epilogue, polynomial
                 if (vec_all) {
                     T* rx = p.xv + ((int64_t)i * p.ld + blockbase);  // scalar row base
                     T* ry = p.yv + ((int64_t)i * p.ld + blockbase);
-                    store_vec2<T>(rx + lane_off, ray[0].x, ray[kRPT - 1].x);
-                    store_vec2<T>(ry + lane_off, ray[0].y, ray[kRPT - 1].y);
+                    store_vec2<T>(rx + lane_off, ray[0].x, ray[RPT - 1].x);
+                    store_vec2<T>(ry + lane_off, ray[0].y, ray[RPT - 1].y);
                 } else if (live[0]) {
-                    store_pair<T>(p.xv + (int64_t)i * p.ld, gbase, two, ray[0].x, ray[kRPT - 1].x);
-                    store_pair<T>(p.yv + (int64_t)i * p.ld, gbase, two, ray[0].y, ray[kRPT - 1].y);
+                    store_pair<T>(p.xv + (int64_t)i * p.ld, gbase, two, ray[0].x, ray[RPT - 1].x);
+                    store_pair<T>(p.yv + (int64_t)i * p.ld, gbase, two, ray[0].y, ray[RPT - 1].y);
                 }
             }
         }
@@ -402,6 +420,7 @@ void k_trace(TraceParams<T> p)   // both outputs, look-back epilogue, polynomial
         trace_surfaces(std::integral_constant<int, MATH_IEEE>{});
     }
 
+    ORT_PHASE(15);
     // The stop filter r > a_stop (PupilSampling.jl:131-132).  The reference sequence takes hypot.  MATH_FAST decides by
     // r^2 against a_stop^2 — the same outcome for every ray farther than kNear from the edge — and only the rays within
     // kNear of it (their wave has retraced with the reference sequence, see the stop capture above) take the hypot.
@@ -416,13 +435,13 @@ void k_trace(TraceParams<T> p)   // both outputs, look-back epilogue, polynomial
 
     if (SUMM) {
         if (live[0]) {
-            if (p.xf) store_pair<T>(p.xf, gbase, two, ray[0].x, ray[kRPT - 1].x);
-            if (p.yf) store_pair<T>(p.yf, gbase, two, ray[0].y, ray[kRPT - 1].y);
-            if (p.xs) store_pair<T>(p.xs, gbase, two, xs_[0], xs_[kRPT - 1]);
-            if (p.ys) store_pair<T>(p.ys, gbase, two, ys_[0], ys_[kRPT - 1]);
+            if (p.xf) store_pair<T>(p.xf, gbase, two, ray[0].x, ray[RPT - 1].x);
+            if (p.yf) store_pair<T>(p.yf, gbase, two, ray[0].y, ray[RPT - 1].y);
+            if (p.xs) store_pair<T>(p.xs, gbase, two, xs_[0], xs_[RPT - 1]);
+            if (p.ys) store_pair<T>(p.ys, gbase, two, ys_[0], ys_[RPT - 1]);
             if (p.status) {
 #pragma unroll
-                for (int r = 0; r < kRPT; ++r) {
+                for (int r = 0; r < RPT; ++r) {
                     if (!live[r]) continue;
                     int32_t s = st[r];
                     if (stopi >= 0) {
@@ -440,10 +459,10 @@ void k_trace(TraceParams<T> p)   // both outputs, look-back epilogue, polynomial
         // 64-bit ballots + popcount prefix per wave, wave offsets through LDS) and streamed to the first half of
         // the bundle's output slab; FT_STATS: per-tile moments only.
         int cnt = 0; double sx = 0.0, sy = 0.0, rmax = -1.0;
-        T exv[kRPT], eyv[kRPT], rv[kRPT], thv[kRPT];
-        bool keep[kRPT];
+        T exv[RPT], eyv[RPT], rv[RPT], thv[RPT];
+        bool keep[RPT];
 #pragma unroll
-        for (int r = 0; r < kRPT; ++r) {
+        for (int r = 0; r < RPT; ++r) {
             const T xf = ray[r].x, yf = ray[r].y;
             T r2;
             const bool outside = outside_stop(xs_[r], ys_[r], r2);                        // :131-132
@@ -464,33 +483,55 @@ void k_trace(TraceParams<T> p)   // both outputs, look-back epilogue, polynomial
         int rank0 = 0;
         if (kCompact) {
             const unsigned long long m0 = __ballot(keep[0]);
-            const unsigned long long m1 = (kRPT > 1) ? __ballot(keep[kRPT - 1]) : 0ull;
+            const unsigned long long m1 = (RPT > 1) ? __ballot(keep[RPT - 1]) : 0ull;
             const unsigned long long lt = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
             rank0 = __popcll(m0 & lt) + __popcll(m1 & lt);
         }
-        // tile aggregates: fixed-shape tree -> bitwise reproducible
+        // tile aggregates: fixed-shape tree -> bitwise reproducible.  The floating-point sums are taken in ONE order whatever
+        // RPT is — that of the two-rays-per-lane shape: a lane's two rays, a 64-lane shuffle tree over each group of 128
+        // rays (-> s_wsx / s_wsy[group]), the groups in sequence by whoever reads them.  With one ray per lane a group
+        // spans two waves: neighbouring lanes pair up, the pair sums meet in LDS, and the tree continues from its second level.
+        auto tile_sum2 = [&](double x, double y) {
+            if constexpr (RPT == 2) {
+                for (int off = 32; off > 0; off >>= 1) { x += __shfl_down(x, off); y += __shfl_down(y, off); }
+                if (lane == 0) { s_wsx[wave] = x; s_wsy[wave] = y; }
+            } else {
+                x += __shfl_xor(x, 1); y += __shfl_xor(y, 1);            // a + b on both lanes of the pair: the same bits
+                if (!(lane & 1)) { s_px[wave][lane >> 1] = x; s_py[wave][lane >> 1] = y; }
+                __syncthreads();
+                if (wave < kSumWaves) {
+                    double qx = 0.0, qy = 0.0;
+                    if (lane < 32) {                                     // the tree's first level: lanes l and l + 32 of the group
+                        qx = s_px[2 * wave][lane] + s_px[2 * wave + 1][lane];
+                        qy = s_py[2 * wave][lane] + s_py[2 * wave + 1][lane];
+                    }
+                    for (int off = 16; off > 0; off >>= 1) { qx += __shfl_down(qx, off); qy += __shfl_down(qy, off); }
+                    if (lane == 0) { s_wsx[wave] = qx; s_wsy[wave] = qy; }
+                }
+            }
+        };
         for (int off = 32; off > 0; off >>= 1) {
             cnt += __shfl_down(cnt, off);
-            sx += __shfl_down(sx, off);
-            sy += __shfl_down(sy, off);
             rmax = fmax(rmax, __shfl_down(rmax, off));
         }
-        if (lane == 0) { s_wcnt[wave] = cnt; s_wsx[wave] = sx; s_wsy[wave] = sy; s_wmax[wave] = rmax; }
+        if (lane == 0) { s_wcnt[wave] = cnt; s_wmax[wave] = rmax; }
+        tile_sum2(sx, sy);
         __syncthreads();
         if (kCompact) {
             __shared__ __attribute__((aligned(16))) T s_cx[kCompact ? kTile : 1], s_cy[kCompact ? kTile : 1], s_cr[kCompact ? kTile : 1], s_ct[kCompact ? kTile : 1];
             __shared__ long long s_base;
             int woff = 0, c = 0;
-            for (int w = 0; w < kBlock / 64; ++w) { woff += (w < wave) ? s_wcnt[w] : 0; c += s_wcnt[w]; }
+            for (int w = 0; w < NT / 64; ++w) { woff += (w < wave) ? s_wcnt[w] : 0; c += s_wcnt[w]; }
             int k = woff + rank0;
 #pragma unroll
-            for (int r = 0; r < kRPT; ++r)
+            for (int r = 0; r < RPT; ++r)
                 if (keep[r]) { s_cx[k] = exv[r]; s_cy[k] = eyv[r]; s_cr[k] = rv[r]; s_ct[k] = thv[r]; ++k; }
             const int tile = (int)(bid - (unsigned)b * (unsigned)p.tiles_per_bundle);
             if (FT == FT_FULL) {
                 if (tid == 0) {
                     double ax = 0.0, ay = 0.0, mx = -1.0;
-                    for (int w = 0; w < kBlock / 64; ++w) { ax += s_wsx[w]; ay += s_wsy[w]; mx = fmax(mx, s_wmax[w]); }
+                    for (int w = 0; w < kSumWaves; ++w) { ax += s_wsx[w]; ay += s_wsy[w]; }
+                    for (int w = 0; w < NT / 64; ++w) mx = fmax(mx, s_wmax[w]);
                     p.tile_cnt[bid] = c; p.tile_sx[bid] = ax; p.tile_sy[bid] = ay; p.tile_rmax[bid] = mx;
                 }
             } else if (wave == 0) {
@@ -498,7 +539,8 @@ void k_trace(TraceParams<T> p)   // both outputs, look-back epilogue, polynomial
                 // the bundle's earlier tiles, 64 at a time.  One 8-byte word per tile carries everything, so relaxed
                 // agent-scope atomics suffice: state 1 = the tile's own count, state 2 = inclusive prefix.
                 double ax = 0.0, ay = 0.0, mx = -1.0;
-                for (int w = 0; w < kBlock / 64; ++w) { ax += s_wsx[w]; ay += s_wsy[w]; mx = fmax(mx, s_wmax[w]); }
+                for (int w = 0; w < kSumWaves; ++w) { ax += s_wsx[w]; ay += s_wsy[w]; }
+                for (int w = 0; w < NT / 64; ++w) mx = fmax(mx, s_wmax[w]);
                 const unsigned long long ep = (unsigned long long)(p.ft_epoch & 0x3fffffffu) << 32;
                 unsigned long long* stw = p.ft_state + (size_t)b * p.tiles_per_bundle;
                 if (lane == 0) {
@@ -561,7 +603,7 @@ void k_trace(TraceParams<T> p)   // both outputs, look-back epilogue, polynomial
                 constexpr int V = 16 / (int)sizeof(T);
                 typedef T vec_t __attribute__((ext_vector_type(V)));
                 const int64_t o0 = (int64_t)bid * kTile;
-                for (int j = tid * V; j < c; j += kBlock * V) {
+                for (int j = tid * V; j < c; j += NT * V) {
                     *reinterpret_cast<vec_t*>(p.out_ex + o0 + j) = *reinterpret_cast<const vec_t*>(s_cx + j);
                     *reinterpret_cast<vec_t*>(p.out_ey + o0 + j) = *reinterpret_cast<const vec_t*>(s_cy + j);
                     *reinterpret_cast<vec_t*>(p.out_r + o0 + j) = *reinterpret_cast<const vec_t*>(s_cr + j);
@@ -579,23 +621,23 @@ void k_trace(TraceParams<T> p)   // both outputs, look-back epilogue, polynomial
             // then squared deviations about them; tiles are merged with Chan's update in k_ft_stats_reduce —
             // as stable as the reference's two-pass sigma (:169-173), without a second pass over memory.
             int c = 0; double ax = 0.0, ay = 0.0, mx = -1.0;
-            for (int w = 0; w < kBlock / 64; ++w) { c += s_wcnt[w]; ax += s_wsx[w]; ay += s_wsy[w]; mx = fmax(mx, s_wmax[w]); }
+            for (int w = 0; w < kSumWaves; ++w) { ax += s_wsx[w]; ay += s_wsy[w]; }
+            for (int w = 0; w < NT / 64; ++w) { c += s_wcnt[w]; mx = fmax(mx, s_wmax[w]); }
             const double mux = c ? ax / (double)c : 0.0, muy = c ? ay / (double)c : 0.0;
             double qx = 0.0, qy = 0.0;
 #pragma unroll
-            for (int r = 0; r < kRPT; ++r) {
+            for (int r = 0; r < RPT; ++r) {
                 if (!(rv[r] < T(0))) {
                     const double dx = (double)exv[r] - mux, dy = (double)eyv[r] - muy;
                     qx += dx * dx; qy += dy * dy;
                 }
             }
-            for (int off = 32; off > 0; off >>= 1) { qx += __shfl_down(qx, off); qy += __shfl_down(qy, off); }
             __syncthreads();                                     // s_wsx / s_wsy are reused below
-            if ((tid & 63) == 0) { s_wsx[wave] = qx; s_wsy[wave] = qy; }
+            tile_sum2(qx, qy);
             __syncthreads();
             if (tid == 0) {
                 double tx = 0.0, ty = 0.0;
-                for (int w = 0; w < kBlock / 64; ++w) { tx += s_wsx[w]; ty += s_wsy[w]; }
+                for (int w = 0; w < kSumWaves; ++w) { tx += s_wsx[w]; ty += s_wsy[w]; }
                 p.tile_cnt[blockIdx.x] = c; p.tile_sx[blockIdx.x] = mux; p.tile_sy[blockIdx.x] = muy;
                 p.tile_m2x[blockIdx.x] = tx; p.tile_m2y[blockIdx.x] = ty; p.tile_rmax[blockIdx.x] = mx;
             }
@@ -950,15 +992,19 @@ __global__ __launch_bounds__(kBlock * kFinishGroups) void k_ft_small_finish(cons
     __shared__ FtPlaceShared<T> ps[kFinishGroups];
     __shared__ double s_r[kBlock];
     const int b = blockIdx.x, tid = threadIdx.x & (kBlock - 1), grp = threadIdx.x / kBlock;
+    ORT_PHASE(10);
     ft_scan_body(b, tile_cnt, tile_sx, tile_sy, tile_rmax, tiles_per_bundle, tile_off, agg, ss, tid, grp == 0);
     __syncthreads();                                             // tile_off, agg[b]: written above, read below by this workgroup
+    ORT_PHASE(11);
     for (int tile0 = 0; tile0 < tiles_per_bundle; tile0 += kFinishGroups) {
         const int tile = tile0 + grp;
         ft_place_body<T>(b * tiles_per_bundle + tile, w_ex, w_ey, w_r, w_th, rpb, tiles_per_bundle, tile_cnt, tile_off, agg,
                          ex, ey, rho, theta, tile_sq, ps[grp], tid, tile < tiles_per_bundle);
         __syncthreads();                                         // the staging buffers are reused; tile_sq is read below
     }
+    ORT_PHASE(12);
     ft_finalize_body(b, tile_sq, tiles_per_bundle, agg, count, rms, nullptr, s_r, tid, grp == 0);
+    ORT_PHASE(13);
 }
 
 // ------------------------------------------------------------------------------------
@@ -1137,29 +1183,34 @@ __device__ inline MerEnd mer_plain_trace_to(const MerSurf* __restrict__ surf, in
     MerEnd e;
     e.y_stop = __builtin_nan(""); e.y_first = y; e.U_last = 0.0;
     double sprev = 0.0, z = 0.0, zp = 0.0;
+    MerSurf nx = surf[0];
     for (int i = 0; i < S; ++i) {
-        const MerSurf s = surf[i];
+        const MerSurf s = nx;
+        nx = surf[i + 1 < S ? i + 1 : i];                             // the next row's record is fetched under this row's arithmetic
         const double tcur = s.t - sprev;                              // ts[i] after :161
-        const double eta = s.eta;
+        // row constants (independent of the ray: they fill the issue slots the ray's dependent chain leaves empty)
+        const double eta = s.eta, eta2 = eta * eta, ome2 = 1.0 - eta2;
         double sg;
         if (s.finite) {
-            const double Qz0 = -tcur - s.R;                           // the ray point relative to the centre of curvature
-            const double b = Qz0 * cU + y * sU;
-            const double disc = b * b - (Qz0 * Qz0 + y * y) + s.R * s.R;
+            const double R2 = s.R * s.R, e2c2 = eta2 * (s.invR * s.invR), ec = eta * __builtin_fabs(s.invR);
+            const double Qz0 = sprev - (s.t + s.R);                   // the ray point relative to the centre of curvature
+            const double b = __builtin_fma(Qz0, cU, y * sU);
+            const double disc = __builtin_fma(b, b, R2 - __builtin_fma(Qz0, Qz0, y * y));
+            // cos^2 I = disc / R^2: the second root's radicand does not wait for the first root
+            const double D2 = __builtin_fma(e2c2, disc, ome2);
             const double sq = aim_sqrt(disc);                         // NaN: the ray misses (:83)
-            const double d = -b - s.sgn * sq;
-            y = y + d * sU;
-            const double Qz = Qz0 + d * cU;
+            const double cr = aim_sqrt(D2);                           // D2 < 0: total internal reflection -> NaN (:164)
+            const double d = -__builtin_fma(s.sgn, sq, b);
+            y = __builtin_fma(d, sU, y);
+            const double Qz = __builtin_fma(d, cU, Qz0);
             sg = Qz + s.R;                                            // sag (:155)
-            const double cosi = __builtin_fabs(s.invR) * sq;          // cos I = |Q . k| / |R|
-            const double D2 = (1.0 - eta * eta) + eta * eta * cosi * cosi;
-            const double gc = (aim_sqrt(D2) - eta * cosi) * s.invR;   // D2 < 0: total internal reflection -> NaN (:164)
-            sU = eta * sU - gc * y;
-            cU = eta * cU - gc * Qz;
+            const double gc = __builtin_fma(-ec, sq, cr) * s.invR;    // (cos I' - eta cos I) / R,  cos I = |Q . k| / |R|
+            sU = __builtin_fma(-gc, y, eta * sU);
+            cU = __builtin_fma(-gc, Qz, eta * cU);
         } else {
-            y = y + (sU * fast_rcp(cU)) * tcur;                       // :152
+            y = __builtin_fma(sU * fast_rcp(cU), tcur, y);            // :152
             sg = 0.0;                                                 // :86
-            const double D2 = (1.0 - eta * eta) + eta * eta * cU * cU;
+            const double D2 = __builtin_fma(eta2 * cU, cU, ome2);
             sU = eta * sU;                                            // normal (0, 1): only the axial component refracts
             cU = aim_sqrt(D2);
         }
@@ -1197,7 +1248,9 @@ __device__ __forceinline__ void pair_newton(F&& trace, double& v, double target,
     int it = 0;
     e.y_stop = e.y_last = e.U_last = e.z_last = e.z_prev = e.y_first = e.s_last = 0.0;
     while (true) {
+        ORT_PHASE(4);
         if (!conv) e = trace(pert ? v + eps : v);
+        ORT_PHASE(9);
         const double L = e.y_stop - target;
         const double L0 = __shfl(L, pairbase, 4), L1 = __shfl(L, pairbase + 1, 4);
         if (!conv) {
@@ -1238,15 +1291,22 @@ __device__ inline AimOut aim_group(const AimIn& a, int role, const MerSurf* __re
     double v = pair == 0 ? -a.chief_u_end : a.y_marg;            // :280 | :225
     MerEnd e; double loss = 0.0;
     double sv = 0.0, cv = 1.0;                                   // sin / cos of the chief pair's last launch angle (plain path)
+    // ONE call for both pairs (lane-selected table and launch data): two calls would run one after the other
+    const bool chief = pair == 0;
+    const MerSurf* tab = chief ? Rv : F;
+    const double* ctab = chief ? cR : cF;
+    const double tl1 = chief ? tlR : tlF;
+    const int stop1 = chief ? stop_rev : a.stop, lay1 = chief ? a.layout_rev : a.layout_fwd;
     pair_newton([&](double w) {
                     if (plain) {
-                        if (pair != 0) return mer_plain_trace_to(F, S, tlF, w, 0.0, 1.0, a.stop);
-                        aim_sincos(w, sv, cv);
-                        return mer_plain_trace_to(Rv, S, tlR, ybp, sv, cv, stop_rev);
+                        double s1, c1;
+                        aim_sincos(chief ? w : 0.0, s1, c1);              // the marginal ray is launched along the axis: (0, 1) exactly
+                        if (chief) { sv = s1; cv = c1; }
+                        return mer_plain_trace_to(tab, S, tl1, chief ? ybp : w, s1, c1, stop1);
                     }
-                    return pair == 0 ? mer_trace_to(Rv, cR, S, ncoef, a.layout_rev, tlR, ybp, w, stop_rev)
-                                     : mer_trace_to(F, cF, S, ncoef, a.layout_fwd, tlF, w, 0.0, a.stop);
+                    return mer_trace_to(tab, ctab, S, ncoef, lay1, tl1, chief ? ybp : w, chief ? w : 0.0, stop1);
                 }, v, pair == 0 ? 0.0 : a.a_stop, a.atol, 200, true, pairbase, role, e, loss, iters, ok);
+    ORT_PHASE(3);
     // results live on the base lanes: chief on lane 0, marginal on lane 2
     double ub1, t_ub1, t_v0;                                     // ū[1], tan(ū[1]), tan(-launch angle of the reversed trace)
     if (plain) {                                                 // the tangents are quotients of what the trace carries; the angle
@@ -1276,8 +1336,10 @@ __device__ inline AimOut aim_group(const AimIn& a, int role, const MerSurf* __re
     const double y0 = (pair == 0 ? y_EP : -y_EP) - u * EP_t;     // :99
     double yy = y0;
     int ok2 = 1;
-    pair_newton([&](double w) { return plain ? mer_plain_trace_to(F, S, tlF, w, sinU, cosU, a.stop)
-                                             : mer_trace_to(F, cF, S, ncoef, a.layout_fwd, tlF, w, U, a.stop); },
+    ORT_PHASE(5);
+    // only ray.y[begin+stop] feeds the loss (PupilSampling.jl:70,76): the traces of this search end at the stop
+    pair_newton([&](double w) { return plain ? mer_plain_trace_to(F, a.stop, tlF, w, sinU, cosU, a.stop)
+                                             : mer_trace_to(F, cF, a.stop, ncoef, a.layout_fwd, tlF, w, U, a.stop); },
                 yy, target, a.atol, 100, false, pairbase, role, e, loss, iters, ok2, edge_inside);
     if (!(fabs(loss) <= 1e300)) yy = y0;                         // isnan(Δ) ? Inf : Δ keeps the start point (:72,78)
     AimOut o;
@@ -1451,24 +1513,33 @@ enum { SURF_SPHERICAL = 0, SURF_COMA, SURF_ASTIGMATISM, SURF_SAGITTAL, SURF_DIST
 // kernel (k_small_prepare), where their latency is on the critical path.
 struct FirstOrderWork { double *tau, *phi, *y1, *w1, *y2, *w2, *yc, *wc; };
 
-// solve(surfaces, a, h') + aberrations(...) of ONE system g of the batch (see k_first_order below).
-__device__ __forceinline__ void first_order_core(int g, int nsys, int rows, const double* __restrict__ R, const double* __restrict__ t,
-                                                 const double* __restrict__ n, const double* __restrict__ a,
-                                                 const double* __restrict__ dn, double h, double lam, const FirstOrderWork& W,
-                                                 FirstOrderOut& o, double* __restrict__ surf, double* __restrict__ inc)
+// solve(surfaces, a, h') of ONE system: Lens, the two paraxial traces, stop, marginal and chief rays, first-order
+// properties (everything of FirstOrderOut but the Seidel sums).  R, t, n, a: the system's own columns (global or LDS).
+// WAVE = false: one thread does it all (k_first_order: one system per thread).  WAVE = true: the 64 lanes of a
+// one-wave workgroup share ONE system whose work arrays live in LDS (k_small_prepare) — the element-wise stages
+// (tau / phi, a ./ y, the scaling, the chief arrays: a division or two per element) run one lane per element, the
+// recurrences and the scalar tail on lane 0; the same operations on the same values either way, `o` valid on lane 0.
+template <bool WAVE>
+__device__ __forceinline__ void first_order_paraxial(int lane, int rows, const double* __restrict__ R, const double* __restrict__ t,
+                                                     const double* __restrict__ n, const double* __restrict__ a,
+                                                     double h, const FirstOrderWork& W, FirstOrderOut& o)
 {
     double* tau = W.tau; double* phi = W.phi; double* y1 = W.y1; double* w1 = W.w1; double* y2 = W.y2; double* w2 = W.w2;
     double* yc = W.yc; double* wc = W.wc;
+    const int step = WAVE ? 64 : 1;
+    const bool lead = !WAVE || lane == 0;
+    auto sync = [&]() { if (WAVE) __syncthreads(); };
     // Lens(surfaces)  RayTracing.jl:38-53
-    for (int i = 0; i < rows; ++i) {
+    for (int i = lane; i < rows; i += step) {
         const double ti = (i == 0 && !__builtin_isfinite(t[0])) ? 0.0 : t[i];      // :42
         tau[i] = ti / n[i];                                                          // :43
         phi[i] = (i < rows - 1) ? (n[i + 1] - n[i]) / R[i + 1] : 0.0;               // :45,50
     }
+    sync();
     const double tl = t[rows - 1];
     const int k = (tl == 0.0 || !__builtin_isfinite(tl)) ? rows - 1 : rows;          // :47-48
     // paraxial traces (1, 0) and (0, 1)  :127-141
-    {
+    if (lead) {
         double ya = 1.0, wa = 0.0, yb = 0.0, wb = 1.0;
         y1[0] = ya; w1[0] = wa; y2[0] = yb; w2[0] = wb;
         for (int i = 0; i < k; ++i) {
@@ -1478,6 +1549,7 @@ __device__ __forceinline__ void first_order_core(int g, int nsys, int rows, cons
             y1[i + 1] = ya; w1[i + 1] = wa; y2[i + 1] = yb; w2[i + 1] = wb;
         }
     }
+    sync();
     o.k = k;
     o.f = -(1.0 / w1[k]);                                                            // :213
     o.EBFD = y1[k] * o.f;                                                            // :214
@@ -1485,23 +1557,28 @@ __device__ __forceinline__ void first_order_core(int g, int nsys, int rows, cons
     // throws a DimensionMismatch otherwise: the host entry points reject k == rows, the bound keeps a device-pointer
     // caller inside its own system's slab
     const int ka = k < rows - 1 ? k : rows - 1;
-    int stop = 0; double s = a[0] / y1[1];
-    for (int i = 1; i < ka; ++i) { const double sv = a[i] / y1[i + 1]; if (sv < s) { s = sv; stop = i; } }   // findmin :215-216
+    for (int i = lane; i < ka; i += step) yc[i] = a[i] / y1[i + 1];                  // sv, parked in the chief array (free until :258)
+    sync();
+    int stop = 0; double s = yc[0];
+    for (int i = 1; i < ka; ++i) { const double sv = yc[i]; if (sv < s) { s = sv; stop = i; } }   // findmin :215-216
     o.stop = stop + 1;
-    for (int i = 0; i <= k; ++i) { y1[i] *= s; w1[i] *= s; }                         // :217
-    w1[k + 1] = w1[k]; y1[k + 1] = (w1[k] == 0.0) ? y1[k] : 0.0;                     // extend :202-206
+    sync();
+    for (int i = lane; i <= k; i += step) { y1[i] *= s; w1[i] *= s; }                // :217
+    sync();
+    if (lead) { w1[k + 1] = w1[k]; y1[k + 1] = (w1[k] == 0.0) ? y1[k] : 0.0; }       // extend :202-206
+    sync();
     // chief  :246-263
     const double y_stop = y1[stop + 1], y2_stop = y2[stop + 1];
     const double nub = -w1[k + 1] * h / y1[1];                                       // :256
-    yc[0] = 0.0; wc[0] = nub;                                                        // :259
-    for (int i = 1; i <= k; ++i) {                                                   // :258
+    for (int i = 1 + lane; i <= k; i += step) {                                      // :258
         yc[i] = nub * (y2[i] - y1[i] * y2_stop / y_stop);
         wc[i] = nub * (w2[i] - w1[i] * y2_stop / y_stop);
     }
-    yc[k + 1] = h; wc[k + 1] = wc[k];                                                // :260
+    sync();
+    if (lead) { yc[0] = 0.0; wc[0] = nub; yc[k + 1] = h; wc[k + 1] = wc[k]; }        // :259,260
+    sync();
     // _solve  :302-323
     const double ybar = yc[1], nubp = wc[k + 1], ym = y1[0], ybpb = yc[k];
-    const double dp = o.EBFD - o.f;
     const double d = (h - nubp * o.f - ybar) / nub;
     o.EFFD = d - o.f;
     o.PN = (n[rows - 1] - n[0]) * o.f;
@@ -1511,27 +1588,53 @@ __device__ __forceinline__ void first_order_core(int g, int nsys, int rows, cons
     o.N = fabs(o.f / o.EP_D);
     auto next = [&](int i) { return n[i < rows ? i : rows - 1]; };                   // n = [n; n[end]]  Types.jl:39
     o.FOV = 2.0 * (::atan(fabs(wc[0] / next(0))) * 57.29577951308232);               // 2atand  :319
-    (void)dp;
     o.y_marg = ym; o.chief_y_end = yc[k + 1]; o.chief_u_end = wc[k + 1] / next(k + 1); o.nu_end = w1[k + 1];
     o.BFD = -y1[k] / (w1[k] / next(k));                                              // Types.jl:44 (t[end] of the marginal)
-    // aberrations  SeidelAberrations.jl:6-53
+}
+
+// aberrations, SeidelAberrations.jl:6-53: the contributions of surface i (loop index, row i + 1) from the marginal and
+// chief arrays first_order_paraxial left in W.  Independent per surface: the small-problem kernel runs them one lane
+// each; the sums are taken in surface order either way (seidel_accumulate).
+struct SeidelTerms { double sph, coma, ast, ptz, dist, axl, lat; };
+__device__ __forceinline__ SeidelTerms seidel_terms(int i, int rows, const double* __restrict__ R, const double* __restrict__ n,
+                                                    const double* __restrict__ dn, double H, double lam, const FirstOrderWork& W,
+                                                    double& A_out)
+{
+    const double* y1 = W.y1; const double* w1 = W.w1; const double* yc = W.yc;
+    auto next = [&](int j) { return n[j < rows ? j : rows - 1]; };
+    const double ni = next(i), nj = next(i + 1), yi = y1[i + 1], ybi = yc[i + 1], Ri = R[i + 1];
+    const double ui = w1[i] / ni, uj = w1[i + 1] / nj;
+    const double A = w1[i] + ni * yi / Ri;
+    const double Ab = (H + A * ybi) / yi;
+    const double yD = yi * (uj / nj - ui / ni);
+    const double yd = dn ? yi * (dn[i + 1] / nj - dn[i] / ni) : 0.0;
+    const double inj = 1.0 / nj, ini = 1.0 / ni;
+    const double Dn2 = inj * inj - ini * ini;
+    const double P = (inj - ini) / Ri;
+    SeidelTerms q;
+    q.sph = -(A * A) * yD / (8.0 * lam);
+    q.coma = -A * Ab * yD / (2.0 * lam);
+    q.ast = -(Ab * Ab) * yD / (2.0 * lam);
+    q.ptz = -(H * H) * P / (4.0 * lam);
+    q.dist = -Ab * ((Ab * Ab) * yi * Dn2 - (H + Ab * yi) * ybi * P) / (2.0 * lam);
+    q.axl = A * yd / (2.0 * lam); q.lat = Ab * yd / lam;
+    A_out = A;
+    return q;
+}
+
+// solve(surfaces, a, h') + aberrations(...) of ONE system g of the batch (see k_first_order below).
+__device__ __forceinline__ void first_order_core(int g, int nsys, int rows, const double* __restrict__ R, const double* __restrict__ t,
+                                                 const double* __restrict__ n, const double* __restrict__ a,
+                                                 const double* __restrict__ dn, double h, double lam, const FirstOrderWork& W,
+                                                 FirstOrderOut& o, double* __restrict__ surf, double* __restrict__ inc)
+{
+    first_order_paraxial<false>(0, rows, R, t, n, a, h, W, o);
+    auto next = [&](int i) { return n[i < rows ? i : rows - 1]; };                   // n = [n; n[end]]  Types.jl:39
     double W040 = 0, W131 = 0, W222 = 0, W311 = 0, W220P = 0, W020 = 0, W111 = 0;
     for (int i = 0; i < rows - 1; ++i) {
-        const double ni = next(i), nj = next(i + 1), yi = y1[i + 1], ybi = yc[i + 1], Ri = R[i + 1];
-        const double ui = w1[i] / ni, uj = w1[i + 1] / nj;
-        const double A = w1[i] + ni * yi / Ri;
-        const double Ab = (o.H + A * ybi) / yi;
-        const double yD = yi * (uj / nj - ui / ni);
-        const double yd = dn ? yi * (dn[i + 1] / nj - dn[i] / ni) : 0.0;
-        const double inj = 1.0 / nj, ini = 1.0 / ni;
-        const double Dn2 = inj * inj - ini * ini;
-        const double P = (inj - ini) / Ri;
-        const double sph = -(A * A) * yD / (8.0 * lam);
-        const double coma = -A * Ab * yD / (2.0 * lam);
-        const double ast = -(Ab * Ab) * yD / (2.0 * lam);
-        const double ptz = -(o.H * o.H) * P / (4.0 * lam);
-        const double dist = -Ab * ((Ab * Ab) * yi * Dn2 - (o.H + Ab * yi) * ybi * P) / (2.0 * lam);
-        const double axl = A * yd / (2.0 * lam), lat = Ab * yd / lam;
+        double A;
+        const SeidelTerms q = seidel_terms(i, rows, R, n, dn, o.H, lam, W, A);
+        const double sph = q.sph, coma = q.coma, ast = q.ast, ptz = q.ptz, dist = q.dist, axl = q.axl, lat = q.lat;
         W040 += sph; W131 += coma; W222 += ast; W311 += dist; W220P += ptz;
         W020 += axl; W111 += lat;
         if (surf) {      // per-surface contributions, SeidelAberrations.jl:25-34: [component][system][surface]
@@ -1543,7 +1646,8 @@ __device__ __forceinline__ void first_order_core(int g, int nsys, int rows, cons
         }
         if (inc) {       // incidences(surfaces, system) = [ni nī i ī], RayTracing.jl:338-353: [column][system][surface]
             const int64_t cs = (int64_t)nsys * (rows - 1), o = (int64_t)g * (rows - 1) + i;
-            const double nib = wc[i] + ni * ybi / Ri;
+            const double ni = next(i), ybi = W.yc[i + 1], Ri = R[i + 1];
+            const double nib = W.wc[i] + ni * ybi / Ri;
             inc[0 * cs + o] = A; inc[1 * cs + o] = nib; inc[2 * cs + o] = A / ni; inc[3 * cs + o] = nib / ni;
         }
     }
@@ -1736,21 +1840,50 @@ __global__ __launch_bounds__(64) void k_small_prepare(int nsys, int nf, int rows
                                                       int* __restrict__ fail_flag)
 {
     __shared__ double s_work[8][kMaxRows + 2];
+    __shared__ double s_in[4][kMaxRows];                                 // the system's R, t, n, a columns
+    __shared__ SeidelTerms s_terms[kMaxRows];
     __shared__ MerSurf s_mf[kMaxRows], s_mr[kMaxRows];
     __shared__ double s_crev[kMaxRows * kMaxCoef];
     __shared__ FirstOrderOut s_fo;
     const int g = blockIdx.x, s = g / nf, f = g - s * nf, lane = threadIdx.x;
-    const double* Rs = R + (int64_t)s * rows; const double* ts = t + (int64_t)s * rows; const double* ns = n + (int64_t)s * rows;
     const double* Ks = K ? K + (int64_t)s * rows : nullptr;
     const double* cs = (coef && ncoef > 0) ? coef + (int64_t)s * rows * ncoef : nullptr;
-    if (lane == 0) {
-        const FirstOrderWork W = {s_work[0], s_work[1], s_work[2], s_work[3], s_work[4], s_work[5], s_work[6], s_work[7]};
-        FirstOrderOut o;
-        first_order_core(s, nsys, rows, Rs, ts, ns, a + (int64_t)s * (rows - 1), nullptr, hp[s], lam, W, o, nullptr, nullptr);
-        s_fo = o;
-        if (f == 0) fo[s] = o;
+    ORT_PHASE(0);
+    const double h_s = hp[s], field_f = fields[f];                      // (the inputs may live in host memory: every fetch up front)
+    // the serial first-order chain reads its columns dozens of times: one parallel fetch into LDS instead of a
+    // global-memory round trip per loop iteration
+    for (int i = lane; i < rows; i += 64) {
+        s_in[0][i] = R[(int64_t)s * rows + i]; s_in[1][i] = t[(int64_t)s * rows + i]; s_in[2][i] = n[(int64_t)s * rows + i];
+        if (i < rows - 1) s_in[3][i] = a[(int64_t)s * (rows - 1) + i];
     }
     __syncthreads();
+    const double* Rs = s_in[0]; const double* ts = s_in[1]; const double* ns = s_in[2];
+    const FirstOrderWork W = {s_work[0], s_work[1], s_work[2], s_work[3], s_work[4], s_work[5], s_work[6], s_work[7]};
+    {
+        FirstOrderOut o;
+        first_order_paraxial<true>(lane, rows, Rs, ts, ns, s_in[3], h_s, W, o);   // every lane holds the scalars; lane 0's are kept
+        if (lane == 0) s_fo = o;
+    }
+    __syncthreads();
+    // Seidel contributions: one lane per surface (independent), summed in surface order by lane 0 — first_order_core's
+    // arithmetic, a surface's latency instead of rows - 1 of them
+    {
+        const double Hl = s_fo.H;
+        for (int i = lane; i < rows - 1; i += 64) { double A; s_terms[i] = seidel_terms(i, rows, Rs, ns, nullptr, Hl, lam, W, A); }
+    }
+    __syncthreads();
+    if (lane == 0) {
+        double W040 = 0, W131 = 0, W222 = 0, W311 = 0, W220P = 0, W020 = 0, W111 = 0;
+        for (int i = 0; i < rows - 1; ++i) {
+            const SeidelTerms q = s_terms[i];
+            W040 += q.sph; W131 += q.coma; W222 += q.ast; W311 += q.dist; W220P += q.ptz; W020 += q.axl; W111 += q.lat;
+        }
+        s_fo.W040 = W040; s_fo.W131 = W131; s_fo.W222 = W222; s_fo.W311 = W311; s_fo.W220P = W220P;
+        s_fo.W220 = W220P + 0.5 * W222; s_fo.W020 = W020; s_fo.W111 = W111;
+        if (f == 0) fo[s] = s_fo;
+    }
+    __syncthreads();
+    ORT_PHASE(1);
     const FirstOrderOut o1 = s_fo;
     for (int i = lane; i < rows; i += 64) {
         const bool mer = i < rows - 1;
@@ -1760,16 +1893,19 @@ __global__ __launch_bounds__(64) void k_small_prepare(int nsys, int nf, int rows
                            mer ? s_mf + i : nullptr, mer ? s_mr + i : nullptr, cs ? s_crev : nullptr);
     }
     __syncthreads();
+    ORT_PHASE(2);
     const double tlF = ts[rows - 1], tlR = !__builtin_isfinite(ts[0]) ? 0.0 : ts[0];
-    const AimIn q = make_aim_in(s, o1, a[(int64_t)s * (rows - 1) + o1.stop - 1], fields[f], layout_fwd);
+    const AimIn q = make_aim_in(s, o1, s_in[3][o1.stop - 1], field_f, layout_fwd);
     const AimOut o = aim_group(q, lane & 3, s_mf, cs, tlF, s_mr, cs ? s_crev : nullptr, tlR, rows - 1, ncoef);
+    ORT_PHASE(6);
     if (lane == 0) {
-        if (!o.ok) atomicOr(fail_flag, 1);
+        if (!o.ok) *fail_flag = 1;                                       // (a plain store: the flag may live in host memory)
         bd[g] = make_dev_bundle<T>(q, o, g, k_rays, k2);
     }
     const int per = k_rays + k2;
     for (int j = lane; j < per; j += 64)                                 // range(y1, y2, k), range(0, y_EP, k / 2)  (:121-122), as k_make_axes
         axes[(int64_t)g * per + j] = (T)((j < k_rays) ? dd_range_elem(o.y1, o.y2, k_rays, j) : dd_range_elem(0.0, o.y_EP, k2, j - k_rays));
+    ORT_PHASE(7);
 }
 
 // ------------------------------------------------------------------------------------

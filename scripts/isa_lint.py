@@ -11,8 +11,8 @@ run this after touching it.   python scripts/isa_lint.py"""
 import os, re, subprocess, sys, tempfile
 from collections import Counter
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-KERNELS = {"history": "_ZN3ort7k_traceIdLi1ELi0ELb1ELb1ELb0ELi0EEEvNS_11TraceParamsIT_EE",
-           "summary": "_ZN3ort7k_traceIdLi1ELi0ELb1ELb0ELb1ELi0EEEvNS_11TraceParamsIT_EE"}
+KERNELS = {"history": "_ZN3ort7k_traceIdLi1ELi0ELb1ELb1ELb0ELi0ELi2EEEvNS_11TraceParamsIT_EE",
+           "summary": "_ZN3ort7k_traceIdLi1ELi0ELb1ELb0ELb1ELi0ELi2EEEvNS_11TraceParamsIT_EE"}
 with tempfile.TemporaryDirectory(dir=os.path.join(ROOT, "build") if os.path.isdir(os.path.join(ROOT, "build")) else None) as td:
     asm = os.path.join(td, "ort.s")
     subprocess.run(["hipcc", "--offload-arch=gfx950", "-O3", "-ffp-contract=off", "-std=c++17", "-fno-slp-vectorize",
