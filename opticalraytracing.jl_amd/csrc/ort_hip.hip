@@ -482,7 +482,8 @@ int run_full_trace(ort_ctx* ctx, TraceParams<T>& p, int nb, T* ex, T* ey, T* rho
             hipLaunchKernelGGL(k_ft_scan, dim3((unsigned)nb), dim3(kBlock), 0, ctx->stream,
                                p.tile_cnt, p.tile_sx, p.tile_sy, p.tile_rmax, p.tiles_per_bundle, tile_off, agg);
             HIP_TRY(hipGetLastError());
-            hipLaunchKernelGGL((k_ft_place<T>), dim3((unsigned)tiles), dim3(kBlock), 0, ctx->stream,
+            const int64_t pgroups = (int64_t)nb * ((p.tiles_per_bundle + kPlaceTiles - 1) / kPlaceTiles);   // kPlaceTiles tiles per workgroup
+            hipLaunchKernelGGL((k_ft_place<T>), dim3((unsigned)pgroups), dim3(kBlock), 0, ctx->stream,
                                wex, wey, wr, wth, rpb, p.tiles_per_bundle, p.tile_cnt, tile_off, agg, dex, dey, drho, dth, chunk_sq);
             HIP_TRY(hipGetLastError());
         }

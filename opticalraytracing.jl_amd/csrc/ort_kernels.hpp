@@ -147,15 +147,17 @@ __device__ __forceinline__ void store_vec2(T* p, T a, T b)
 
 // ------------------------------------------------------------------------------------
 // 16-byte streaming of a compacted tile held in LDS to an arbitrarily aligned place of an output array: `head`
-// scalar elements up to the first 16-byte boundary of the destination, then one aligned vector per thread and trip
-// (2 doubles / 4 floats, non-temporal), then a scalar tail.  F maps the staged value to the stored one.
+// scalar elements up to the first 128-BYTE LINE boundary of the destination, then one aligned vector per thread and trip
+// (2 doubles / 4 floats, non-temporal: every wave-wide store covers 8 whole lines), then a scalar tail.  Cutting at
+// 16-byte boundaries only left a partial line at each end of every wave store, to be completed by its neighbour's
+// partial line: ~35 % slower per byte (k_ft_place, profiles/r03_place_ab.log).  F maps the staged value to the stored one.
 template <typename T, typename F>
 __device__ __forceinline__ void stream_out(T* __restrict__ dst, const T* __restrict__ lds, int c, int tid, F f)
 {
-    constexpr int V = 16 / (int)sizeof(T);
+    constexpr int V = 16 / (int)sizeof(T), L = 128 / (int)sizeof(T);
     typedef T vec_t __attribute__((ext_vector_type(V)));
-    const int mis = (int)((reinterpret_cast<uintptr_t>(dst) & 15) / sizeof(T));     // elements past a 16-byte boundary
-    const int head = min(c, mis ? V - mis : 0);
+    const int mis = (int)((reinterpret_cast<uintptr_t>(dst) & 127) / sizeof(T));    // elements past a 128-byte line
+    const int head = min(c, mis ? L - mis : 0);
     const int nvec = (c - head) / V;
     if (tid < head) __builtin_nontemporal_store(f(lds[tid]), dst + tid);
     for (int g = tid; g < nvec; g += kBlock) {
@@ -788,10 +790,99 @@ __global__ __launch_bounds__(kBlock) void k_ft_scan(const int32_t* __restrict__ 
 // from the 16-byte-aligned slot), staged in LDS, 64 B written as aligned 16-byte streaming stores whatever the parity of
 // the tile's offset and of m (stream_out): the kernel is bound by HBM, and 8-byte accesses ran it at half the store rate.
 // ------------------------------------------------------------------------------------
-template <typename T> struct FtPlaceShared { __attribute__((aligned(16))) T v[4][kTile]; double wsq[kBlock / 64]; };
+template <typename T> struct FtPlaceShared { double wsq[kBlock / 64]; };
 
-// tile `bid` (= bundle * tiles_per_bundle + tile), by kBlock threads tid = 0 .. kBlock-1 of a workgroup (also the second
-// stage of k_ft_small_finish, whose workgroup places four tiles at a time; active = false: no tile for this group)
+// x / d with r = 1 / d (correctly rounded) given: the quotient, its exact remainder, one correction — the correctly
+// rounded quotient (Markstein), three operations per element instead of a division sequence each.
+__device__ __forceinline__ double place_div(double x, double d, double r) { return ieee_div_nofix(x, d, r); }
+__device__ __forceinline__ float place_div(float x, float d, float) { return x / d; }
+
+// One half of a tile's placement: c compacted entries of the four workspace arrays at element `src` go to element `dst` of
+// the four outputs.  The DESTINATION decides the chunking, and at the granularity the memory system writes in: `head`
+// single elements up to the destination's first 128-byte line boundary, then 16-byte non-temporal stores of which every
+// wave-wide instruction covers 8 WHOLE lines, then a tail.  Cut at 16-byte boundaries only, every wave store left a
+// partial line at each end — completed later by its neighbour's partial line — and the pass ran 35 % slower per byte
+// than with every slot full and aligned (ORT_PLACE_DEBUG A/Bs, profiles/r03_place_ab.log: 700 -> 477 us once each tile
+// started on a line).  The loads take whatever alignment that leaves them (the slot is L2-resident: a misaligned 16-byte
+// load costs one extra line per wave).  No staging buffer, no barrier.  FIRST half: also the squared deviations of the
+// mirrored pair about the centroid (:169-173); MIRROR: [-ex; ey; rho; pi - theta] (:139-144).
+template <typename T, bool MIRROR>
+__device__ __forceinline__ double place_half(const T* __restrict__ w_ex, const T* __restrict__ w_ey, const T* __restrict__ w_r,
+                                             const T* __restrict__ w_th, int64_t src, T* __restrict__ ex, T* __restrict__ ey,
+                                             T* __restrict__ rho, T* __restrict__ theta, int64_t dst, int c, int tid,
+                                             const FtBundleAgg& a, T rmax, T rinv)
+{
+    constexpr int V = 16 / (int)sizeof(T), L = 128 / (int)sizeof(T);
+    typedef T vec_t __attribute__((ext_vector_type(V)));
+    double sq = 0.0;
+    auto one = [&](int j) {
+        const T vx = w_ex[src + j], vy = w_ey[src + j], vr = w_r[src + j], vt = w_th[src + j];
+        if (!MIRROR) {
+            const double dx1 = (double)vx - a.mux, dx2 = -(double)vx - a.mux, dy = (double)vy - a.muy;
+            sq += (dx1 * dx1 + dx2 * dx2) + (dy * dy + dy * dy);
+        }
+        __builtin_nontemporal_store(MIRROR ? -vx : vx, ex + dst + j);                                   // :141
+        __builtin_nontemporal_store(vy, ey + dst + j);                                                  // :140
+        __builtin_nontemporal_store(place_div(vr, rmax, rinv), rho + dst + j);                          // :142,143
+        __builtin_nontemporal_store(MIRROR ? (T)3.141592653589793 - vt : vt, theta + dst + j);          // :144
+    };
+    // vector stores need the four outputs equally placed inside a 16-byte word (they sit at the same element offset of
+    // equally aligned arrays unless the caller passed odd pointers); the line cut is taken from ex
+    const unsigned mis16 = (unsigned)(reinterpret_cast<uintptr_t>(ex + dst) & 15);
+    const bool same = (reinterpret_cast<uintptr_t>(ey + dst) & 15) == mis16 && (reinterpret_cast<uintptr_t>(rho + dst) & 15) == mis16 &&
+                      (reinterpret_cast<uintptr_t>(theta + dst) & 15) == mis16 && mis16 % sizeof(T) == 0;
+    if (!same) {
+        for (int j = tid; j < c; j += kBlock) one(j);
+        return sq;
+    }
+    const int mis = (int)((reinterpret_cast<uintptr_t>(ex + dst) & 127) / sizeof(T));     // elements past a 128-byte line
+    const int head = min(c, mis ? L - mis : 0);
+    const int nvec = (c - head) / V;
+    if (tid < head) one(tid);
+    for (int g = tid; g < nvec; g += kBlock) {                                            // a wave: 1 KiB from a line boundary
+        const int j = head + g * V;
+        vec_t vx, vy, vr, vt;
+        __builtin_memcpy(&vx, w_ex + src + j, sizeof(vec_t)); __builtin_memcpy(&vy, w_ey + src + j, sizeof(vec_t));
+        __builtin_memcpy(&vr, w_r + src + j, sizeof(vec_t));  __builtin_memcpy(&vt, w_th + src + j, sizeof(vec_t));
+        vec_t ox, orr, ot;
+#pragma unroll
+        for (int q = 0; q < V; ++q) {
+            if (!MIRROR) {
+                const double dx1 = (double)vx[q] - a.mux, dx2 = -(double)vx[q] - a.mux, dy = (double)vy[q] - a.muy;
+                sq += (dx1 * dx1 + dx2 * dx2) + (dy * dy + dy * dy);
+            }
+            ox[q] = MIRROR ? -vx[q] : vx[q];
+            orr[q] = place_div(vr[q], rmax, rinv);
+            ot[q] = MIRROR ? (T)3.141592653589793 - vt[q] : vt[q];
+        }
+        __builtin_nontemporal_store(ox, reinterpret_cast<vec_t*>(ex + dst + j));
+        __builtin_nontemporal_store(vy, reinterpret_cast<vec_t*>(ey + dst + j));
+        __builtin_nontemporal_store(orr, reinterpret_cast<vec_t*>(rho + dst + j));
+        __builtin_nontemporal_store(ot, reinterpret_cast<vec_t*>(theta + dst + j));
+    }
+    const int jt = head + nvec * V + tid;                                                 // < V - 1 elements left
+    if (jt < c) one(jt);
+    return sq;
+}
+
+// One tile's placement by kBlock threads: `c` survivors of slot `bid` to element `dst` of the bundle's first half and to
+// dst + m of its mirror half.  Returns this thread's share of the tile's squared deviations.
+template <typename T>
+__device__ __forceinline__ double ft_place_tile(int bid, int c, int64_t dst, const FtBundleAgg& a,
+                                                const T* __restrict__ w_ex, const T* __restrict__ w_ey,
+                                                const T* __restrict__ w_r, const T* __restrict__ w_th,
+                                                T* __restrict__ ex, T* __restrict__ ey, T* __restrict__ rho, T* __restrict__ theta,
+                                                int tid)
+{
+    const int64_t src = (int64_t)bid * kTile;                                     // the tile's slot: 16-byte aligned, kTile entries
+    const T rmax = (T)a.rmax, rinv = T(1) / rmax;                                 // r ./ maximum(r)  (:142)
+    const double sq = place_half<T, false>(w_ex, w_ey, w_r, w_th, src, ex, ey, rho, theta, dst, c, tid, a, rmax, rinv);
+    place_half<T, true>(w_ex, w_ey, w_r, w_th, src, ex, ey, rho, theta, dst + a.m, c, tid, a, rmax, rinv);
+    return sq;
+}
+
+// tile `bid` (= bundle * tiles_per_bundle + tile), by kBlock threads tid = 0 .. kBlock-1 of a workgroup: the second stage of
+// k_ft_small_finish, whose workgroup places four tiles at a time; active = false: no tile for this group
 template <typename T>
 __device__ __forceinline__ void ft_place_body(int bid, const T* __restrict__ w_ex, const T* __restrict__ w_ey,
                                               const T* __restrict__ w_r, const T* __restrict__ w_th,
@@ -802,43 +893,13 @@ __device__ __forceinline__ void ft_place_body(int bid, const T* __restrict__ w_e
                                               T* __restrict__ rho, T* __restrict__ theta,
                                               double* __restrict__ tile_sq, FtPlaceShared<T>& sh, int tid, bool active)
 {
-    constexpr int V = 16 / (int)sizeof(T);
-    typedef T vec_t __attribute__((ext_vector_type(V)));
-    T (*s_v)[kTile] = sh.v;
     double* s_wsq = sh.wsq;
     const int lane = tid & 63, wave = tid >> 6;
     const int b = active ? bid / tiles_per_bundle : 0;
     const int c = active ? tile_cnt[bid] : 0;
     const FtBundleAgg a = agg[b];
-    const int64_t src = (int64_t)bid * kTile;                                     // the tile's slot: 16-byte aligned, kTile entries
     const int64_t dst = (int64_t)b * 2 * rpb + (active ? tile_off[bid] : 0);
-    double sq = 0.0;
-    for (int j = tid * V; j < c; j += kBlock * V) {                               // the slot holds kTile entries: reads past c stay inside it
-        const vec_t vx = *reinterpret_cast<const vec_t*>(w_ex + src + j), vy = *reinterpret_cast<const vec_t*>(w_ey + src + j);
-        const vec_t vr = *reinterpret_cast<const vec_t*>(w_r + src + j), vt = *reinterpret_cast<const vec_t*>(w_th + src + j);
-        vec_t rr;
-#pragma unroll
-        for (int q = 0; q < V; ++q) {
-            rr[q] = vr[q] / (T)a.rmax;                                            // :142
-            if (j + q < c) {
-                const double dx1 = (double)vx[q] - a.mux, dx2 = -(double)vx[q] - a.mux;
-                const double dy = (double)vy[q] - a.muy;
-                sq += (dx1 * dx1 + dx2 * dx2) + (dy * dy + dy * dy);
-            }
-        }
-        *reinterpret_cast<vec_t*>(&s_v[0][j]) = vx; *reinterpret_cast<vec_t*>(&s_v[1][j]) = vy;
-        *reinterpret_cast<vec_t*>(&s_v[2][j]) = rr; *reinterpret_cast<vec_t*>(&s_v[3][j]) = vt;
-    }
-    __syncthreads();
-    auto same = [](T v) { return v; };
-    stream_out<T>(ex + dst, s_v[0], c, tid, same);
-    stream_out<T>(ey + dst, s_v[1], c, tid, same);
-    stream_out<T>(rho + dst, s_v[2], c, tid, same);
-    stream_out<T>(theta + dst, s_v[3], c, tid, same);
-    stream_out<T>(ex + dst + a.m, s_v[0], c, tid, [](T v) { return -v; });                                   // :141
-    stream_out<T>(ey + dst + a.m, s_v[1], c, tid, same);                                                      // :140
-    stream_out<T>(rho + dst + a.m, s_v[2], c, tid, same);                                                     // :143
-    stream_out<T>(theta + dst + a.m, s_v[3], c, tid, [](T v) { return (T)3.141592653589793 - v; });          // :144
+    double sq = ft_place_tile<T>(bid, c, dst, a, w_ex, w_ey, w_r, w_th, ex, ey, rho, theta, tid);
     for (int off = 32; off > 0; off >>= 1) sq += __shfl_down(sq, off);
     if (lane == 0) s_wsq[wave] = sq;
     __syncthreads();
@@ -848,6 +909,12 @@ __device__ __forceinline__ void ft_place_body(int bid, const T* __restrict__ w_e
         tile_sq[bid] = t;
     }
 }
+
+// kPlaceTiles consecutive tiles of one bundle per workgroup, their headers fetched together (one round trip for the group).
+#ifndef ORT_PLACE_TILES
+#define ORT_PLACE_TILES 2
+#endif
+constexpr int kPlaceTiles = ORT_PLACE_TILES;
 
 template <typename T>
 __global__ __launch_bounds__(kBlock) void k_ft_place(const T* __restrict__ w_ex, const T* __restrict__ w_ey,
@@ -859,9 +926,31 @@ __global__ __launch_bounds__(kBlock) void k_ft_place(const T* __restrict__ w_ex,
                                                      T* __restrict__ rho, T* __restrict__ theta,
                                                      double* __restrict__ tile_sq)
 {
-    __shared__ FtPlaceShared<T> sh;
-    ft_place_body<T>(blockIdx.x, w_ex, w_ey, w_r, w_th, rpb, tiles_per_bundle, tile_cnt, tile_off, agg, ex, ey, rho, theta, tile_sq, sh,
-                     threadIdx.x, true);
+    __shared__ double s_wsq[kPlaceTiles][kBlock / 64];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int groups = (tiles_per_bundle + kPlaceTiles - 1) / kPlaceTiles;
+    const int b = blockIdx.x / groups, t0 = (blockIdx.x - b * groups) * kPlaceTiles;
+    const FtBundleAgg a = agg[b];
+    int c[kPlaceTiles]; int64_t off[kPlaceTiles];
+#pragma unroll
+    for (int q = 0; q < kPlaceTiles; ++q) {
+        const bool in = t0 + q < tiles_per_bundle;
+        const int bid = b * tiles_per_bundle + (in ? t0 + q : t0);
+        c[q] = in ? tile_cnt[bid] : 0; off[q] = tile_off[bid];
+    }
+#pragma unroll
+    for (int q = 0; q < kPlaceTiles; ++q) {
+        double sq = ft_place_tile<T>(b * tiles_per_bundle + t0 + q, c[q], (int64_t)b * 2 * rpb + off[q], a, w_ex, w_ey, w_r, w_th,
+                                     ex, ey, rho, theta, tid);
+        for (int o = 32; o > 0; o >>= 1) sq += __shfl_down(sq, o);
+        if (lane == 0) s_wsq[q][wave] = sq;
+    }
+    __syncthreads();
+    if (tid < kPlaceTiles && t0 + tid < tiles_per_bundle) {
+        double t = 0.0;
+        for (int w = 0; w < kBlock / 64; ++w) t += s_wsq[tid][w];
+        tile_sq[b * tiles_per_bundle + t0 + tid] = t;
+    }
 }
 
 // ------------------------------------------------------------------------------------
@@ -1000,7 +1089,7 @@ __global__ __launch_bounds__(kBlock * kFinishGroups) void k_ft_small_finish(cons
         const int tile = tile0 + grp;
         ft_place_body<T>(b * tiles_per_bundle + tile, w_ex, w_ey, w_r, w_th, rpb, tiles_per_bundle, tile_cnt, tile_off, agg,
                          ex, ey, rho, theta, tile_sq, ps[grp], tid, tile < tiles_per_bundle);
-        __syncthreads();                                         // the staging buffers are reused; tile_sq is read below
+        __syncthreads();                                         // ps[].wsq is reused; tile_sq is read below
     }
     ORT_PHASE(12);
     ft_finalize_body(b, tile_sq, tiles_per_bundle, agg, count, rms, nullptr, s_r, tid, grp == 0);
