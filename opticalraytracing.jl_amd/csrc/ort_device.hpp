@@ -147,6 +147,43 @@ __device__ __forceinline__ float fast_rsqrt(float a)
     const float e = __builtin_fmaf(-a * r0, r0, 1.0f);
     return __builtin_fmaf(r0, 0.5f * e, r0);
 }
+
+// MATH_FAST: atan(y, x) (theta of the full_trace output, src/PupilSampling.jl:133) without ocml's ~120 instructions per
+// ray — a fifth of everything the full_trace kernel issues per ray on a 12-surface system.  One division:
+// t = min / max of (|x|, |y|) directly, or (min - max) / (min + max) = (t - 1) / (t + 1) when t > tan(pi/8), which
+// brings the argument to |u| <= tan(pi/8); atan(u) = u + u w P(w), w = u^2, P of degree 9 (interpolated at Chebyshev
+// nodes in 50-digit arithmetic: approximation error 5e-17); then the octant is unfolded.  Measured against libm on 4e5
+// points: <= 4.4e-16 absolute.  atan(0, 0) = 0 for either sign of x's zero (libm: pi for -0); NaN in, NaN out.
+__device__ __forceinline__ double fast_atan2(double y, double x)
+{
+    const double ax = __builtin_fabs(x), ay = __builtin_fabs(y);
+    const double mx = __builtin_fmax(ax, ay), mn = __builtin_fmin(ax, ay);
+    const bool big = mn > 0.41421356237309503 * mx;
+    const double num = big ? mn - mx : mn;
+    double den = big ? mn + mx : mx;
+    den = den == 0.0 ? 1.0 : den;
+    const double r = fast_rcp(den);
+    double u = num * r;
+    u = __builtin_fma(__builtin_fma(-u, den, num), r, u);
+    const double w = u * u;
+    double p = 2.27505269933616708e-02;
+    p = __builtin_fma(p, w, -4.48333462227288593e-02);
+    p = __builtin_fma(p, w, 5.73633216590764272e-02);
+    p = __builtin_fma(p, w, -6.64961369529166874e-02);
+    p = __builtin_fma(p, w, 7.69105515839314940e-02);
+    p = __builtin_fma(p, w, -9.09085255717604901e-02);
+    p = __builtin_fma(p, w, 1.11111096365343609e-01);
+    p = __builtin_fma(p, w, -1.42857142660966191e-01);
+    p = __builtin_fma(p, w, 1.99999999998984074e-01);
+    p = __builtin_fma(p, w, -3.33333333333332482e-01);
+    double a = __builtin_fma(u * w, p, u);
+    a = big ? 0.7853981633974483 + a : a;
+    a = ay > ax ? 1.5707963267948966 - a : a;
+    a = x < 0.0 ? 3.141592653589793 - a : a;
+    a = __builtin_isunordered(x, y) ? __builtin_nan("") : a;      // (max / min drop a NaN operand)
+    return __builtin_copysign(a, y);
+}
+__device__ __forceinline__ float fast_atan2(float y, float x) { return ::atan2f(y, x); }
 // sqrt(a) = a * rsqrt(a) for a > 0; a < 0 -> NaN (a ray that misses, :9).
 // Float64: g = a r0 refined by ONE Newton step, g (1 + e/2) with e = 1 - g r0: error 3/8 e^2 ~ 2^-50
 // — 5 instructions instead of the 7 of a * fast_rsqrt(a), and it is the sqrt, not the reciprocal root,

@@ -417,7 +417,11 @@ int run_full_trace(ort_ctx* ctx, TraceParams<T>& p, int nb, T* ex, T* ey, T* rho
     const int64_t rpb = p.rpb, N = rpb * nb;
     const int64_t tiles = (int64_t)nb * p.tiles_per_bundle;
     if (tiles > 0x7fffffffLL) return fail(ORT_EINVAL, "launch too large");
-    const bool small_f64 = sizeof(T) == 8 && p.tiles_per_bundle <= kSmallTiles && tiles <= kSmallGridTiles && !(flags & ORT_NO_SMALL_PATH);
+#ifndef ORT_POLY_RPT1
+#define ORT_POLY_RPT1 0
+#endif
+    const bool small_f64 = sizeof(T) == 8 && ((p.tiles_per_bundle <= kSmallTiles && tiles <= kSmallGridTiles && !(flags & ORT_NO_SMALL_PATH)) ||
+                                              (ORT_POLY_RPT1 && p.arms == ARMS_POLY));
     int rc;
     rc = dev_out<int32_t>(ctx, SL_TCNT, (size_t)tiles, &p.tile_cnt); if (rc) return rc;
     rc = dev_out<double>(ctx, SL_TSX, (size_t)tiles, &p.tile_sx); if (rc) return rc;

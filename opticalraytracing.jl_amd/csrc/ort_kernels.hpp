@@ -32,6 +32,9 @@ __device__ unsigned long long g_phase[32];
 
 
 // Tunables (compile-time; the defaults are the measured best).
+#ifndef ORT_POLY_WAVES
+#define ORT_POLY_WAVES (ORT_MIN_WAVES - 1)   // waves per SIMD the polynomial-arm builds are compiled for
+#endif
 #ifndef ORT_RPT
 #define ORT_RPT 2            // rays per lane
 #endif
@@ -200,7 +203,7 @@ constexpr int kStatusVignetted = 1 << 17, kStatusVigShift = 20;
 // one wave's instruction stream, and RPT = 1 — the same 512-ray tile on 512 threads — halves it.  Same results bit for
 // bit (the tile sums are taken in the RPT = 2 order, tile_sum2 below).
 template <typename T, int MATH, int ARMS, bool GRID, bool HIST, bool SUMM, int FT, int RPT = kRPT>
-__global__ __launch_bounds__(kTile / RPT, (ARMS == ARMS_POLY || (HIST && SUMM) || FT == 3 /* FT_LOOKBACK */) ? ORT_MIN_WAVES - 1 : HIST ? ORT_MIN_WAVES : ORT_WAVES_NOHIST)
+__global__ __launch_bounds__(kTile / RPT, ARMS == ARMS_POLY ? ORT_POLY_WAVES : ((HIST && SUMM) || FT == 3 /* FT_LOOKBACK */) ? ORT_MIN_WAVES - 1 : HIST ? ORT_MIN_WAVES : ORT_WAVES_NOHIST)
 void k_trace(TraceParams<T> p)   // both outputs, look-back epilogue, polynomial arms: 128 VGPRs (at 96 they park tens of values per row in scratch)
 {
     constexpr int NT = kTile / RPT;                              // threads per workgroup: one tile of kTile rays
@@ -475,7 +478,7 @@ void k_trace(TraceParams<T> p)   // both outputs, look-back epilogue, polynomial
             else if (kCompact) ri = r2 * fast_rsqrt(r2 + (sizeof(T) == 8 ? (T)1e-300 : (T)1e-36));
             const bool drop = outside || t_isnan(xf) || t_isnan(yf) || !live[r] || (st[r] & kStatusVignetted);
             keep[r] = !drop;
-            if (kCompact) thv[r] = dev_atan2(ys_[r], xs_[r]);          // :133
+            if (kCompact) thv[r] = MATH == MATH_FAST ? fast_atan2(ys_[r], xs_[r]) : dev_atan2(ys_[r], xs_[r]);   // :133
             eyv[r] = yf - hprime;                                    // :134
             exv[r] = xf;                                             // :135
             rv[r] = drop ? T(-1) : ri;                               // :136, -1 marks a dropped ray

@@ -52,3 +52,14 @@ def trace_fast_with_retrace(pres, y, x, u, v, isys: int = 0):
         ix, iy, _ = trace(pres, np.asarray(y)[odd], np.asarray(x)[odd], np.asarray(u)[odd], np.asarray(v)[odd], False, isys)
         fx[:, odd], fy[:, odd] = ix, iy
     return fx, fy, odd
+
+
+def fast_atan2(y, x):
+    """ort::fast_atan2 (the FAST policy's theta), element-wise, on the host."""
+    y = np.ascontiguousarray(y, dtype=np.float64); x = np.ascontiguousarray(x, dtype=np.float64)
+    out = np.empty_like(y)
+    L = lib()
+    L.emu_fast_atan2.argtypes = [C.c_long, C.c_void_p, C.c_void_p, C.c_void_p]
+    L.emu_fast_atan2.restype = None
+    L.emu_fast_atan2(y.size, _p(y), _p(x), _p(out))
+    return out

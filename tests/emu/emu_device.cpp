@@ -55,3 +55,9 @@ extern "C" int emu_trace(int fast, int rows, const double* R, const double* t, c
     }
     return 0;
 }
+
+// theta of the full_trace output under MATH_FAST (ort_device.hpp: fast_atan2), element-wise
+extern "C" void emu_fast_atan2(long n, const double* y, const double* x, double* out)
+{
+    for (long i = 0; i < n; ++i) out[i] = ort::fast_atan2(y[i], x[i]);
+}

@@ -138,3 +138,18 @@ def test_fast_policy_is_status_exact_by_construction(oracle_engine, wide):
         ntot += m; nodd += int(odd.sum()); nill += int((err > TOL).sum())
     assert nill <= 2e-3 * ntot, (nill, ntot)
     assert nodd < (0.5 if wide else 0.05) * ntot, (nodd, ntot)       # the retrace is the exception, not the rule
+
+
+def test_fast_atan2_against_libm():
+    """theta under the FAST policy (ort::fast_atan2, one division + a degree-9 polynomial) against numpy's atan2 on every
+    octant, tiny and huge ratios, the axes and NaN: <= 1e-15 absolute (the parity bar is 1e-10)."""
+    rng = np.random.default_rng(5)
+    n = 400000
+    x = rng.uniform(-10, 10, n); y = rng.uniform(-10, 10, n)
+    x[::7] *= 1e-6; y[::11] *= 1e-7; x[::13] *= 1e5
+    got = emu.fast_atan2(y, x); ref = np.arctan2(y, x)
+    assert np.abs(got - ref).max() <= 1e-15
+    ys = np.array([0.0, 1.0, -1.0, 0.0, 0.0, 2.0, -2.0, 1e-30, np.nan, 1.0])
+    xs = np.array([1.0, 0.0, 0.0, -1.0, 0.0, 2.0, -2.0, 1e-30, 1.0, np.nan])
+    g = emu.fast_atan2(ys, xs); r = np.arctan2(ys, xs)
+    assert np.allclose(g[:8], r[:8], rtol=0, atol=1e-15) and np.isnan(g[8]) and np.isnan(g[9])
