@@ -154,6 +154,9 @@ __device__ __forceinline__ float fast_rsqrt(float a)
 // brings the argument to |u| <= tan(pi/8); atan(u) = u + u w P(w), w = u^2, P of degree 9 (interpolated at Chebyshev
 // nodes in 50-digit arithmetic: approximation error 5e-17); then the octant is unfolded.  Measured against libm on 4e5
 // points: <= 4.4e-16 absolute.  atan(0, 0) = 0 for either sign of x's zero (libm: pi for -0); NaN in, NaN out.
+__constant__ double kAtanP[10] = {-3.33333333333332482e-01, 1.99999999998984074e-01, -1.42857142660966191e-01, 1.11111096365343609e-01,
+                                        -9.09085255717604901e-02, 7.69105515839314940e-02, -6.64961369529166874e-02, 5.73633216590764272e-02,
+                                        -4.48333462227288593e-02, 2.27505269933616708e-02};
 __device__ __forceinline__ double fast_atan2(double y, double x)
 {
     const double ax = __builtin_fabs(x), ay = __builtin_fabs(y);
@@ -166,16 +169,11 @@ __device__ __forceinline__ double fast_atan2(double y, double x)
     double u = num * r;
     u = __builtin_fma(__builtin_fma(-u, den, num), r, u);
     const double w = u * u;
-    double p = 2.27505269933616708e-02;
-    p = __builtin_fma(p, w, -4.48333462227288593e-02);
-    p = __builtin_fma(p, w, 5.73633216590764272e-02);
-    p = __builtin_fma(p, w, -6.64961369529166874e-02);
-    p = __builtin_fma(p, w, 7.69105515839314940e-02);
-    p = __builtin_fma(p, w, -9.09085255717604901e-02);
-    p = __builtin_fma(p, w, 1.11111096365343609e-01);
-    p = __builtin_fma(p, w, -1.42857142660966191e-01);
-    p = __builtin_fma(p, w, 1.99999999998984074e-01);
-    p = __builtin_fma(p, w, -3.33333333333332482e-01);
+    // the coefficients come from constant memory (scalar loads -> SGPR operands of v_fma): as literals the compiler moves
+    // each one into a VGPR pair first (two v_mov per FMA)
+    double p = kAtanP[9];
+#pragma unroll
+    for (int j = 8; j >= 0; --j) p = __builtin_fma(p, w, kAtanP[j]);
     double a = __builtin_fma(u * w, p, u);
     a = big ? 0.7853981633974483 + a : a;
     a = ay > ax ? 1.5707963267948966 - a : a;

@@ -7,6 +7,7 @@
 #include <cstdint>
 #define __device__
 #define __host__
+#define __constant__ static
 #define __forceinline__ inline
 #define __global__
 static inline double __builtin_amdgcn_rcp(double a) { return (double)(float)(1.0 / a); }
