@@ -20,4 +20,4 @@ for route in place lookback; do
   timeout -k 10 300 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/ft_write_$route -- python3 /root/repo/bench.py $Q --mode full_trace $extra > $OUT/ft_write_$route.log 2>&1 || exit 1
 done
 timeout -k 10 300 rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_BUSY_CU_CYCLES SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY --kernel-trace --output-format csv -d $OUT/sq_both -- python3 /root/repo/bench.py $Q --policy fast > $OUT/sq_both.log 2>&1 || exit 1
-ORT_ROUND=r02 python3 /root/repo/scripts/collect_final.py
+ORT_ROUND=${ORT_ROUND:-r03} python3 /root/repo/scripts/collect_final.py
