@@ -120,12 +120,22 @@ __device__ __forceinline__ float t_abs(float a) { return __builtin_fabsf(a); }
 // 2^-24.4 / 2^-24.2 on gfx950, tools/ubench.hip) + ONE cubically convergent step:
 //   1/a      = r0 (1 + e + e^2 + ...),        e = 1 - a r0        -> error e^3  ~ 2^-73
 //   1/sqrt a = r0 (1 + e/2 + 3e^2/8 + ...),   e = 1 - a r0^2      -> error 5e^3/16 ~ 2^-71
+#ifndef ORT_QUAD
+#define ORT_QUAD 1
+#endif
+#ifndef ORT_UNNORM
+#define ORT_UNNORM 1
+#endif
 __device__ __forceinline__ double fast_rcp(double a)
 {
     const double r0 = __builtin_amdgcn_rcp(a);
     const double e = __builtin_fma(-a, r0, 1.0);
+#if ORT_QUAD
+    return __builtin_fma(r0, e, r0);
+#else
     const double p = __builtin_fma(e, e, e);
     return __builtin_fma(r0, p, r0);
+#endif
 }
 __device__ __forceinline__ float fast_rcp(float a)
 {
@@ -137,9 +147,15 @@ __device__ __forceinline__ double fast_rsqrt(double a)
 {
     const double r0 = __builtin_amdgcn_rsq(a);
     const double t = a * r0;
+#if ORT_QUAD
+    const double h = 0.5 * r0;
+    const double e = __builtin_fma(-t, r0, 1.0);
+    return __builtin_fma(h, e, r0);
+#else
     const double e = __builtin_fma(-t, r0, 1.0);
     const double p = __builtin_fma(0.375, e, 0.5);
     return __builtin_fma(r0, e * p, r0);
+#endif
 }
 __device__ __forceinline__ float fast_rsqrt(float a)
 {
@@ -537,6 +553,19 @@ __device__ __forceinline__ void surface_step_fast_poly(Ray<T>& r, const SurfRec<
     r.sprev = sg;
     T tx, ty;
     poly_tilt_fast<T, FORM>(pl, r.x, r.y, xx, yy, is, tx, ty);   // Q2: p'(x) on the x slope, p'(y) on the y slope
+#if ORT_UNNORM
+    // un-normalised normal N = (tx, ty, -1), |N|^2 = n2, gu = -k.N:  with g = gu / |N| the reference's
+    //   k' = eta k + (eta g - sqrt(1 - eta^2 (1 - g^2))) N / |N|  =  eta k + (eta gu - sqrt(W)) N / n2,
+    //   W = (1 - eta^2) n2 + eta^2 gu^2 = n2 (1 - eta^2 (1 - g^2)):  the root and the reciprocal are independent of each
+    // other (one refined reciprocal root and its two products less, and the two seeds issue back to back)
+    const T n2 = t_fma<T>(tx, tx, t_fma<T>(ty, ty, T(1)));
+    const T gu = t_fma<T>(-r.k1, ty, t_fma<T>(-r.k0, tx, r.k2));
+    const T W = t_fma<T>(s.eta2 * gu, gu, s.ome2 * n2);
+    // TIR rows: total internal reflection (the reference leaves k untouched, Q1) and its neighbourhood (:25) are left to
+    // the reference sequence: 1 - eta^2 (1 - g^2) < thr  <=>  W < thr n2
+    if (TIR) odd = odd || (W < Near<T>::thr * n2);
+    const T cf = t_fma<T>(s.eta, gu, -sqrt_core(W)) * fast_rcp(n2);
+#else
     const T inv = fast_rsqrt(t_fma<T>(tx, tx, t_fma<T>(ty, ty, T(1))));
     // un-normalised normal N = (tx, ty, -1), m = N inv:  g = -k.m,  k' = eta k + (eta g - sqrt(D2)) inv N
     const T g = t_fma<T>(-r.k1, ty, t_fma<T>(-r.k0, tx, r.k2)) * inv;
@@ -545,6 +574,7 @@ __device__ __forceinline__ void surface_step_fast_poly(Ray<T>& r, const SurfRec<
     // left to the reference sequence — one compare instead of a compare and four selects; a NaN ray is neither
     if (TIR) odd = odd || (D2 < Near<T>::thr);
     const T cf = t_fma<T>(s.eta, g, -sqrt_core(D2)) * inv;
+#endif
     const T ee = s.eta;
     // product on the OLD component first, then accumulate into it: the two-address v_fmac then updates k in
     // place (the other association lands in a temporary and costs a v_mov per component)
@@ -715,7 +745,7 @@ __device__ __forceinline__ void surface_step_fast_sphere_c(Ray<T>& r, const Surf
 // One record from row i+1 of the prescription as loop iteration i sees it.  nc = coefficients in use (0: p = zero),
 // pcls = the CLS_P* bits of the row's polynomial record.  Every derived field is ONE IEEE operation on the row's data,
 // the same on both sides.
-// Returns the row's ARMS level (below).
+// Returns the row's NEED_* bits (below): which arms of the surface loop it takes.
 template <typename T>
 __host__ __device__ inline int make_rec(SurfRec<T>& r, T t, T Rv, T n1, T n2, T Kv, int nc, int pcls)
 {
@@ -736,7 +766,9 @@ __host__ __device__ inline int make_rec(SurfRec<T>& r, T t, T Rv, T n1, T n2, T 
     }
     r.cls = (r.finite ? CLS_FINITE : 0) | (nc > 0 ? CLS_HASP : 0) | ((r.eta != T(1)) ? CLS_REFR : 0) |
             (!(r.eta > T(0) && r.eta <= T(1)) ? CLS_TIR : 0) | (kind << CLS_KIND_SHIFT) | (nc > 0 ? pcls : 0);
-    return kind == KIND_POLY ? 2 : (kind == KIND_CONIC || (kind == KIND_SPHERE && sizeof(T) == 8)) ? 1 : 0;
+    // what this row asks of the kernel build (NEED_* below): a polynomial row in even form on a curved base has its own arms
+    if (kind == KIND_POLY) return (r.finite && (pcls & CLS_PEVEN)) ? 2 /* NEED_EVEN */ : 4 /* NEED_POLY */;
+    return (kind == KIND_CONIC || (kind == KIND_SPHERE && sizeof(T) == 8)) ? 1 /* NEED_GENERAL */ : 0;
 }
 
 // One polynomial record (layout: kPolyRec above) from a raw coefficient row c[0 .. ncoef); returns its CLS_P* bits.
@@ -771,9 +803,20 @@ __host__ __device__ inline int make_poly_rec(T* rec, const double* c, int ncoef,
 // spherical system holds the centre-form sphere and flat arms and NOTHING else:
 //   ARMS_BASIC    centre-form spheres (Float32: general-form spheres) + flat rows
 //   ARMS_GENERAL  + general-form spheres (Float64 rows with |R| > kCentreFormMaxR) and conics
-//   ARMS_POLY     + polynomial rows: two interleaved ~100-instruction chains + the row's coefficients need the
-//                 128-VGPR budget (k_trace's launch bounds); at 96 they park tens of values per row in scratch
-enum { ARMS_BASIC = 0, ARMS_GENERAL = 1, ARMS_POLY = 2 };
+//   ARMS_EVEN     ARMS_BASIC + even aspheres on a curved base (polynomial rows whose odd coefficients are all zero, finite
+//                 R: p(y) = E(y^2) of <= 4 / <= 6 terms), as independent arms — the usual aspheric lens; without the
+//                 general arm in the loop its sphere / flat arms carry no merge copies (7 % fewer instructions on config 3)
+//   ARMS_POLY     everything: + general-form spheres, conics and general polynomial rows (one grouped arm).  Polynomial
+//                 rows: two interleaved ~100-instruction chains + the row's coefficients need the 128-VGPR budget
+//                 (k_trace's launch bounds); at 96 they park tens of values per row in scratch
+enum { ARMS_BASIC = 0, ARMS_GENERAL = 1, ARMS_EVEN = 2, ARMS_POLY = 3 };
+// what a row needs (make_rec's return value, OR-ed over a batch's rows) -> the build that runs the batch
+enum { NEED_GENERAL = 1, NEED_EVEN = 2, NEED_POLY = 4 };
+__host__ __device__ inline int arms_of_needs(int m)
+{
+    if ((m & NEED_POLY) || ((m & NEED_EVEN) && (m & NEED_GENERAL))) return ARMS_POLY;
+    return (m & NEED_EVEN) ? ARMS_EVEN : (m & NEED_GENERAL) ? ARMS_GENERAL : ARMS_BASIC;
+}
 template <typename T, int MATH, int N, int ARMS>
 __device__ __forceinline__ void surface_step_n(Ray<T> (&r)[N], const SurfRec<T>& s,
                                                const T* __restrict__ pl, int cls, bool last, bool& odd)
@@ -782,7 +825,7 @@ __device__ __forceinline__ void surface_step_n(Ray<T> (&r)[N], const SurfRec<T>&
     if (MATH == MATH_IEEE) {
         // hot arms first (spherical / conic rows and flat rows without a polynomial), as independent ifs; rows
         // with a polynomial and the final iteration share one grouped arm
-        const bool fin = cls & CLS_FINITE, hasp = ARMS >= ARMS_POLY && (cls & CLS_HASP);
+        const bool fin = cls & CLS_FINITE, hasp = ARMS >= ARMS_EVEN && (cls & CLS_HASP);
         if (fin && !hasp && !last)  { ORT_ALL_RAYS((surface_step_ieee<T, true, false, false>(r[q], s, pl))) }
         if (!fin && !hasp && !last) { ORT_ALL_RAYS((surface_step_ieee_flat<T>(r[q], s))) }
         if (hasp || last) {
@@ -811,14 +854,24 @@ __device__ __forceinline__ void surface_step_n(Ray<T> (&r)[N], const SurfRec<T>&
         constexpr bool kF32 = sizeof(T) == 4;
         if (kF32 && kind == KIND_SPHERE && !tir) { ORT_ALL_RAYS((surface_step_fast_conic<T, KIND_SPHERE, true, false>(r[q], s, odd))) }
         if (kF32 && kind == KIND_SPHERE && tir)  { ORT_ALL_RAYS((surface_step_fast_conic<T, KIND_SPHERE, true, true>(r[q], s, odd))) }
-        if (ARMS >= ARMS_GENERAL && ((!kF32 && kind == KIND_SPHERE) || kind == KIND_CONIC || (ARMS >= ARMS_POLY && kind == KIND_POLY))) {   // the general forms share ONE arm:
+        if (ARMS == ARMS_EVEN) {
+            // even aspheres on a curved base (the usual case): four independent arms, nothing else in the loop
+            const bool big = cls & CLS_PBIG;
+            if (kind == KIND_POLY && !big && !tir) { ORT_ALL_RAYS((surface_step_fast_poly<T, 0, true, false>(r[q], s, pl, odd))) }
+            if (kind == KIND_POLY && !big && tir)  { ORT_ALL_RAYS((surface_step_fast_poly<T, 0, true, true>(r[q], s, pl, odd))) }
+            if (kind == KIND_POLY && big && !tir)  { ORT_ALL_RAYS((surface_step_fast_poly<T, 1, true, false>(r[q], s, pl, odd))) }
+            if (kind == KIND_POLY && big && tir)   { ORT_ALL_RAYS((surface_step_fast_poly<T, 1, true, true>(r[q], s, pl, odd))) }
+        }
+        if ((ARMS == ARMS_GENERAL || ARMS == ARMS_POLY) &&
+            ((!kF32 && kind == KIND_SPHERE) || kind == KIND_CONIC || (ARMS == ARMS_POLY && kind == KIND_POLY)))
+        {   // the general forms share ONE arm:
             // as independent arms they drag their merge copies back onto the path of the sphere / flat rows (measured)
             if (!kF32 && kind == KIND_SPHERE) {
                 if (tir) { ORT_ALL_RAYS((surface_step_fast_conic<T, KIND_SPHERE, true, true>(r[q], s, odd))) }
                 else     { ORT_ALL_RAYS((surface_step_fast_conic<T, KIND_SPHERE, true, false>(r[q], s, odd))) }
             } else if (kind == KIND_CONIC) {
                 ORT_ALL_RAYS((surface_step_fast_conic<T, KIND_CONIC, true, true>(r[q], s, odd)))
-            } else if (ARMS >= ARMS_POLY) {
+            } else if (ARMS == ARMS_POLY) {
                 // polynomial rows: FORM = how p is evaluated (even form needs a finite R: the staged block is ev | qd only then)
                 const bool fin = cls & CLS_FINITE, big = cls & CLS_PBIG, even = (cls & CLS_PEVEN) && fin;
 #define ORT_POLY_ARM(FORM, FIN) { if (tir) { ORT_ALL_RAYS((surface_step_fast_poly<T, FORM, FIN, true>(r[q], s, pl, odd))) } \

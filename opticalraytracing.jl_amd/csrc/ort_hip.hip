@@ -122,7 +122,7 @@ struct ort_system {
     void* slab = nullptr;          // the one device allocation all of the above point into
     double* ap64 = nullptr;        // [nsys][S] squared clear semi-diameters (ort_system_set_apertures), or null
     float* ap32 = nullptr;
-    int arms64 = 0, arms32 = 0;    // highest ARMS level among the batch's rows: which kernel build runs it
+    int arms64 = 0, arms32 = 0;    // ARMS level of the batch (arms_of_needs over its rows): which kernel build runs it
 };
 
 namespace {
@@ -149,11 +149,11 @@ int build_records(int nsys, int rows, int ncoef, const double* R, const double* 
             int nc = 0, pcls = 0;
             if (hasp)
                 pcls = make_poly_rec<T>(pout.data() + ((size_t)s * S + i) * kPolyRec, coef + ((size_t)s * rows + (i + 1)) * ncoef, ncoef, &nc);
-            arms = std::max(arms, make_rec<T>(r, (T)ts[i], (T)Rs[i + 1], (T)ns[i], (T)ns[i + 1], Ks ? (T)Ks[i + 1] : T(0), nc, pcls));
+            arms |= make_rec<T>(r, (T)ts[i], (T)Rs[i + 1], (T)ns[i], (T)ns[i + 1], Ks ? (T)Ks[i + 1] : T(0), nc, pcls);   // NEED_* bits
             out[(size_t)s * S + i] = r;
         }
     }
-    return arms;
+    return arms_of_needs(arms);
 }
 
 template <typename T> struct Sel;
@@ -182,6 +182,7 @@ int launch_trace(ort_ctx* ctx, const TraceParams<T>& p, int64_t blocks, unsigned
 #define ORT_LAUNCH(M, A) hipLaunchKernelGGL((k_trace<T, M, A, GRID, HIST, SUMM, FT, RPT>), g, b, 0, ctx->stream, p)
     if (p.arms <= ARMS_BASIC)        { if (fast) ORT_LAUNCH(MATH_FAST, ARMS_BASIC);   else ORT_LAUNCH(MATH_IEEE, ARMS_BASIC); }
     else if (p.arms == ARMS_GENERAL) { if (fast) ORT_LAUNCH(MATH_FAST, ARMS_GENERAL); else ORT_LAUNCH(MATH_IEEE, ARMS_GENERAL); }
+    else if (p.arms == ARMS_EVEN && fast) ORT_LAUNCH(MATH_FAST, ARMS_EVEN);          // (the reference sequence has one polynomial build)
     else                             { if (fast) ORT_LAUNCH(MATH_FAST, ARMS_POLY);    else ORT_LAUNCH(MATH_IEEE, ARMS_POLY); }
 #undef ORT_LAUNCH
     HIP_TRY(hipGetLastError());
@@ -421,7 +422,7 @@ int run_full_trace(ort_ctx* ctx, TraceParams<T>& p, int nb, T* ex, T* ey, T* rho
 #define ORT_POLY_RPT1 0
 #endif
     const bool small_f64 = sizeof(T) == 8 && ((p.tiles_per_bundle <= kSmallTiles && tiles <= kSmallGridTiles && !(flags & ORT_NO_SMALL_PATH)) ||
-                                              (ORT_POLY_RPT1 && p.arms == ARMS_POLY));
+                                              (ORT_POLY_RPT1 && p.arms >= ARMS_EVEN));
     int rc;
     rc = dev_out<int32_t>(ctx, SL_TCNT, (size_t)tiles, &p.tile_cnt); if (rc) return rc;
     rc = dev_out<double>(ctx, SL_TSX, (size_t)tiles, &p.tile_sx); if (rc) return rc;

@@ -203,13 +203,13 @@ constexpr int kStatusVignetted = 1 << 17, kStatusVigShift = 20;
 // one wave's instruction stream, and RPT = 1 — the same 512-ray tile on 512 threads — halves it.  Same results bit for
 // bit (the tile sums are taken in the RPT = 2 order, tile_sum2 below).
 template <typename T, int MATH, int ARMS, bool GRID, bool HIST, bool SUMM, int FT, int RPT = kRPT>
-__global__ __launch_bounds__(kTile / RPT, ARMS == ARMS_POLY ? ORT_POLY_WAVES : ((HIST && SUMM) || FT == 3 /* FT_LOOKBACK */) ? ORT_MIN_WAVES - 1 : HIST ? ORT_MIN_WAVES : ORT_WAVES_NOHIST)
+__global__ __launch_bounds__(kTile / RPT, ARMS >= ARMS_EVEN ? ORT_POLY_WAVES : ((HIST && SUMM) || FT == 3 /* FT_LOOKBACK */) ? ORT_MIN_WAVES - 1 : HIST ? ORT_MIN_WAVES : ORT_WAVES_NOHIST)
 void k_trace(TraceParams<T> p)   // both outputs, look-back epilogue, polynomial arms: 128 VGPRs (at 96 they park tens of values per row in scratch)
 {
     constexpr int NT = kTile / RPT;                              // threads per workgroup: one tile of kTile rays
     constexpr int kSumWaves = kBlock / 64;                       // waves of the RPT = 2 shape: the order the tile sums are taken in
     static_assert(RPT == 1 || RPT == 2, "one or two rays per lane");
-    constexpr bool POLY = ARMS == ARMS_POLY;
+    constexpr bool POLY = ARMS >= ARMS_EVEN;
     __shared__ SurfRec<T> s_rec[kMaxRows];
     __shared__ __attribute__((aligned(16))) T s_poly[POLY ? kMaxRows * kPolyLds : 1];
     __shared__ int s_wcnt[NT / 64];
@@ -371,11 +371,13 @@ void k_trace(TraceParams<T> p)   // both outputs, look-back epilogue, polynomial
             const T* cf = (M == MATH) ? (s_poly + i * kPolyLds) : (gpoly ? gpoly + i * kPolyRec : nullptr);
             surface_step_n<T, M, RPT, ARMS>(ray, rec, cf, cls, i == S - 1, odd);
             if (SUMM || FT) {
+                if (SUMM) {                                          // the full_trace epilogue reads the final NaN-ness only: no count
 #pragma unroll
-                for (int r = 0; r < RPT; ++r) {
-                    // NaN is sticky (every later transfer propagates it), so the 1-based index of the first
-                    // NaN surface is 1 + the number of surfaces with ordered (x, y): one v_cmp_o + one add.
-                    st[r] += __builtin_isunordered(ray[r].x, ray[r].y) ? 0 : 1;
+                    for (int r = 0; r < RPT; ++r) {
+                        // NaN is sticky (every later transfer propagates it), so the 1-based index of the first
+                        // NaN surface is 1 + the number of surfaces with ordered (x, y): one v_cmp_o + one add.
+                        st[r] += __builtin_isunordered(ray[r].x, ray[r].y) ? 0 : 1;
+                    }
                 }
                 if (i == stop_u) {
                     const T a2 = a_stop * a_stop, alim = (T)Near<T>::thr * a2;
@@ -395,7 +397,7 @@ void k_trace(TraceParams<T> p)   // both outputs, look-back epilogue, polynomial
                         const T r2 = ray[r].x * ray[r].x + ray[r].y * ray[r].y;
                         if (M == MATH_FAST) odd = odd || near_zero<T>(r2 - a2, (T)Near<T>::thr * a2);
                         st[r] |= (r2 > a2) ? kStatusVignetted : 0;
-                        st[r] += (st[r] & kStatusVignetted) ? 0 : (1 << kStatusVigShift);
+                        if (SUMM) st[r] += (st[r] & kStatusVignetted) ? 0 : (1 << kStatusVigShift);
                     }
                 }
             }

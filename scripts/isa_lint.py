@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Build-side guard for the hot loop of the FAST trace kernels (runs here, no GPU): compiles the library to
-gfx950 assembly and checks, for the history and the summary kernel,
+gfx950 assembly and checks, for the history and the summary kernel (and the even-asphere build's statistics kernel),
   * the centre-form sphere arms (the blocks with exactly 4 v_rsq_f64 and no v_rcp_f64) carry no v_mov_b64,
   * no other block of the hot surface loop is a pure copy block (>= 10 v_mov_b64 in <= 20 instructions),
   * no scratch (spill) instruction in the centre-form sphere and flat arms of the hot surface loop (the blocks laid out
@@ -12,7 +12,11 @@ import os, re, subprocess, sys, tempfile
 from collections import Counter
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 KERNELS = {"history": "_ZN3ort7k_traceIdLi1ELi0ELb1ELb1ELb0ELi0ELi2EEEvNS_11TraceParamsIT_EE",
-           "summary": "_ZN3ort7k_traceIdLi1ELi0ELb1ELb0ELb1ELi0ELi2EEEvNS_11TraceParamsIT_EE"}
+           "summary": "_ZN3ort7k_traceIdLi1ELi0ELb1ELb0ELb1ELi0ELi2EEEvNS_11TraceParamsIT_EE",
+           # the even-asphere build (ARMS_EVEN), statistics-only full_trace (config 3): its sphere arms may end in the copy
+           # of one ray's (x, y) for the stop capture, nothing more
+           "even_stats": "_ZN3ort7k_traceIdLi1ELi2ELb1ELb0ELb0ELi2ELi2EEEvNS_11TraceParamsIT_EE"}
+MOV_ALLOWANCE = {"even_stats": 2}
 with tempfile.TemporaryDirectory(dir=os.path.join(ROOT, "build") if os.path.isdir(os.path.join(ROOT, "build")) else None) as td:
     asm = os.path.join(td, "ort.s")
     subprocess.run(["hipcc", "--offload-arch=gfx950", "-O3", "-ffp-contract=off", "-std=c++17", "-fno-slp-vectorize",
@@ -48,7 +52,7 @@ for tag, name in KERNELS.items():
     # the general (grouped) arm keeps its own merge copies; they must not sit on the sphere / flat path:
     # heuristically, at most one pure copy block may remain in the hot loop.  Spills are tolerated only outside it
     # (the MATH_IEEE retrace of a wave that left the fast forms' domain is cold code).
-    ok = scratch_hot == 0 and len(arms) >= 2 and all(m == 0 for m in arm_movs[:2]) and len(copy_blocks) <= 1
+    ok = scratch_hot == 0 and len(arms) >= 2 and all(m <= MOV_ALLOWANCE.get(tag, 0) for m in arm_movs[:2]) and len(copy_blocks) <= 1
     print(f"{tag}: {n_inst} instructions ({sum(len(b) for _, b in hot_blocks)} in the hot loop), scratch in the hot loop's centre-form sphere / flat arms {scratch_hot} "
           f"(kernel {scratch_all}), sphere arms VALU {arm_valu[:2]} with v_mov_b64 {arm_movs[:2]}, pure copy blocks {copy_blocks} "
           f"-> {'ok' if ok else 'REGRESSION'}")
