@@ -11,15 +11,20 @@ measures: the other arithmetic policy, a sustained figure over >= 1 s of launche
 config 3 (aspheric, 2048^2 pupil) through full_trace with the stop-filter compaction, an oracle check of a
 strided sample of the timed kernel's output, and the CPU baseline.
 
-N > 1 (BASELINE.json configs[3], the multi-GPU workload): zoom-lens sweep, 32 positions x 5 index columns x
-5 fields x 512^2 pupil = 209,715,200 rays, 2.52e9 intersections per step, STRONG scaling: the 800 bundles are
-split into contiguous rank-ordered slabs (no data-path collective), every rank traces its slab in summary
-mode into a packed [2][n] hit slab, and ONE RCCL all-gather per step reassembles the image-plane hits of the
-whole sweep on every rank in the reference's append order (src/PupilSampling.jl:134-137).  The all-gather is
-INSIDE the timed region, on the communicator's own stream, overlapped with the next step's trace.
-The same line also carries the gather-exclusive rate, the all-gather alone, rank 0's bit-for-bit check of the gathered
-hits against its own single-rank trace (and that rate as the strong-scaling reference) and, under `extra`, the spot-
-statistics form of the sweep: one `ort_spot_batch` call per rank and a 16-B-per-bundle all-gather — nothing ray-sized moves.
+N > 1: the SAME workload and metric under WEAK scaling — the path shards over independent (system, field, index column,
+pupil row) units (src/PupilSampling.jl:34-65 is a pure function of its arguments), so rank r traces its own instance of
+the batch (zoom position r of the same Double-Gauss: the same 9 bundles x 1024^2 rays x S = 12) with NO collective in the
+data path; the K steps are bracketed by a barrier + synchronize on both sides, the slowest rank's time counts, `value` =
+N x 113,246,208 x K / that time.  One curve over N = 1, 2, 4, 8 is therefore one workload.
+The exchange step north_star names — reassembling the image-plane hits of a sharded sweep — is measured in the same run
+and reported under `extra.config4_allgather` (BASELINE.json configs[3]): zoom-lens sweep, 32 positions x 5 index columns
+x 5 fields x 512^2 pupil = 209,715,200 rays, 2.52e9 intersections per step, STRONG scaling: the 800 bundles are split
+into contiguous rank-ordered slabs, every rank traces its slab in summary mode into a packed [2][n] hit slab, and ONE
+RCCL all-gather per step reassembles the hits of the whole sweep on every rank in the reference's append order
+(src/PupilSampling.jl:134-137), inside that leg's timed region, on the communicator's own stream, overlapped with the
+next step's trace.  The leg carries its gather-exclusive rate, the all-gather alone, rank 0's bit-for-bit check of the
+gathered hits against its own single-rank trace and the spot-statistics form of the sweep (one `ort_spot_batch` call per
+rank and a 16-B-per-bundle all-gather — nothing ray-sized moves).  `--workload config4` runs that leg alone.
 
 Prints ONE JSON line on rank 0.
 """
@@ -137,13 +142,20 @@ def timed_launches(eng, fn, steps: int, warmup: int = 2):
     return eng.ctx.timer_stop() / steps
 
 
-def bench_single(args, torch, rank, world, local_rank):
+def bench_single(args, torch, rank, world, local_rank, emit=True):
+    """The headline workload (BASELINE config 2, one trace launch per step).  world > 1: WEAK scaling — every rank traces
+    its own instance of the batch (zoom position `rank` of the same Double-Gauss: the same 9 bundles x k^2 rays x S = 12),
+    no collective anywhere in the data path; the K steps are bracketed by a barrier + synchronize on both sides and the
+    slowest rank's time counts.  Returns the result dict on rank 0 (printed when `emit`)."""
     import ctypes as C
     import numpy as np
     import opticalraytracing_jl_amd as ort
-    from opticalraytracing_jl_amd import _capi, api, workloads
+    from opticalraytracing_jl_amd import _capi, api, dist as odist, workloads
 
     fast = args.policy == "fast"
+    backend = os.environ.get("ORT_BENCH_BACKEND", "nccl")     # "gloo": rehearsal of N > 1 on a 1-GPU box
+    if world > 1 and backend == "nccl" and world > torch.cuda.device_count():
+        raise SystemExit(f"{world} ranks but {torch.cuda.device_count()} GPUs: one process per GPU")
     local_dev = local_rank % torch.cuda.device_count()
     torch.cuda.set_device(local_dev)
     dev = torch.device("cuda", local_dev)
@@ -157,7 +169,10 @@ def bench_single(args, torch, rank, world, local_rank):
 
     # ---- untimed setup: solve (paraxial + ABCD kernels), bundle descriptors, device buffers ----
     k = args.pupil
-    pres, bundles, axes = workloads.config2(api, k, engine=eng)
+    dist = odist.init_process_group(backend) if world > 1 else None
+    # rank r > 0: zoom position r of BASELINE config 4's sweep (the two air gaps around the stop moved by +-0.1 r mm):
+    # another prescription, the same shape and cost; rank 0 = the N = 1 system
+    pres, bundles, axes = workloads.config2(api, k, engine=eng, gap_shift=0.1 * rank)
     nb, rpb = len(bundles), k * k
     N, S = nb * rpb, pres.rows - 1
     inter = N * S
@@ -220,17 +235,29 @@ def bench_single(args, torch, rank, world, local_rank):
     for _ in range(args.warmup):
         step()
     torch.cuda.synchronize(dev)
+    if dist is not None:
+        odist.barrier(local_dev)
+        torch.cuda.synchronize(dev)
     eng.ctx.timer_start()                                   # hipEventRecord on the launch stream
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
     ev_ms = eng.ctx.timer_stop()                            # hipEventSynchronize + elapsed
     torch.cuda.synchronize(dev)
+    if dist is not None:
+        odist.barrier(local_dev)
     wall = time.perf_counter() - t0
+    per_rank = None
+    if dist is not None:                                    # the slowest rank's time counts; every rank's own time is reported
+        tw = torch.tensor([wall], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
+        allw = [torch.empty_like(tw) for _ in range(world)]
+        dist.all_gather(allw, tw)
+        per_rank = [float(t[0]) / args.steps * 1e3 for t in allw]
+        wall = max(float(t[0]) for t in allw)
 
     kernel_ms = ev_ms / args.steps
     achieved = algo_bytes / (kernel_ms * 1e-3) / 1e9
-    value = inter * args.steps / wall
+    value = world * inter * args.steps / wall
 
     # ---- correctness of what was just timed: a strided sample of the history against the CPU oracle ----
     verify = None
@@ -240,9 +267,15 @@ def bench_single(args, torch, rank, world, local_rank):
         except Exception as exc:                                # noqa: BLE001 — reported as not verified, never hidden
             verify = {"verified": False, "error": f"{type(exc).__name__}: {exc}"}
 
+    if dist is not None and verify is not None:             # every rank checked its own history: all of them must agree
+        vf = torch.tensor([1 if verify.get("verified") else 0], dtype=torch.int32, device=dev if backend == "nccl" else "cpu")
+        dist.all_reduce(vf, op=dist.ReduceOp.MIN)
+        verify["verified_on_every_rank"] = bool(int(vf[0]))
+        verify["verified"] = bool(verify.get("verified")) and bool(int(vf[0]))
+
     # ---- the other arithmetic policy, same launch, reported beside the headline ----
     other = None
-    if args.mode != "full_trace":
+    if args.mode != "full_trace" and world == 1:
         ofl = (fl & ~_capi.ORT_FAST_MATH) if fast else (fl | _capi.ORT_FAST_MATH)
         ostep = grid_step(out, ofl)
         osus = None
@@ -413,7 +446,7 @@ def bench_single(args, torch, rank, world, local_rank):
         return extra
 
     extra = {}
-    if not args.no_extras and args.mode == "history":
+    if not args.no_extras and args.mode == "history" and world == 1:
         try:
             extra = run_extras()
         except Exception as exc:                                # noqa: BLE001 — the headline line must still be printed
@@ -434,7 +467,7 @@ def bench_single(args, torch, rank, world, local_rank):
             traffic = None
     res = {
         "metric": METRIC, "value": value, "unit": "ray-surface intersections/s",
-        "n_gpus": 1, "steps": args.steps, "warmup": args.warmup,
+        "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": wall / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": "f64", "data": "synthetic",
         "config": {"workload": f"Double-Gauss 10 spherical surfaces + stop + image (S={S}), 3 fields x 3 index "
@@ -448,7 +481,11 @@ def bench_single(args, torch, rank, world, local_rank):
                                      "reflected ray, a far-cap hit, a backward direction or a polynomial row outside its conic retraces "
                                      "with the reference sequence (bit-identical there); tests/test_gpu_parity.py::_fast_attribution, "
                                      "tests/test_device_emulation.py"),
-                   "parallelism": "1 GPU", "device": info["name"]},
+                   "parallelism": "1 GPU" if world == 1 else
+                                  (f"{world} ranks (one process per GPU), WEAK scaling: every rank traces its own zoom position of the same "
+                                   "batch — the path shards over independent (system, field, index column) units, no data-path collective; "
+                                   "barrier + synchronize around the K steps, slowest rank counts"),
+                   "device": info["name"]},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_source,
                      "kernel": f"ort::k_trace<double, {1 if fast else 0}, ...>", "kernel_ms": kernel_ms,
@@ -473,17 +510,29 @@ def bench_single(args, torch, rank, world, local_rank):
         res["other_policy"] = other
     if extra:
         res["extra"] = extra
-    if not args.no_cpu_baseline:
+    if world > 1:
+        res["ms_per_step_per_rank"] = per_rank
+        res["nranks_seen"] = dist.get_world_size()
+        res["roofline"]["note"] = "per GPU: rank 0's kernel, hipEvents on its launch stream"
+        res["backend"] = backend
+    if not args.no_cpu_baseline and world == 1:
         try:
             res["cpu_baseline"] = cpu_baseline(api, pres, bundles, axes, k)
             res["cpu_baseline"]["gpu_over_cpu_1core"] = value / res["cpu_baseline"]["value"]
         except Exception as exc:                                # noqa: BLE001
             res["cpu_baseline"] = {"error": f"{type(exc).__name__}: {exc}"}
-    print(json.dumps(res), flush=True)
+    if emit and rank == 0:
+        print(json.dumps(res), flush=True)
+    del xv, yv
+    torch.cuda.empty_cache()
+    return res if rank == 0 else None
 
 
-def bench_multi(args, torch, rank, world, local_rank):
-    """BASELINE config 4, strong scaling over the ranks (see the module docstring)."""
+def bench_multi(args, torch, rank, world, local_rank, emit=True, headline=None):
+    """BASELINE config 4, strong scaling over the ranks: the sweep's bundles split into rank-ordered slabs + ONE all-gather
+    of the image-plane hits per step (see the module docstring).  Returns the result dict on rank 0 (printed when `emit`).
+    `headline`: the already measured weak-scaling line this leg is an extra of (printed with the error if the
+    communicator cannot be built)."""
     import numpy as np
     import opticalraytracing_jl_amd as ort
     from opticalraytracing_jl_amd import batch, dist as odist, workloads
@@ -550,12 +599,18 @@ def bench_multi(args, torch, rank, world, local_rank):
             if th.is_alive():
                 # ncclCommInitRank did not return: a thread of this process is still inside RCCL on this GPU.  Nothing may
                 # run beside a half-built communicator — report and leave (every rank times out the same way)
-                if rank == 0:
+                err = ("RCCL rendezvous timeout: ort_comm_create (ncclCommInitRank) did not return within "
+                       f"{os.environ.get('ORT_BENCH_COMM_TIMEOUT_S', '180')} s")
+                if rank == 0 and headline is not None:          # the weak-scaling line stands; this leg is reported as failed
+                    headline.setdefault("extra", {})["config4_allgather"] = {"error": err, "nranks_seen": None}
+                    headline["exchange_leg_ok"] = False
+                    print(json.dumps(headline), flush=True)
+                elif rank == 0:
                     print(json.dumps({"metric": METRIC, "value": None, "unit": "ray-surface intersections/s", "n_gpus": world,
-                                      "error": "RCCL rendezvous timeout: ort_comm_create (ncclCommInitRank) did not return within "
-                                               f"{os.environ.get('ORT_BENCH_COMM_TIMEOUT_S', '180')} s", "nranks_seen": None}), flush=True)
+                                      "error": err, "nranks_seen": None}), flush=True)
                 sys.stdout.flush()
-                os._exit(3)
+                sys.stderr.write("bench.py: " + err + "\n"); sys.stderr.flush()
+                os._exit(0 if headline is not None else 3)
             if "err" in made:
                 raise made["err"]
             comm = made["comm"]
@@ -694,6 +749,7 @@ def bench_multi(args, torch, rank, world, local_rank):
                  "finite": bool(torch.isfinite(gath[:, 1]).all()), "kept_fraction": float(gath[:, 0].sum()) / rays_stats / 2.0}
     if dist is not None:
         odist.barrier(local_dev)
+    res = None
     if rank == 0:
         msg_bytes = 2.0 * esz * slab
         res = {
@@ -732,11 +788,13 @@ def bench_multi(args, torch, rank, world, local_rank):
             res["strong_scaling_reference"] = ref
         if stats is not None:
             res["extra"] = {"spot_statistics": stats}
-        print(json.dumps(res), flush=True)
+        if emit:
+            print(json.dumps(res), flush=True)
     if comm is not None:
         comm.close()
     if dist is not None:
         dist.destroy_process_group()
+    return res
 
 
 def spawn_ranks(n: int, argv, timeout_s: float = 3300.0):
@@ -845,12 +903,23 @@ def main():
     import torch
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the engine has no CPU fallback")
-    multi = args.workload in ("config4", "config5") or (args.workload == "auto" and world > 1)
-    if multi:
+    if args.workload in ("config4", "config5"):
         bench_multi(args, torch, rank, world, local_rank)
+    elif world > 1 and args.workload == "auto":
+        # N > 1: the headline workload under weak scaling, then the exchange step (config 4 + all-gather) as an extra of the line
+        res = bench_single(args, torch, rank, world, local_rank, emit=False)
+        leg = None
+        if not args.no_extras:
+            try:
+                leg = bench_multi(args, torch, rank, world, local_rank, emit=False, headline=res)
+            except Exception as exc:                            # noqa: BLE001 — the headline line must still be printed
+                leg = {"error": f"{type(exc).__name__}: {exc}"}
+        if rank == 0:
+            if leg is not None:
+                res.setdefault("extra", {})["config4_allgather"] = leg
+                res["exchange_leg_ok"] = bool(leg.get("verified")) and "error" not in leg
+            print(json.dumps(res), flush=True)
     else:
-        if world > 1:
-            raise SystemExit("--workload config2 is the single-GPU line; N > 1 runs config 4")
         bench_single(args, torch, rank, world, local_rank)
 
 

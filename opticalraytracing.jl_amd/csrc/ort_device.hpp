@@ -17,7 +17,7 @@
 //              cosine of incidence on a sphere, and the sphere's normal needs no square root:
 //              2 rsq + 1 rcp seeds per ray-surface instead of 4 IEEE sqrt + 6 IEEE divisions.
 //              Seeds (v_rsq_f64 / v_rcp_f64, 2^-24 accurate, measured: tools/ubench.hip) are
-//              refined by ONE cubically convergent step to <= 1 ulp.  Rows carrying a
+//              refined by ONE Newton step to ~2^-49.  Rows carrying a
 //              polynomial term keep the reference's slope form (its additive p(y) is a quirk,
 //              not a geometric intersection, Q2).  Differs from MATH_IEEE by rounding only
 //              (tested <= 1e-12 relative, bar 1e-10).  The forms hold for the rays a lens passes; where the
@@ -117,25 +117,17 @@ __device__ __forceinline__ double t_abs(double a) { return __builtin_fabs(a); }
 __device__ __forceinline__ float t_abs(float a) { return __builtin_fabsf(a); }
 
 // Fast reciprocal / reciprocal square root (MATH_FAST): hardware seed (relative error
-// 2^-24.4 / 2^-24.2 on gfx950, tools/ubench.hip) + ONE cubically convergent step:
-//   1/a      = r0 (1 + e + e^2 + ...),        e = 1 - a r0        -> error e^3  ~ 2^-73
-//   1/sqrt a = r0 (1 + e/2 + 3e^2/8 + ...),   e = 1 - a r0^2      -> error 5e^3/16 ~ 2^-71
-#ifndef ORT_QUAD
-#define ORT_QUAD 1
-#endif
-#ifndef ORT_UNNORM
-#define ORT_UNNORM 1
-#endif
+// 2^-24.4 / 2^-24.2 on gfx950, tools/ubench.hip) + ONE Newton step:
+//   1/a      = r0 (1 + e),      e = 1 - a r0        -> error e^2      ~ 2^-48.8
+//   1/sqrt a = r0 (1 + e/2),    e = 1 - a r0^2      -> error 3/8 e^2  ~ 2^-49.8
+// (the accuracy sqrt_core below always had; the cubically convergent step of rounds 1-2 bought 2^-71 for one more FMA per
+// seed — measured on configs 2 and 3: worst deviation from the reference sequence 3.7e-13 / 2.9e-13 with it, 3.7e-13 /
+// 1.9e-13 without, bar 1e-10.)
 __device__ __forceinline__ double fast_rcp(double a)
 {
     const double r0 = __builtin_amdgcn_rcp(a);
     const double e = __builtin_fma(-a, r0, 1.0);
-#if ORT_QUAD
     return __builtin_fma(r0, e, r0);
-#else
-    const double p = __builtin_fma(e, e, e);
-    return __builtin_fma(r0, p, r0);
-#endif
 }
 __device__ __forceinline__ float fast_rcp(float a)
 {
@@ -146,16 +138,9 @@ __device__ __forceinline__ float fast_rcp(float a)
 __device__ __forceinline__ double fast_rsqrt(double a)
 {
     const double r0 = __builtin_amdgcn_rsq(a);
-    const double t = a * r0;
-#if ORT_QUAD
-    const double h = 0.5 * r0;
+    const double t = a * r0, h = 0.5 * r0;
     const double e = __builtin_fma(-t, r0, 1.0);
     return __builtin_fma(h, e, r0);
-#else
-    const double e = __builtin_fma(-t, r0, 1.0);
-    const double p = __builtin_fma(0.375, e, 0.5);
-    return __builtin_fma(r0, e * p, r0);
-#endif
 }
 __device__ __forceinline__ float fast_rsqrt(float a)
 {
@@ -553,7 +538,6 @@ __device__ __forceinline__ void surface_step_fast_poly(Ray<T>& r, const SurfRec<
     r.sprev = sg;
     T tx, ty;
     poly_tilt_fast<T, FORM>(pl, r.x, r.y, xx, yy, is, tx, ty);   // Q2: p'(x) on the x slope, p'(y) on the y slope
-#if ORT_UNNORM
     // un-normalised normal N = (tx, ty, -1), |N|^2 = n2, gu = -k.N:  with g = gu / |N| the reference's
     //   k' = eta k + (eta g - sqrt(1 - eta^2 (1 - g^2))) N / |N|  =  eta k + (eta gu - sqrt(W)) N / n2,
     //   W = (1 - eta^2) n2 + eta^2 gu^2 = n2 (1 - eta^2 (1 - g^2)):  the root and the reciprocal are independent of each
@@ -565,16 +549,6 @@ __device__ __forceinline__ void surface_step_fast_poly(Ray<T>& r, const SurfRec<
     // the reference sequence: 1 - eta^2 (1 - g^2) < thr  <=>  W < thr n2
     if (TIR) odd = odd || (W < Near<T>::thr * n2);
     const T cf = t_fma<T>(s.eta, gu, -sqrt_core(W)) * fast_rcp(n2);
-#else
-    const T inv = fast_rsqrt(t_fma<T>(tx, tx, t_fma<T>(ty, ty, T(1))));
-    // un-normalised normal N = (tx, ty, -1), m = N inv:  g = -k.m,  k' = eta k + (eta g - sqrt(D2)) inv N
-    const T g = t_fma<T>(-r.k1, ty, t_fma<T>(-r.k0, tx, r.k2)) * inv;
-    const T D2 = t_fma<T>(-s.eta2, t_fma<T>(-g, g, T(1)), T(1));
-    // TIR rows: total internal reflection (D2 < 0: the reference leaves k untouched, Q1) and its neighbourhood (:25) are
-    // left to the reference sequence — one compare instead of a compare and four selects; a NaN ray is neither
-    if (TIR) odd = odd || (D2 < Near<T>::thr);
-    const T cf = t_fma<T>(s.eta, g, -sqrt_core(D2)) * inv;
-#endif
     const T ee = s.eta;
     // product on the OLD component first, then accumulate into it: the two-address v_fmac then updates k in
     // place (the other association lands in a temporary and costs a v_mov per component)
