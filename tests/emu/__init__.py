@@ -39,9 +39,15 @@ def trace(pres, y, x, u, v, fast: bool, isys: int = 0):
     y, x, u, v = (f(a) for a in np.broadcast_arrays(y, x, u, v))
     N, S = y.size, R.size - 1
     xv = np.empty((S, N)); yv = np.empty((S, N)); odd = np.zeros(N, dtype=np.int32)
+    arms = C.c_int(-1)
     lib().emu_trace(1 if fast else 0, R.size, _p(R), _p(t), _p(n), _p(K), _p(coef), nc, C.c_long(N), _p(y), _p(x), _p(u), _p(v),
-                    _p(xv), _p(yv), odd.ctypes.data_as(C.POINTER(C.c_int)))
+                    _p(xv), _p(yv), odd.ctypes.data_as(C.POINTER(C.c_int)), C.byref(arms))
+    global last_arms
+    last_arms = arms.value            # the kernel build the host would launch for this system (ARMS_*: 0 basic .. 3 everything)
     return xv, yv, odd.astype(bool)
+
+
+last_arms = -1
 
 
 def trace_fast_with_retrace(pres, y, x, u, v, isys: int = 0):

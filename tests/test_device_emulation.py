@@ -62,8 +62,11 @@ def test_polynomial_arms_even_and_general_forms(oracle_engine):
     c_odd = coef.copy(); c_odd[7, 3] = 4e-6; c_odd[1, 5] = -3e-9                                               # general, <= 8
     c_odd12 = np.zeros((coef.shape[0], 12)); c_odd12[:, :7] = c_odd; c_odd12[11, 11] = 1e-18; c_odd12[5, 9] = 2e-15
     cases = {"config3": coef, "even6": c10, "odd8": c_odd, "odd12": c_odd12}
+    builds = {"config3": 2, "even6": 2, "odd8": 3, "odd12": 3}          # ARMS_EVEN for the even aspheres, ARMS_POLY otherwise
     for tag, c in cases.items():
         pres = pres_with(c)
+        emu.trace(pres, y[:1], x[:1], u[:1], v[:1], fast=True)
+        assert emu.last_arms == builds[tag], (tag, emu.last_arms)
         ox, oy = oracle_engine.skew(pres, y, x, u, v, slopes=True)
         ex, ey, _ = emu.trace(pres, y, x, u, v, fast=False)
         # the reference takes p' by a complex step (RayTracing.jl:103), the device analytically: O(eps^2) apart
@@ -72,6 +75,13 @@ def test_polynomial_arms_even_and_general_forms(oracle_engine):
         assert np.array_equal(np.isnan(fx), np.isnan(ox)), tag
         assert max(cm.rel_err(fx, ox, 1.0).max(), cm.rel_err(fy, oy, 1.0).max()) <= 1e-11, tag
         assert odd.mean() < 0.01, tag
+    # an even asphere beside a row the even-asphere build does not carry (|R| > 1e3: vertex-form sphere) -> the full build
+    weak = ext.copy(); weak[3, 0] = 2500.0
+    pres = Prescription(weak[:, 0], weak[:, 1], weak[:, 2], weak[:, 3], np.vstack([coef, np.zeros((1, coef.shape[1]))])[None])
+    ox, oy = oracle_engine.skew(pres, y, x, u, v, slopes=True)
+    fx, fy, odd = emu.trace_fast_with_retrace(pres, y, x, u, v)
+    assert emu.last_arms == 3
+    assert np.array_equal(np.isnan(fx), np.isnan(ox)) and max(cm.rel_err(fx, ox, 1.0).max(), cm.rel_err(fy, oy, 1.0).max()) <= 1e-11
     # a plane surface with a polynomial: sag = 0 WITHOUT p(y) (PupilSampling.jl:12), tilt = p' only (:18)
     S = np.array([[math.inf, 0.0, 1.0, 0.0], [math.inf, 4.0, 1.52, 0.0], [-80.0, 30.0, 1.0, 0.0], [math.inf, 0.0, 1.0, 0.0]])
     c = np.zeros((4, 7)); c[1, 2] = 1e-4; c[1, 4] = -3e-7

@@ -852,6 +852,46 @@ def _fast_attribution(fast, oracle_engine, pres, y, x, u, v, tag):
     return y.size, int((err > FAST_TOL).sum()), int((mg[:, 3] > 0).sum())
 
 
+def test_polynomial_forms_on_device(hip_engine, oracle_engine):
+    """Every polynomial arm of the FAST policy on the device, and the build each system is launched with: BASELINE config
+    3's rows (conic + 4-term even form: the even-asphere build), a 10th-order even asphere (6-term even form, same build),
+    odd coefficients (general forms of <= 8 and <= 12 coefficients: the full build), an even asphere beside a vertex-form
+    sphere (|R| > 1e3: full build) and a plane carrying a polynomial (Schmidt-like; sag = 0 WITHOUT p(y),
+    src/PupilSampling.jl:12, tilt = p' only, :18).  Status identical on every ray, coordinates <= 1e-11 (both policies:
+    the reference takes p' by a complex step, src/RayTracing.jl:103, the device analytically)."""
+    fast = ort.HipEngine(0, fast_math=True)
+    M4, coef = cm.double_gauss_aspheric()
+    ext = np.vstack([M4, [math.inf, 0.0, 1.0, 0.0]]); ext[-2, 1] = 57.8
+    rng = np.random.default_rng(3)
+    m = 6000
+    y = rng.uniform(-14, 14, m); x = rng.uniform(-14, 14, m)
+    u = np.tan(rng.uniform(-0.1, 0.1, m)); v = np.tan(rng.uniform(-0.1, 0.1, m))
+    c10 = np.zeros((coef.shape[0], 11)); c10[:, :7] = coef; c10[1, 8] = 3e-14; c10[5, 10] = -2e-16
+    c_odd = coef.copy(); c_odd[7, 3] = 4e-6; c_odd[1, 5] = -3e-9
+    c_odd12 = np.zeros((coef.shape[0], 12)); c_odd12[:, :7] = c_odd; c_odd12[11, 11] = 1e-18; c_odd12[5, 9] = 2e-15
+    weak = ext.copy(); weak[3, 0] = 2500.0
+    S = np.array([[math.inf, 0.0, 1.0, 0.0], [math.inf, 4.0, 1.52, 0.0], [-80.0, 30.0, 1.0, 0.0], [math.inf, 0.0, 1.0, 0.0]])
+    cs = np.zeros((4, 7)); cs[1, 2] = 1e-4; cs[1, 4] = -3e-7
+    cases = [("config3", ext, coef), ("even6", ext, c10), ("odd8", ext, c_odd), ("odd12", ext, c_odd12), ("weak", weak, coef)]
+    for tag, M, c in cases:
+        c = np.vstack([c, np.zeros((1, c.shape[1]))])
+        pres = Prescription(M[:, 0], M[:, 1], M[:, 2], M[:, 3], c[None])
+        ox, oy, os_ = oracle_engine.skew(pres, y, x, u, v, slopes=True, want_status=True)
+        assert (os_ == M.shape[0]).mean() > 0.3, tag                  # a good share of the bundle reaches the image
+        for eng in (hip_engine, fast):
+            gx, gy, gs = eng.skew(pres, y, x, u, v, slopes=True, want_status=True)
+            assert np.array_equal(gs, os_), tag
+            assert np.array_equal(np.isnan(gx), np.isnan(ox)) and np.array_equal(np.isnan(gy), np.isnan(oy)), tag
+            assert max(cm.rel_err(gx, ox, 1.0).max(), cm.rel_err(gy, oy, 1.0).max()) <= 1e-11, (tag, eng is fast)
+    pres = Prescription(S[:, 0], S[:, 1], S[:, 2], S[:, 3], cs[None])
+    ys, xs = y * 0.5, x * 0.5
+    ox, oy, os_ = oracle_engine.skew(pres, ys, xs, u * 0.5, v * 0.5, slopes=True, want_status=True)
+    for eng in (hip_engine, fast):
+        gx, gy, gs = eng.skew(pres, ys, xs, u * 0.5, v * 0.5, slopes=True, want_status=True)
+        assert np.array_equal(gs, os_)
+        assert max(cm.rel_err(gx, ox, 1.0).max(), cm.rel_err(gy, oy, 1.0).max()) <= 1e-11
+
+
 def test_random_systems_property(hip_engine, oracle_engine):
     """120 random prescriptions (2-14 rows; flat rows, both curvature signs, conics, polynomial
     terms, glass/air sequences that TIR and miss) x 1500 random skew rays each: the IEEE policy is
