@@ -424,6 +424,18 @@ def bench_single(args, torch, rank, world, local_rank, emit=True):
         extra["config3_statistics_only"] = {
             "workload": "same bundles, statistics-only route (count, RMS per bundle: 16 B per bundle out)",
             "pipeline_ms": ms, "value": N3 * S3 / (ms * 1e-3), "bound": "FP64 VALU", "mean_rms": float(rms.mean().item())}
+        sq3 = newest_profile("sq_config3_trace_before_after.json")       # committed counter + clock pass of this kernel (static)
+        if sq3 and fast:
+            try:
+                c3 = json.load(open(sq3))
+                c3 = c3[sorted(c3)[-1]]                                   # the newest build of the pass
+                extra["config3_statistics_only"]["valu_roofline"] = {
+                    "valu_instructions_per_intersection": c3["valu_per_wave"] / (128.0 * S3),
+                    "issue_slot_utilisation": c3["valu_issue_utilisation"], "effective_clock_GHz": c3["clock_GHz"],
+                    "note": "SQ_ACTIVE_INST_VALU over SQ_BUSY_CU_CYCLES; clock = GRBM_GUI_ACTIVE / 8 XCDs / kernel time",
+                    "source": f"profiles/{os.path.basename(sq3)} (static; scripts/clock_config3.sh)"}
+            except Exception:                                   # noqa: BLE001 — an optional annotation
+                pass
         del ex, ey, rho, th
         torch.cuda.empty_cache()
         # BASELINE config 5: Seidel / spot Monte-Carlo over perturbed instances, Float32 pupil trace, ONE C call

@@ -655,14 +655,24 @@ int spot_batch_impl(ort_ctx* ctx, int nsys, int rows, const double* R, const dou
     TraceParams<T> p;
     memset(&p, 0, sizeof p);
     p.recs = d_rec; p.polys = d_poly; p.S = S; p.bundles = d_bd; p.axes = d_axes;
-    // which kernel build: coefficients -> polynomial arms; conic constants, or a Float64 row too weak for the centre form
-    // (|R| > kCentreFormMaxR; device-resident prescriptions cannot be inspected: assume one) -> general arms
-    p.arms = ncoef > 0 ? ARMS_POLY : ARMS_BASIC;
-    if (p.arms == ARMS_BASIC) {
-        bool general = K != nullptr || (devp && sizeof(T) == 8);
-        if (!devp && sizeof(T) == 8)
-            for (size_t i = 0; i < nr && !general; ++i) general = std::isfinite(R[i]) && std::fabs(R[i]) > kCentreFormMaxR;
-        if (general) p.arms = ARMS_GENERAL;
+    // which kernel build (device-resident prescriptions cannot be inspected: coefficients -> every arm; conic constants, or
+    // Float64, where a row may be too weak for the centre form -> general arms)
+    if (!devp) {
+        // host-visible prescriptions: classify every row exactly as the device-side table builder will (make_poly_rec /
+        // make_rec, ort_device.hpp) and run the build its rows need — an even asphere gets the even-asphere build
+        int needs = 0;
+        T prec[kPolyRec];
+        for (int s = 0; s < nsys; ++s)
+            for (int i = 0; i + 1 < rows; ++i) {
+                const size_t r0 = (size_t)s * rows;
+                int nc = 0, pcls = 0;
+                if (ncoef > 0) pcls = make_poly_rec<T>(prec, coef + (r0 + i + 1) * (size_t)ncoef, ncoef, &nc);
+                SurfRec<T> rec;
+                needs |= make_rec<T>(rec, (T)t[r0 + i], (T)R[r0 + i + 1], (T)n[r0 + i], (T)n[r0 + i + 1], K ? (T)K[r0 + i + 1] : T(0), nc, pcls);
+            }
+        p.arms = arms_of_needs(needs);                              // (the appended image row is a plane: basic arms)
+    } else {
+        p.arms = ncoef > 0 ? ARMS_POLY : ((K != nullptr || sizeof(T) == 8) ? ARMS_GENERAL : ARMS_BASIC);
     }
     p.ny = k_rays; p.nx = k2; p.rpb = rpb; p.tiles_per_bundle = (int)((rpb + kTile - 1) / kTile);
     auto nblk = [](int64_t n, int b) { return dim3((unsigned)((n + b - 1) / b)); };

@@ -39,7 +39,7 @@ def devi(ax, ay, bx, by):
 
 for case in range(ncase):
     rows = int(rng.integers(2, 15))
-    aspheric = case % 3 == 0
+    aspheric = (True, "even", False)[case % 3]
     R, t, n, K, coef = _random_system(rng, rows, aspheric)
     wide = case % 5 == 4
     if wide:                                # strongly curved rows and wide bundles: far-cap hits, TIR and misses

@@ -17,7 +17,7 @@ hip = ort.HipEngine(0); fast = ort.HipEngine(0, fast_math=True); orc = OracleEng
 bad = worst_fast = 0; nfr = ntot = 0
 for case in range(nsys):
     rows = int(rng.integers(2, 20))
-    aspheric = case % 3 == 0
+    aspheric = (True, "even", False)[case % 3]
     R, t, n, K, coef = _random_system(rng, rows, aspheric)
     if case % 7 == 0:                       # extremes: very strong and very weak curvatures
         R[1:] = np.where(rng.random(rows - 1) < 0.3, R[1:] * 1e4, R[1:])

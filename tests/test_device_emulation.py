@@ -102,8 +102,19 @@ def _random_system(rng, rows, aspheric):
     for i in range(1, rows):
         glass = not glass if rng.random() < 0.7 else glass
         n[i] = rng.uniform(1.45, 1.9) if glass else 1.0
-    K = np.zeros(rows); coef = np.zeros((rows, 7))
-    if aspheric:
+    K = np.zeros(rows); coef = np.zeros((rows, 11 if aspheric == "even" else 7))
+    if aspheric == "even":
+        # the usual aspheric lens: even polynomial terms (4th .. 10th order, sometimes a 2nd-order term) on curved rows, a conic
+        # constant only where there is a polynomial -> the even-asphere kernel build (ARMS_EVEN), both of its forms
+        for i in range(1, rows):
+            if math.isfinite(R[i]) and rng.random() < 0.4:
+                K[i] = rng.uniform(-1.5, 0.5) if rng.random() < 0.7 else 0.0
+                coef[i, 4] = rng.uniform(-2e-7, 2e-7); coef[i, 6] = rng.uniform(-5e-10, 5e-10)
+                if rng.random() < 0.5:
+                    coef[i, 8] = rng.uniform(-1e-12, 1e-12); coef[i, 10] = rng.uniform(-2e-15, 2e-15)
+                if rng.random() < 0.3:
+                    coef[i, 2] = rng.uniform(-2e-4, 2e-4)
+    elif aspheric:
         for i in range(1, rows):
             if math.isfinite(R[i]) and rng.random() < 0.4:
                 K[i] = rng.uniform(-1.5, 0.5)
@@ -122,7 +133,7 @@ def test_fast_policy_is_status_exact_by_construction(oracle_engine, wide):
     ntot = nodd = nill = 0
     for case in range(40):
         rows = int(rng.integers(3, 15))
-        aspheric = case % 3 == 0
+        aspheric = (True, "even", False)[case % 3]
         R, t, n, K, coef = _random_system(rng, rows, aspheric)
         if wide:
             fin = np.isfinite(R); R[fin] = np.sign(R[fin]) * rng.uniform(6.5, 30.0, int(fin.sum()))
