@@ -10,12 +10,12 @@ done
 python3 - <<'PY'
 import csv, glob, collections
 for mode in ("history","summary"):
-    f=glob.glob(f"/root/repo/gpurun_out/clock/{mode}/**/*counter_collection.csv", recursive=True)[0]
     acc=collections.defaultdict(list); dur=[]
-    for r in csv.DictReader(open(f)):
-        if "k_trace<double, 1" not in r["Kernel_Name"]: continue
-        acc[r["Counter_Name"]].append(float(r["Counter_Value"]))
-        if r["Counter_Name"]=="GRBM_GUI_ACTIVE": dur.append((int(r["End_Timestamp"])-int(r["Start_Timestamp"]))*1e-9)
+    for f in glob.glob(f"/root/repo/gpurun_out/clock/{mode}/**/*counter_collection.csv", recursive=True):   # (bench.py's helper child writes one too)
+        for r in csv.DictReader(open(f)):
+            if "k_trace<double, 1" not in r["Kernel_Name"]: continue
+            acc[r["Counter_Name"]].append(float(r["Counter_Value"]))
+            if r["Counter_Name"]=="GRBM_GUI_ACTIVE": dur.append((int(r["End_Timestamp"])-int(r["Start_Timestamp"]))*1e-9)
     # drop the other-policy launches (they are a different kernel name) and warmups: use medians
     med=lambda v: sorted(v)[len(v)//2]
     t=med(dur); g=med(acc["GRBM_GUI_ACTIVE"])
