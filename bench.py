@@ -430,7 +430,7 @@ def bench_single(args, torch, rank, world, local_rank, emit=True):
                 c3 = json.load(open(sq3))
                 c3 = c3[sorted(c3)[-1]]                                   # the newest build of the pass
                 extra["config3_statistics_only"]["valu_roofline"] = {
-                    "valu_instructions_per_intersection": c3["valu_per_wave"] / (128.0 * S3),
+                    "instructions_per_intersection": c3["valu_per_wave"] * 64.0 / (128.0 * S3),   # lane-instructions, as in config2_summary
                     "issue_slot_utilisation": c3["valu_issue_utilisation"], "effective_clock_GHz": c3["clock_GHz"],
                     "note": "SQ_ACTIVE_INST_VALU over SQ_BUSY_CU_CYCLES; clock = GRBM_GUI_ACTIVE / 8 XCDs / kernel time",
                     "source": f"profiles/{os.path.basename(sq3)} (static; scripts/clock_config3.sh)"}
@@ -455,6 +455,44 @@ def bench_single(args, torch, rank, world, local_rank, emit=True):
             "rms_mean": float(np.nanmean(r5["rms"])), "count_mean": float(r5["count"].mean()),
             "bound": "FP32 VALU; wall time of the whole call incl. the H2D of the prescriptions and the D2H of the results"}
 
+        # BASELINE config 4 on this one GPU: the zoom sweep's summary trace into the packed hit slab (what each rank of the
+        # N > 1 exchange leg runs on its slab; nothing to gather at N = 1)
+        mats4 = np.array([workloads.double_gauss(line, -1.5 + 3.0 * z / max(1, args.zoom - 1))
+                          for z in range(args.zoom) for line in (0, 1, 2, 1, 2)])
+        f4 = (0.0, 0.5, 0.7, 0.85, 1.0)
+        plan = batch.ImageHitsPlan(mats4, workloads.DG_A, workloads.DG_H, f4, args.pupil4, engine=eng, dtype=np.float64)
+        h4 = plan.new_hits()
+        plan.trace(h4); eng.ctx.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(5):
+            plan.trace(h4)
+        eng.ctx.synchronize()
+        t4 = (time.perf_counter() - t0) / 5
+        rays4 = mats4.shape[0] * len(f4) * args.pupil4 * args.pupil4
+        extra["config4_single_gpu"] = {
+            "workload": f"BASELINE config 4 on one GPU: {args.zoom} zoom positions x 5 index columns x 5 fields x {args.pupil4}^2 pupil, "
+                        "Float64, summary trace into the packed [2][n] image-plane hit slab (16 B per ray)",
+            "rays": rays4, "intersections": rays4 * S, "ms_per_sweep": t4 * 1e3, "value": rays4 * S / t4, "bound": "FP64 VALU",
+            "finite_fraction": float(torch.isfinite(h4[0]).float().mean().item())}
+        del h4, plan
+        torch.cuda.empty_cache()
+        # BASELINE config 1: the reference's own call, full_trace(solve(Cooke triplet), H, 64) (test/runtests.jl:19-35), ONE C
+        # call with the error vectors back in host memory; wall time seen from Python (ctypes marshalling included — the plain-C
+        # caller of examples/cooke_full_trace.c is ~25 us lower: profiles/rNN_config1_c_abi_wall.log)
+        c1 = {}
+        for H in (0.0, 1.0):
+            fn = lambda: batch.full_trace_systems(workloads.COOKE[None], workloads.COOKE_A, workloads.COOKE_H, (H,), 64, engine=eng)
+            for _ in range(5):
+                r1 = fn()
+            ts = []
+            for _ in range(100):
+                t0 = time.perf_counter(); r1 = fn(); ts.append(time.perf_counter() - t0)
+            c1[f"H={H:g}"] = {"wall_us_median": float(np.median(ts)) * 1e6, "wall_us_min": float(np.min(ts)) * 1e6,
+                              "rays_kept": int(r1[1][0]["count"]), "rms": float(r1[1][0]["rms"])}
+        extra["config1_reference_call"] = {
+            "workload": "BASELINE config 1: Cooke triplet (test/runtests.jl:19-35), full_trace(system, H, 64): first-order solve, "
+                        "aiming, 64 x 32 half-pupil trace, stop filter + compaction + mirror, RMS — ort_full_trace_batch_f64, host "
+                        "arrays in, RealRayError vectors out", "rays_traced": 2048, "calls": c1, "bound": "latency (3 dependent launches)"}
         return extra
 
     extra = {}
@@ -525,6 +563,8 @@ def bench_single(args, torch, rank, world, local_rank, emit=True):
     if world > 1:
         res["ms_per_step_per_rank"] = per_rank
         res["nranks_seen"] = dist.get_world_size()
+        # what ONE rank makes of this same workload in this same run (its own K steps): value / that = the scaling over N
+        res["single_rank_same_workload_value"] = inter / (per_rank[0] * 1e-3)
         res["roofline"]["note"] = "per GPU: rank 0's kernel, hipEvents on its launch stream"
         res["backend"] = backend
     if not args.no_cpu_baseline and world == 1:

@@ -40,6 +40,14 @@ DG_H = 24.0
 DG_FIELDS = (0.0, 0.7, 1.0)      # the field values the reference's tests use (test/runtests.jl:367-369)
 
 
+# BASELINE config 1: the reference's own test prescription (Cooke triplet, test/runtests.jl:19-29: [R t n]; clear
+# semi-diameters :31-33; image height :35) — data, as the reference's tests hold it
+COOKE = np.array([[INF, 0.0, 1.0], [37.40, 5.90, 1.61272], [-341.48, 12.93, 1.0], [-42.65, 2.50, 1.64769],
+                  [36.40, 2.00, 1.0], [INF, 9.85, 1.0], [204.52, 5.90, 1.61272], [-37.05, 0.0, 1.0]])
+COOKE_A = np.array([14.7, 14.7, 10.8, 10.8, 10.3, 11.6, 11.6])
+COOKE_H = 21.248
+
+
 def double_gauss(line: int = 0, gap_shift: float = 0.0) -> np.ndarray:
     """rows x 3 surface matrix [R t n]; line 0/1/2 = d/F/C; gap_shift moves the two air gaps
     around the stop in opposite directions (the "zoom position" of BASELINE config 4)."""

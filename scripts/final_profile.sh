@@ -21,3 +21,13 @@ for route in place lookback; do
 done
 timeout -k 10 300 rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_BUSY_CU_CYCLES SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY --kernel-trace --output-format csv -d $OUT/sq_both -- python3 /root/repo/bench.py $Q --policy fast > $OUT/sq_both.log 2>&1 || exit 1
 ORT_ROUND=${ORT_ROUND:-r03} python3 /root/repo/scripts/collect_final.py
+# the rest of the round's judged artefacts, same box: config 3 / config 1 kernel statistics, the plain-C caller's wall time, the
+# counter + clock pass of the config-3 trace kernel, the 2-rank rehearsal of `bench.py --gpus 2` (gloo; both ranks on this GPU)
+T=${ORT_ROUND:-r03}
+cd /root/repo
+bash scripts/config3_kernels.sh ${T}_c3k > /dev/null 2>&1; cp gpurun_out/${T}_c3k.log profiles/${T}_config3_kernels.log 2>/dev/null
+bash scripts/config1_kernels.sh > gpurun_out/${T}_c1k.log 2>&1; cp gpurun_out/${T}_c1k.log profiles/${T}_config1_kernels.log
+[ -x build/cooke_full_trace ] && (./build/cooke_full_trace --time 0.0; ./build/cooke_full_trace --time 1.0) > gpurun_out/${T}_c1_cabi.log 2>&1
+bash scripts/clock_config3.sh ${T}_clk > gpurun_out/${T}_clk.log 2>&1
+cd /root/repo
+ORT_BENCH_BACKEND=gloo timeout -k 10 600 python bench.py --gpus 2 --steps 5 --warmup 2 > gpurun_out/${T}_n2_gloo.json 2> gpurun_out/${T}_n2_gloo.err || echo "n2 rehearsal rc=$?"
