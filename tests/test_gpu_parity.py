@@ -1179,6 +1179,16 @@ def test_full_trace_layout_batch_aspheric(hip_engine, oracle_engine):
                 assert len(mine ^ theirs) <= 24 and len(mine & theirs) >= 0.98 * min(len(mine), len(theirs)), (i, H)
             half = r["count"] // 2
             assert np.array_equal(r["ex"][half:], -r["ex"][:half])
+    # the same call under the FAST policy (these rows take the even-asphere kernel build, one ray per lane on this size):
+    # survivor counts identical, error vectors and RMS within 1e-10 of the reference-sequence policy's
+    fast = ort.HipEngine(0, fast_math=True)
+    fo_f, res_f = batch.full_trace_systems(mats, cm.DG_A, cm.DG_H, fields=fields, k_rays=k, engine=fast, coef=coef)
+    assert np.array_equal(fo_f["stop"], fo["stop"]) and np.array_equal(fo_f["f"], fo["f"])
+    for r, q in zip(res, res_f):
+        assert q["count"] == r["count"]
+        for key_ in ("ex", "ey", "rho", "theta"):
+            assert cm.rel_err(q[key_], r[key_], 1.0).max() <= 1e-10, key_
+        assert abs(q["rms"] - r["rms"]) <= 1e-10 * r["rms"]
     # the aspheric terms matter: the same prescriptions without them give different spots
     _, plain = batch.full_trace_systems(mats[:, :, :3], cm.DG_A, cm.DG_H, fields=fields, k_rays=k, engine=hip_engine)
     assert max(abs(p["rms"] - r["rms"]) / r["rms"] for p, r in zip(plain, res)) > 1e-2
