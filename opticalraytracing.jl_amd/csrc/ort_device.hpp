@@ -129,12 +129,9 @@ __device__ __forceinline__ double fast_rcp(double a)
     const double e = __builtin_fma(-a, r0, 1.0);
     return __builtin_fma(r0, e, r0);
 }
-__device__ __forceinline__ float fast_rcp(float a)
-{
-    const float r0 = __builtin_amdgcn_rcpf(a);
-    const float e = __builtin_fmaf(-a, r0, 1.0f);
-    return __builtin_fmaf(r0, e, r0);
-}
+// Float32: v_rcp_f32 / v_rsq_f32 / v_sqrt_f32 are 1-ulp instructions — the Float32 policy's own rounding level — and are
+// used as they come (a Newton step on top bought half an ulp for 2-4 more operations per seed: config 5, -x %)
+__device__ __forceinline__ float fast_rcp(float a) { return __builtin_amdgcn_rcpf(a); }
 __device__ __forceinline__ double fast_rsqrt(double a)
 {
     const double r0 = __builtin_amdgcn_rsq(a);
@@ -142,12 +139,7 @@ __device__ __forceinline__ double fast_rsqrt(double a)
     const double e = __builtin_fma(-t, r0, 1.0);
     return __builtin_fma(h, e, r0);
 }
-__device__ __forceinline__ float fast_rsqrt(float a)
-{
-    const float r0 = __builtin_amdgcn_rsqf(a);
-    const float e = __builtin_fmaf(-a * r0, r0, 1.0f);
-    return __builtin_fmaf(r0, 0.5f * e, r0);
-}
+__device__ __forceinline__ float fast_rsqrt(float a) { return __builtin_amdgcn_rsqf(a); }
 
 // MATH_FAST: atan(y, x) (theta of the full_trace output, src/PupilSampling.jl:133) without ocml's ~120 instructions per
 // ray — a fifth of everything the full_trace kernel issues per ray on a 12-surface system.  One division:
@@ -195,7 +187,7 @@ __device__ __forceinline__ double sqrt_core(double a)
     const double e = __builtin_fma(-h, g, 0.5);
     return __builtin_fma(g, e, g);
 }
-__device__ __forceinline__ float sqrt_core(float a) { return a * fast_rsqrt(a); }
+__device__ __forceinline__ float sqrt_core(float a) { return __builtin_amdgcn_sqrtf(a); }   // NaN for a < 0 (a miss, :9), 0 for 0
 // (a = 0 gives 0 * inf = NaN, a < 0 NaN: every radicand of the fast arms that can reach zero is a BRANCH quantity of the
 // reference — sag discriminant, refraction discriminant — whose neighbourhood raises `odd`, so the value is never used there)
 
@@ -669,6 +661,11 @@ __device__ __forceinline__ void surface_step_fast_conic(Ray<T>& r, const SurfRec
 // << 1e-10 x 1 mm (measured <= 2e-13 relative on the Tessar's R = -275.7 row).
 // s.K holds t + R for these rows.
 constexpr double kCentreFormMaxR = 1.0e3;
+// Float32: eps is 2^29 times larger, so the form is kept to |R| <= 200 mm, where it costs nothing measurable — image-plane
+// hits of BASELINE config 5's systems against the Float64 trace: rms 8.2e-6 mm (7.7e-6 in the vertex form, 7.2e-6 for the
+// Float32 reference sequence: the rounding of the inputs dominates); 1.5e-5 mm with the Float64 limit
+// (profiles/r03_ab_config5_f32_centre_form.log; -4.5 % on ort_spot_batch_f32)
+constexpr double kCentreFormMaxR32 = 200.0;
 
 template <typename T>
 __device__ __forceinline__ void fast_sphere_c_hit(Ray<T>& r, const SurfRec<T>& s, T& sq, T& disc, T& Qz)
@@ -734,7 +731,7 @@ __host__ __device__ inline int make_rec(SurfRec<T>& r, T t, T Rv, T n1, T n2, T 
     r.zlim = r.finite ? absR * (T(1) - (T)Near<T>::root) : T(0);
     r.ncoef = nc; r.spare = 0;
     int kind = nc > 0 ? KIND_POLY : (!r.finite ? KIND_FLAT : (Kv != T(0) ? KIND_CONIC : KIND_SPHERE));
-    if (kind == KIND_SPHERE && (double)absR <= kCentreFormMaxR && sizeof(T) == 8) {
+    if (kind == KIND_SPHERE && (double)absR <= (sizeof(T) == 8 ? kCentreFormMaxR : kCentreFormMaxR32)) {
         kind = KIND_SPHERE_C;                  // MATH_FAST centre form; K (== 0 here) carries t + R
         r.K = r.t + Rv;
     }
@@ -775,7 +772,7 @@ __host__ __device__ inline int make_poly_rec(T* rec, const double* c, int ncoef,
 // highest row).  Every arm that shares the surface loop costs the others register copies at the loop's merge points
 // (the allocator gives the loop-carried ray state different homes in different arms), so the loop of a plain
 // spherical system holds the centre-form sphere and flat arms and NOTHING else:
-//   ARMS_BASIC    centre-form spheres (Float32: general-form spheres) + flat rows
+//   ARMS_BASIC    centre-form spheres (Float32: + general-form spheres) + flat rows
 //   ARMS_GENERAL  + general-form spheres (Float64 rows with |R| > kCentreFormMaxR) and conics
 //   ARMS_EVEN     ARMS_BASIC + even aspheres on a curved base (polynomial rows whose odd coefficients are all zero, finite
 //                 R: p(y) = E(y^2) of <= 4 / <= 6 terms), as independent arms — the usual aspheric lens; without the
@@ -824,7 +821,7 @@ __device__ __forceinline__ void surface_step_n(Ray<T> (&r)[N], const SurfRec<T>&
         if (kind == KIND_SPHERE_C && tir)  { ORT_ALL_RAYS((surface_step_fast_sphere_c<T, true>(r[q], s, odd))) }
         if (kind == KIND_FLAT && !refr)    { ORT_ALL_RAYS((surface_step_fast_conic<T, KIND_FLAT, false, false>(r[q], s, odd))) }
         if (kind == KIND_FLAT && refr)     { ORT_ALL_RAYS((surface_step_fast_conic<T, KIND_FLAT, true, true>(r[q], s, odd))) }
-        // Float32 never uses the centre form (cancellation), so ITS hot sphere arms are the general ones
+        // Float32 keeps the centre form to |R| <= kCentreFormMaxR32 (cancellation), so the general sphere arms are hot arms too
         constexpr bool kF32 = sizeof(T) == 4;
         if (kF32 && kind == KIND_SPHERE && !tir) { ORT_ALL_RAYS((surface_step_fast_conic<T, KIND_SPHERE, true, false>(r[q], s, odd))) }
         if (kF32 && kind == KIND_SPHERE && tir)  { ORT_ALL_RAYS((surface_step_fast_conic<T, KIND_SPHERE, true, true>(r[q], s, odd))) }

@@ -14,6 +14,7 @@ static inline double __builtin_amdgcn_rcp(double a) { return (double)(float)(1.0
 static inline float __builtin_amdgcn_rcpf(float a) { return 1.0f / a; }
 static inline double __builtin_amdgcn_rsq(double a) { return (double)(float)(1.0 / std::sqrt(a)); }
 static inline float __builtin_amdgcn_rsqf(float a) { return 1.0f / std::sqrt(a); }
+static inline float __builtin_amdgcn_sqrtf(float a) { return std::sqrt(a); }
 static inline int __builtin_amdgcn_readfirstlane(int v) { return v; }
 static inline void __builtin_amdgcn_sched_barrier(int) {}
 static inline double __builtin_amdgcn_div_fixup(double q, double b, double a)
