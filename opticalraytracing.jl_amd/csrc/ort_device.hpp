@@ -130,7 +130,8 @@ __device__ __forceinline__ double fast_rcp(double a)
     return __builtin_fma(r0, e, r0);
 }
 // Float32: v_rcp_f32 / v_rsq_f32 / v_sqrt_f32 are 1-ulp instructions — the Float32 policy's own rounding level — and are
-// used as they come (a Newton step on top bought half an ulp for 2-4 more operations per seed: config 5, -x %)
+// used as they come (a Newton step on top bought half an ulp for 2-4 more operations per seed; without it ort_spot_batch_f32
+// on config 5 runs 3 % faster and its hits sit as close to the Float64 trace as before: rms 7.6e-6 mm)
 __device__ __forceinline__ float fast_rcp(float a) { return __builtin_amdgcn_rcpf(a); }
 __device__ __forceinline__ double fast_rsqrt(double a)
 {
@@ -664,7 +665,7 @@ constexpr double kCentreFormMaxR = 1.0e3;
 // Float32: eps is 2^29 times larger, so the form is kept to |R| <= 200 mm, where it costs nothing measurable — image-plane
 // hits of BASELINE config 5's systems against the Float64 trace: rms 8.2e-6 mm (7.7e-6 in the vertex form, 7.2e-6 for the
 // Float32 reference sequence: the rounding of the inputs dominates); 1.5e-5 mm with the Float64 limit
-// (profiles/r03_ab_config5_f32_centre_form.log; -4.5 % on ort_spot_batch_f32)
+// (profiles/r03_ab_config5_f32.log; -4.5 % on ort_spot_batch_f32)
 constexpr double kCentreFormMaxR32 = 200.0;
 
 template <typename T>
