@@ -76,7 +76,7 @@ enum { SL_IN0 = 0, SL_IN1, SL_IN2, SL_IN3, SL_OUT0, SL_OUT1, SL_OUT2, SL_OUT3, S
        SL_BUNDLES, SL_AXES, SL_WEX, SL_WEY, SL_WR, SL_WTH, SL_TCNT, SL_TSX, SL_TSY, SL_TRM,
        SL_TOFF, SL_TSQ, SL_AGG, SL_RES0, SL_RES1, SL_TAB0, SL_TAB1, SL_TAB2, SL_TAB3,
        SL_SB_FO, SL_SB_REC, SL_SB_MF, SL_SB_MR, SL_SB_TLF, SL_SB_TLR, SL_SB_AIN, SL_SB_AOUT, SL_SB_ENDS, SL_SB_FLAG,
-       SL_SB_FIELDS, SL_SB_A, SL_SB_HP, SL_SB_PACK, SL_SB_CEXT, SL_SB_CREV, SL_FTSTATE, SL_FTTICKET, SL_FTERR, SL_DOMAIN, SL_COUNT };
+       SL_SB_FIELDS, SL_SB_A, SL_SB_HP, SL_SB_PACK, SL_SB_CEXT, SL_SB_CREV, SL_FTSTATE, SL_FTTICKET, SL_FTERR, SL_DOMAIN, SL_RBSLOPES, SL_COUNT };
 
 }  // namespace
 
@@ -198,6 +198,11 @@ int launch_trace_modes(ort_ctx* ctx, const TraceParams<T>& p, int64_t blocks, bo
     return fail(ORT_EINVAL, "no output requested");
 }
 
+// finite-conjugate launch rule (ORT_RAYBASIS): the launch slopes per pupil row and column, one tiny launch ahead of the trace
+// (k_make_slope_axes); needs p.bundles, p.axes, p.ny, p.nx
+template <typename T>
+int make_rb_slopes(ort_ctx* ctx, TraceParams<T>& p, int nb);
+
 int check_ctx(ort_ctx* ctx)
 {
     if (!ctx) return fail(ORT_EINVAL, "null context");
@@ -238,6 +243,20 @@ template <typename T>
 int from_device(ort_ctx* ctx, T* host, const T* dev, size_t count)
 {
     HIP_TRY(hipMemcpyAsync(host, dev, count * sizeof(T), hipMemcpyDeviceToHost, ctx->stream));
+    return ORT_OK;
+}
+
+template <typename T>
+int make_rb_slopes(ort_ctx* ctx, TraceParams<T>& p, int nb)
+{
+    if (!p.raybasis) return ORT_OK;
+    const size_t cnt = (size_t)nb * (size_t)(p.ny + p.nx);
+    T* d = nullptr;
+    int rc = dev_out<T>(ctx, SL_RBSLOPES, cnt, &d); if (rc) return rc;
+    hipLaunchKernelGGL((k_make_slope_axes<T>), dim3((unsigned)((cnt + kBlock - 1) / kBlock)), dim3(kBlock), 0, ctx->stream,
+                       nb, p.ny, p.nx, p.bundles, p.axes, d);
+    HIP_TRY(hipGetLastError());
+    p.rb_slopes = d;
     return ORT_OK;
 }
 
@@ -317,12 +336,14 @@ int trace_grid_impl(ort_ctx* ctx, const ort_system* sys, int nb, const ort_bundl
 
     if (devp) {
         p.axes = axes;
+        rc = make_rb_slopes<T>(ctx, p, nb); if (rc) return rc;
         p.xv = out->xv; p.yv = out->yv; p.ld = out->ld;
         p.xf = out->xf; p.yf = out->yf; p.xs = out->xs; p.ys = out->ys; p.status = out->status;
         return launch_trace_modes<T, true>(ctx, p, blocks, hist, summ, flags);
     }
     // host buffers: stage through context scratch
     rc = to_device<T>(ctx, SL_AXES, axes, (size_t)axes_len, &p.axes); if (rc) return rc;
+    rc = make_rb_slopes<T>(ctx, p, nb); if (rc) return rc;
     T *dxv = nullptr, *dyv = nullptr;
     if (hist) {
         rc = dev_out<T>(ctx, SL_OUT0, (size_t)S * N, &dxv); if (rc) return rc;
@@ -578,6 +599,7 @@ int full_trace_impl(ort_ctx* ctx, const ort_system* sys, int nb, const ort_bundl
     p.raybasis = (flags & ORT_RAYBASIS) ? 1 : 0;
     if (devp) p.axes = axes;
     else { rc = to_device<T>(ctx, SL_AXES, axes, (size_t)axes_len, &p.axes); if (rc) return rc; }
+    rc = make_rb_slopes<T>(ctx, p, nb); if (rc) return rc;
     return run_full_trace<T>(ctx, p, nb, ex, ey, rho, theta, count, rms, flags);
 }
 

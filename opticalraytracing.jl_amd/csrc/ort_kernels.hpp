@@ -95,6 +95,7 @@ struct TraceParams {
     const T* ly; const T* lx; const T* lU; const T* lV;
     int64_t nrays; int isys; int slopes_given;
     int raybasis;
+    const T* rb_slopes;         // raybasis: [nb][ny + nx] launch slopes per pupil row | column (k_make_slope_axes), never null then
     const T* apert2;            // [nsys][S] squared clear semi-diameters (extension, off when null)
     // outputs
     T* xv; T* yv; int64_t ld;
@@ -318,9 +319,12 @@ void k_trace(TraceParams<T> p)   // both outputs, look-back epilogue, polynomial
                 y = p.axes[bd.yoff + iy];
                 x = p.axes[bd.xoff + ix];
                 stopi = bd.stop; hprime = bd.hprime; a_stop = bd.a_stop;
-                if (p.raybasis) {                        // PupilSampling.jl:124-127 (Q8)
-                    u = dev_tan((bd.ybar - y) / bd.z0);
-                    v = dev_tan(-x / bd.z0);
+                if (p.raybasis) {                        // PupilSampling.jl:124-127 (Q8): U = (ybar - y) / z0, V = -x / z0, then
+                    // tan(U), tan(V) (:38-39) — functions of the pupil row and of the pupil column alone: taken once per
+                    // row / column by k_make_slope_axes (ny + nx tangents per bundle instead of 2 ny nx), read here like y, x
+                    const T* sl = p.rb_slopes + (int64_t)b * (p.ny + p.nx);
+                    u = sl[iy];
+                    v = sl[p.ny + ix];
                 } else {                                 // shared field angles: direction cosines are bundle-uniform
                     ray[r].y = y; ray[r].x = x; ray[r].u = bd.u; ray[r].v = bd.v; ray[r].sprev = T(0);
                     ray[r].k0 = bd.k0; ray[r].k1 = bd.k1; ray[r].k2 = bd.k2;
@@ -1584,6 +1588,21 @@ __global__ __launch_bounds__(kBlock) void k_make_axes(int nb, int ny, int nx, co
     const int b = (int)(g / per), j = (int)(g - (int64_t)b * per);
     const double* e = ends + (int64_t)b * 4;
     axes[g] = (T)((j < ny) ? dd_range_elem(e[0], e[1], ny, j) : dd_range_elem(e[2], e[3], nx, j - ny));
+}
+
+// Launch slopes of the finite-conjugate rule (src/PupilSampling.jl:124-127 then :38-39): per bundle, tan((ybar - y) / z0) for its
+// ny pupil rows and tan(-x / z0) for its nx columns — the same expressions, operand for operand, the trace kernel used to
+// evaluate per ray.  out : [nb][ny + nx].
+template <typename T>
+__global__ __launch_bounds__(kBlock) void k_make_slope_axes(int nb, int ny, int nx, const DevBundle<T>* __restrict__ bundles,
+                                                            const T* __restrict__ axes, T* __restrict__ out)
+{
+    const int64_t g = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    const int per = ny + nx;
+    if (g >= (int64_t)nb * per) return;
+    const int b = (int)(g / per), j = (int)(g - (int64_t)b * per);
+    const DevBundle<T>& bd = bundles[b];
+    out[g] = (j < ny) ? dev_tan((bd.ybar - axes[bd.yoff + j]) / bd.z0) : dev_tan(-axes[bd.xoff + (j - ny)] / bd.z0);
 }
 
 // ------------------------------------------------------------------------------------

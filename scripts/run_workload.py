@@ -26,6 +26,8 @@ def main():
     ap.add_argument("--reps", type=int, default=5)
     ap.add_argument("--field", type=float, default=1.0)
     ap.add_argument("--lib", default=None, help="another build of libort_hip.so (A/B)")
+    ap.add_argument("--raybasis", action="store_true", help="config2 / config3: the finite-conjugate launch rule (per-ray angles, "
+                    "src/PupilSampling.jl:124-127) with the object 900 mm in front of the first surface")
     a = ap.parse_args()
     if a.lib:
         root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -36,7 +38,7 @@ def main():
     eng = ort.HipEngine(fast_math=(a.policy == "fast"))
     ort.set_default_engine(eng)
     lib, h = eng.ctx.lib, eng.ctx.h
-    res = {"workload": a.workload, "mode": a.mode, "policy": a.policy, "reps": a.reps}
+    res = {"workload": a.workload, "mode": a.mode, "policy": a.policy, "reps": a.reps, "raybasis": bool(a.raybasis)}
 
     def timed(fn):
         fn(); eng.ctx.synchronize()
@@ -71,9 +73,12 @@ def main():
     dev = torch.device("cuda", 0)
     nb, rpb = len(bundles), k * k
     N, S = nb * rpb, pres.rows - 1
+    if a.raybasis:
+        for bd in bundles:
+            bd["ybar"], bd["z0"] = -40.0 * bd["U"] / 0.3, -900.0
     sysd = eng.system(pres); barr = _capi.make_bundles(bundles)
     d_axes = torch.from_numpy(axes).to(dev)
-    fl = eng.base_flags | _capi.ORT_DEVICE_PTRS
+    fl = eng.base_flags | _capi.ORT_DEVICE_PTRS | (_capi.ORT_RAYBASIS if a.raybasis else 0)
     res.update(rays=N, intersections=N * S, pupil=k)
     if a.mode in ("summary", "history"):
         out = _capi.ort_grid_out_f64()
