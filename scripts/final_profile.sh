@@ -31,3 +31,5 @@ bash scripts/config1_kernels.sh > gpurun_out/${T}_c1k.log 2>&1; cp gpurun_out/${
 bash scripts/clock_config3.sh ${T}_clk > gpurun_out/${T}_clk.log 2>&1
 cd /root/repo
 ORT_BENCH_BACKEND=gloo timeout -k 10 600 python bench.py --gpus 2 --steps 5 --warmup 2 > gpurun_out/${T}_n2_gloo.json 2> gpurun_out/${T}_n2_gloo.err || echo "n2 rehearsal rc=$?"
+# the exchange leg alone with the native RCCL communicator of the C ABI (ort_comm_*), one rank: the code path the N > 1 line takes
+timeout -k 10 300 python bench.py --workload config4 --steps 5 --warmup 2 > gpurun_out/${T}_config4_world1_native_rccl.json 2> gpurun_out/${T}_config4_world1.err || echo "config4 world1 rc=$?"
