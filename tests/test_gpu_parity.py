@@ -237,6 +237,20 @@ def test_full_trace_multi_bundle_and_raybasis(hip_engine, oracle_engine):
         assert gb["count"] == ob["count"]
         assert cm.rel_err(gb["ex"], ob["ex"], 1.0).max() <= TOL
         assert abs(gb["rms"] - ob["rms"]) <= TOL * max(ob["rms"], 1e-3)
+    # the same rule through the grid entry point (history + summary), both policies; bundles that SHARE their axes but not
+    # their (ybar, z0): the launch slopes are taken per bundle (k_make_slope_axes), not per axis
+    shared = [dict(b) for b in bundles[:3]]
+    for j, b in enumerate(shared):
+        b["yaxis_off"], b["xaxis_off"] = shared[0]["yaxis_off"], shared[0]["xaxis_off"]
+        b["ybar"], b["z0"] = -40.0 + 15.0 * j, -900.0 - 100.0 * j
+    og = oracle_engine.grid(pres, shared, axes, 50, 50, raybasis=True)
+    for eng in (hip_engine, ort.HipEngine(0, fast_math=True)):
+        gg = eng.grid(pres, shared, axes, 50, 50, raybasis=True)
+        assert np.array_equal(gg["status"], og["status"])
+        for key in ("xv", "yv", "xf", "yf", "xs", "ys"):
+            assert np.array_equal(np.isnan(gg[key]), np.isnan(og[key])), key
+            assert cm.rel_err(gg[key], og[key], 1.0).max() <= TOL, key
+    assert not np.array_equal(og["xf"][:2500], og["xf"][2500:5000])        # the bundles do differ
 
 
 def test_meridional(hip_engine, oracle_engine):
