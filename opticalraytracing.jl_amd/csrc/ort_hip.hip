@@ -69,6 +69,11 @@ constexpr int kSmallGridTiles = 256;  // full_trace launches of at most this man
                                       // 8 waves per tile on 1024 SIMDs — beyond two waves per SIMD the two-ray form's lower instruction count wins
 constexpr size_t kZeroCopyBytes = (size_t)1 << 20;   // spot pipelines whose packed block [inputs | results] is at most this large run on the
                                                      // pinned host block directly (no copy dispatches)
+#ifndef ORT_WALK_TARGET
+#define ORT_WALK_TARGET 16384
+#endif
+constexpr int64_t kWalkTargetGroups = ORT_WALK_TARGET;   // statistics-only walk route: workgroups a launch is cut into when it has that many spans
+                                               // (~8 per resident slot of the chip); fewer spans: one workgroup per span
 constexpr int kSmallPairs = 256;    // spot pipelines of at most this many (system, field) pairs prepare in one launch (k_small_prepare)
 constexpr size_t kPackedVectorBytes = 32u << 20;   // host callers: error vectors up to this size come back in ONE copy
 
@@ -445,10 +450,12 @@ int run_full_trace(ort_ctx* ctx, TraceParams<T>& p, int nb, T* ex, T* ey, T* rho
     const bool small_f64 = sizeof(T) == 8 && ((p.tiles_per_bundle <= kSmallTiles && tiles <= kSmallGridTiles && !(flags & ORT_NO_SMALL_PATH)) ||
                                               (ORT_POLY_RPT1 && p.arms >= ARMS_EVEN));
     int rc;
-    rc = dev_out<int32_t>(ctx, SL_TCNT, (size_t)tiles, &p.tile_cnt); if (rc) return rc;
-    rc = dev_out<double>(ctx, SL_TSX, (size_t)tiles, &p.tile_sx); if (rc) return rc;
-    rc = dev_out<double>(ctx, SL_TSY, (size_t)tiles, &p.tile_sy); if (rc) return rc;
-    rc = dev_out<double>(ctx, SL_TRM, (size_t)tiles, &p.tile_rmax); if (rc) return rc;
+    // per-tile aggregates — or, on the statistics-only walk route, four partials per span of kWalkTiles tiles
+    const size_t npart = std::max<size_t>((size_t)tiles, (size_t)nb * (size_t)((p.tiles_per_bundle + kWalkTiles - 1) / kWalkTiles) * (kBlock / 64));
+    rc = dev_out<int32_t>(ctx, SL_TCNT, npart, &p.tile_cnt); if (rc) return rc;
+    rc = dev_out<double>(ctx, SL_TSX, npart, &p.tile_sx); if (rc) return rc;
+    rc = dev_out<double>(ctx, SL_TSY, npart, &p.tile_sy); if (rc) return rc;
+    rc = dev_out<double>(ctx, SL_TRM, npart, &p.tile_rmax); if (rc) return rc;
     int64_t* dcount = count; double* drms = rms;
     if (!devp) {
         rc = dev_out<int64_t>(ctx, SL_RES0, (size_t)nb, &dcount); if (rc) return rc;
@@ -456,14 +463,30 @@ int run_full_trace(ort_ctx* ctx, TraceParams<T>& p, int nb, T* ex, T* ey, T* rho
     }
     if (stats_only) {
         // one pass: trace + stop filter + per-tile (n, mean, M2), merged per bundle — no ray-sized buffer at all
-        rc = dev_out<double>(ctx, SL_TOFF, (size_t)tiles, &p.tile_m2x); if (rc) return rc;
-        rc = dev_out<double>(ctx, SL_TSQ, (size_t)tiles, &p.tile_m2y); if (rc) return rc;
-        // bundles of a few tiles: a handful of waves, each alone on its SIMD — one ray per lane halves the time (k_trace)
-        if (small_f64) rc = launch_trace<T, true, false, false, FT_STATS, sizeof(T) == 8 ? 1 : kRPT>(ctx, p, tiles, flags);
-        else rc = launch_trace<T, true, false, false, FT_STATS>(ctx, p, tiles, flags);
+        rc = dev_out<double>(ctx, SL_TOFF, npart, &p.tile_m2x); if (rc) return rc;
+        rc = dev_out<double>(ctx, SL_TSQ, npart, &p.tile_m2y); if (rc) return rc;
+        // Which kernel is a function of the BUNDLE's shape and of T alone, so a bundle's statistics never depend on what else is
+        // in the launch: Float64 bundles of a few tiles (the reference's own call) take the per-tile epilogue, whose one-ray-per-
+        // lane form (a handful of waves, each alone on its SIMD: half the instruction stream) is bit-identical to the general
+        // one; everything else walks spans of kWalkTiles tiles per workgroup and reduces once per span (k_trace, FT_WALK)
+        int parts = p.tiles_per_bundle;                             // (n, mean, M2) partials per bundle
+        if (sizeof(T) == 8 && p.tiles_per_bundle <= kSmallTiles) {
+            if (small_f64) rc = launch_trace<T, true, false, false, FT_STATS, sizeof(T) == 8 ? 1 : kRPT>(ctx, p, tiles, flags);
+            else rc = launch_trace<T, true, false, false, FT_STATS>(ctx, p, tiles, flags);
+        } else {
+            // spans of kWalkTiles tiles, four partials (one per wave) each; a workgroup walks walk_group consecutive spans of
+            // its bundle: as many as leave the launch ~8 workgroups per resident slot (the partials, and so the results, do not
+            // depend on it)
+            p.walk_spans = (p.tiles_per_bundle + kWalkTiles - 1) / kWalkTiles;
+            parts = p.walk_spans * (kBlock / 64);
+            const int64_t spans = (int64_t)nb * p.walk_spans;
+            p.walk_group = (int)std::min<int64_t>(p.walk_spans, std::max<int64_t>(1, spans / kWalkTargetGroups));
+            const int groups = (p.walk_spans + p.walk_group - 1) / p.walk_group;
+            rc = launch_trace<T, true, false, false, FT_WALK>(ctx, p, (int64_t)nb * groups, flags);
+        }
         if (rc) return rc;
         hipLaunchKernelGGL(k_ft_stats_reduce, dim3((unsigned)nb), dim3(kBlock), 0, ctx->stream,
-                           p.tile_cnt, p.tile_sx, p.tile_sy, p.tile_m2x, p.tile_m2y, p.tile_rmax, p.tiles_per_bundle, dcount, drms);
+                           p.tile_cnt, p.tile_sx, p.tile_sy, p.tile_m2x, p.tile_m2y, p.tile_rmax, parts, dcount, drms);
         HIP_TRY(hipGetLastError());
         if (!devp) {
             rc = from_device<int64_t>(ctx, count, dcount, (size_t)nb); if (rc) return rc;
@@ -893,6 +916,19 @@ extern "C" int ort_debug_phase_clocks(ort_ctx* ctx, unsigned long long* out32)
     int rc = check_ctx(ctx); if (rc) return rc;
     HIP_TRY(hipStreamSynchronize(ctx->stream));
     HIP_TRY(hipMemcpyFromSymbol(out32, HIP_SYMBOL(ort::g_phase), 32 * sizeof(unsigned long long)));
+    return ORT_OK;
+}
+#endif
+
+#ifdef ORT_COUNT_RETRACE
+// measurement build only: {tile-waves traced by MATH_FAST kernels, tile-waves that traced again with the reference sequence} since
+// the last reset (scripts/run_workload.py --retrace)
+extern "C" int ort_debug_retrace_counts(ort_ctx* ctx, unsigned long long* out2, int reset)
+{
+    int rc = check_ctx(ctx); if (rc) return rc;
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    HIP_TRY(hipMemcpyFromSymbol(out2, HIP_SYMBOL(ort::g_retrace), 2 * sizeof(unsigned long long)));
+    if (reset) { const unsigned long long z[2] = {0, 0}; HIP_TRY(hipMemcpyToSymbol(HIP_SYMBOL(ort::g_retrace), z, sizeof z)); }
     return ORT_OK;
 }
 #endif

@@ -29,6 +29,9 @@ __device__ unsigned long long g_phase[32];
 #else
 #define ORT_PHASE(i) do { } while (0)
 #endif
+#ifdef ORT_COUNT_RETRACE             // measurement build only (scripts/run_workload.py --retrace): [0] = tile-waves traced by a
+__device__ unsigned long long g_retrace[2];   // MATH_FAST kernel, [1] = those that traced again with the reference sequence
+#endif
 
 
 // Tunables (compile-time; the defaults are the measured best).
@@ -52,6 +55,9 @@ __device__ unsigned long long g_phase[32];
 #endif
 #ifndef ORT_WAVES_NOHIST
 #define ORT_WAVES_NOHIST ORT_MIN_WAVES   // the same for the kernels without history stores (A/B: 6 = 80 VGPRs spills)
+#endif
+#ifndef ORT_WAVES_F32
+#define ORT_WAVES_F32 ORT_WAVES_NOHIST   // the same for the Float32 kernels without history stores
 #endif
 #ifndef ORT_BLOCK
 #define ORT_BLOCK 256          // threads per workgroup (A/B builds: 128 halves the tile and the end-of-launch tail)
@@ -112,6 +118,8 @@ struct TraceParams {
     int* ft_err;                        // look-back fault word: bit 0 = a wait hit its poll cap, bit 1 = a ticket outside the grid
     int32_t* tile_cnt; double* tile_sx; double* tile_sy; double* tile_rmax;
     double* tile_m2x; double* tile_m2y;     // FT_STATS: sums of squared deviations about the tile means
+    int walk_spans;                         // FT_WALK: spans (of kWalkTiles consecutive tiles) per bundle
+    int walk_group;                         //          consecutive spans of one bundle a workgroup walks (launch shape only: no result depends on it)
 };
 
 // Two adjacent rays of one lane: one 2*sizeof(T) streaming store when the address allows.
@@ -175,6 +183,14 @@ __device__ __forceinline__ void stream_out(T* __restrict__ dst, const T* __restr
     if (j < c) __builtin_nontemporal_store(f(lds[j]), dst + j);
 }
 
+// lane `lane` (wave-uniform) of a double, as a SCALAR value
+__device__ __forceinline__ double readlane_f64(double v, int lane)
+{
+    const unsigned long long u = (unsigned long long)__double_as_longlong(v);
+    const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(u & 0xffffffffull), lane), hi = (unsigned)__builtin_amdgcn_readlane((int)(u >> 32), lane);
+    return __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
+}
+
 __device__ __forceinline__ double dev_tan(double a) { return ::tan(a); }
 __device__ __forceinline__ float dev_tan(float a) { return ::tanf(a); }
 __device__ __forceinline__ double dev_hypot(double a, double b) { return ::hypot(a, b); }
@@ -194,8 +210,21 @@ __device__ __forceinline__ float dev_atan2(float a, float b) { return ::atan2f(a
 //                bundle's earlier tiles (tiles taken in ticket order); k_ft_mirror adds the second half — least
 //                HBM traffic (84 vs 103 B/ray measured), but every tile waits for its predecessors' counts and the kernel holds
 //                4 waves per SIMD instead of 5 (ORT_FT_LOOKBACK; 5 % slower);
-//   FT_STATS     per-tile (count, mean, M2, max r) only — nothing ray-sized is written: the statistics-only route.
-enum { FT_NONE = 0, FT_FULL = 1, FT_STATS = 2, FT_LOOKBACK = 3 };
+//   FT_STATS     per-tile (count, mean, M2, max r) only — nothing ray-sized is written: the statistics-only route of
+//                bundles of a few tiles (the reference's own call), bit-identical between RPT = 1 and RPT = 2;
+//   FT_WALK      the statistics-only route of everything else: a workgroup WALKS consecutive tiles of its bundle with the
+//                table staged once and no barrier after that; every lane carries (n, sum d, sum d^2) of its survivors about
+//                the first survivor its wave met, and every SPAN of kWalkTiles tiles each wave folds its lanes (one shuffle
+//                tree) and writes ONE partial (n, mean, M2) — four per span, merged by k_ft_stats_reduce.  What a partial
+//                holds is fixed by kWalkTiles alone, so a bundle's statistics do not depend on how many spans a workgroup
+//                walks (walk_group: chosen per launch to keep the chip full) nor on what else is in the launch.  Per
+//                workgroup — not per tile — is what the per-tile route paid: staging + three dependent round trips before
+//                the first ray moves, 1.28 M times on BASELINE config 5 (profiles/r04_ab_walk.log).
+enum { FT_NONE = 0, FT_FULL = 1, FT_STATS = 2, FT_LOOKBACK = 3, FT_WALK = 4 };
+#ifndef ORT_WALK_TILES
+#define ORT_WALK_TILES 8     // tiles per span of the FT_WALK route
+#endif
+constexpr int kWalkTiles = ORT_WALK_TILES;
 constexpr int kStatusVignetted = 1 << 17, kStatusVigShift = 20;
 // ------------------------------------------------------------------------------------
 // ARMS: the row classes this build carries (surface_step_n): the batch's highest row decides (ort_system::arms).
@@ -204,13 +233,15 @@ constexpr int kStatusVignetted = 1 << 17, kStatusVigShift = 20;
 // one wave's instruction stream, and RPT = 1 — the same 512-ray tile on 512 threads — halves it.  Same results bit for
 // bit (the tile sums are taken in the RPT = 2 order, tile_sum2 below).
 template <typename T, int MATH, int ARMS, bool GRID, bool HIST, bool SUMM, int FT, int RPT = kRPT>
-__global__ __launch_bounds__(kTile / RPT, ARMS >= ARMS_EVEN ? ORT_POLY_WAVES : ((HIST && SUMM) || FT == 3 /* FT_LOOKBACK */) ? ORT_MIN_WAVES - 1 : HIST ? ORT_MIN_WAVES : ORT_WAVES_NOHIST)
-void k_trace(TraceParams<T> p)   // both outputs, look-back epilogue, polynomial arms: 128 VGPRs (at 96 they park tens of values per row in scratch)
+__global__ __launch_bounds__(kTile / RPT, ARMS >= ARMS_EVEN ? ORT_POLY_WAVES : ((HIST && SUMM) || FT == 3 /* FT_LOOKBACK */ || (FT == 4 /* FT_WALK */ && sizeof(T) == 8)) ? ORT_MIN_WAVES - 1 : HIST ? ORT_MIN_WAVES : sizeof(T) == 4 ? ORT_WAVES_F32 : ORT_WAVES_NOHIST)
+void k_trace(TraceParams<T> p)   // both outputs, look-back epilogue, Float64 running sums, polynomial arms: 128 VGPRs (at 96 they park tens of values per row in scratch)
 {
     constexpr int NT = kTile / RPT;                              // threads per workgroup: one tile of kTile rays
     constexpr int kSumWaves = kBlock / 64;                       // waves of the RPT = 2 shape: the order the tile sums are taken in
     static_assert(RPT == 1 || RPT == 2, "one or two rays per lane");
     constexpr bool POLY = ARMS >= ARMS_EVEN;
+    constexpr bool WALK = FT == FT_WALK;
+    static_assert(!WALK || (GRID && !HIST && !SUMM && RPT == kRPT), "FT_WALK: grid source, no other output");
     __shared__ SurfRec<T> s_rec[kMaxRows];
     __shared__ __attribute__((aligned(16))) T s_poly[POLY ? kMaxRows * kPolyLds : 1];
     __shared__ int s_wcnt[NT / 64];
@@ -249,9 +280,20 @@ void k_trace(TraceParams<T> p)   // both outputs, look-back epilogue, polynomial
     int64_t gbase;       // global index of ray j0
     int64_t limit;       // rays in this bundle / list
     unsigned tile_base = 0;   // first ray of this workgroup's tile inside its bundle (wave-uniform)
+    int walk_n = 1;           // tiles this workgroup traces one after the other (FT_WALK: walk_group spans of its bundle)
+    int walk_tile = 0;        // FT_WALK: the tile being traced (index inside the bundle)
     if (GRID) {
-        b = bid / p.tiles_per_bundle;
-        const int tile = bid - b * p.tiles_per_bundle;
+        int tile;
+        if (WALK) {
+            const int groups = (p.walk_spans + p.walk_group - 1) / p.walk_group;      // workgroups per bundle
+            b = bid / groups;
+            tile = (bid - b * groups) * p.walk_group * kWalkTiles;
+            walk_n = min(p.walk_group * kWalkTiles, p.tiles_per_bundle - tile);
+            walk_tile = tile;
+        } else {
+            b = bid / p.tiles_per_bundle;
+            tile = bid - b * p.tiles_per_bundle;
+        }
         tile_base = (unsigned)tile * (unsigned)kTile;
         sysid = p.bundles[b].system;
         j0 = (int64_t)tile * kTile + (int64_t)tid * RPT;
@@ -286,371 +328,436 @@ void k_trace(TraceParams<T> p)   // both outputs, look-back epilogue, polynomial
         __syncthreads();
     }
 
-    ORT_PHASE(14);
-    Ray<T> ray[RPT];
-    bool live[RPT];
-    int32_t st[RPT];
-    T xs_[RPT], ys_[RPT];
-    int stopi = -1;
-    T hprime = T(0), a_stop = T(0);
-    // (a lambda: a wave whose rays leave the domain of the fast forms launches them a second time, see below)
-    auto launch_rays = [&](auto math) {
-        constexpr int M = decltype(math)::value;
+    // FT_WALK: this lane's survivors so far — their number and the sums of (ex - Kx), (ey - Ky) and of their squares, (Kx, Ky) =
+    // the FIRST survivor its wave meets (wave-uniform: scalar registers): every term is of the size of the spot, so nothing
+    // cancels whatever the centroid's offset
+    int wk_n = 0;
+    bool wk_have = false;
+    double wk_kx = 0.0, wk_ky = 0.0, wk_sx = 0.0, wk_sy = 0.0, wk_qx = 0.0, wk_qy = 0.0;
+    for (int wt = 0; wt < walk_n; ++wt) {
+        ORT_PHASE(14);
+        Ray<T> ray[RPT];
+        bool live[RPT];
+        int32_t st[RPT];
+        T xs_[RPT], ys_[RPT];
+        int stopi = -1;
+        T hprime = T(0), a_stop = T(0);
+        // (a lambda: a wave whose rays leave the domain of the fast forms launches them a second time, see below)
+        auto launch_rays = [&](auto math) {
+            constexpr int M = decltype(math)::value;
 #pragma unroll
-        for (int r = 0; r < RPT; ++r) {
-            const int64_t j = j0 + r;
-            live[r] = j < limit;
-            const int64_t jj = live[r] ? j : (limit - 1);   // clamp: dead lanes retrace a valid ray
-            T y, x, u, v;
-            if (GRID) {
-                const DevBundle<T>& bd = p.bundles[b];
-                // (iy, ix) of ray jj without a per-lane 64-bit division: the tile's first ray is
-                // divided once in scalar registers, lanes walk forward from there.
-                unsigned iy, ix;
-                if (live[r] && p.nx >= 64) {
-                    const unsigned iy0 = tile_base / (unsigned)p.nx;         // wave-uniform: scalar division
-                    ix = (tile_base - iy0 * (unsigned)p.nx) + (unsigned)(tid * RPT + r);
-                    iy = iy0;
-                    while (ix >= (unsigned)p.nx) { ix -= (unsigned)p.nx; ++iy; }
+            for (int r = 0; r < RPT; ++r) {
+                const int64_t j = j0 + r;
+                live[r] = j < limit;
+                const int64_t jj = live[r] ? j : (limit - 1);   // clamp: dead lanes retrace a valid ray
+                T y, x, u, v;
+                if (GRID) {
+                    const DevBundle<T>& bd = p.bundles[b];
+                    // (iy, ix) of ray jj without a per-lane 64-bit division: the tile's first ray is
+                    // divided once in scalar registers, lanes walk forward from there.
+                    unsigned iy, ix;
+                    if (live[r] && p.nx >= 64) {
+                        const unsigned iy0 = tile_base / (unsigned)p.nx;         // wave-uniform: scalar division
+                        ix = (tile_base - iy0 * (unsigned)p.nx) + (unsigned)(tid * RPT + r);
+                        iy = iy0;
+                        while (ix >= (unsigned)p.nx) { ix -= (unsigned)p.nx; ++iy; }
+                    } else {
+                        iy = (unsigned)((uint32_t)jj / (uint32_t)p.nx);
+                        ix = (unsigned)jj - iy * (unsigned)p.nx;
+                    }
+                    y = p.axes[bd.yoff + iy];
+                    x = p.axes[bd.xoff + ix];
+                    stopi = bd.stop; hprime = bd.hprime; a_stop = bd.a_stop;
+                    if (p.raybasis) {                        // PupilSampling.jl:124-127 (Q8): U = (ybar - y) / z0, V = -x / z0, then
+                        // tan(U), tan(V) (:38-39) — functions of the pupil row and of the pupil column alone: taken once per
+                        // row / column by k_make_slope_axes (ny + nx tangents per bundle instead of 2 ny nx), read here like y, x
+                        const T* sl = p.rb_slopes + (int64_t)b * (p.ny + p.nx);
+                        u = sl[iy];
+                        v = sl[p.ny + ix];
+                    } else {                                 // shared field angles: direction cosines are bundle-uniform
+                        ray[r].y = y; ray[r].x = x; ray[r].u = bd.u; ray[r].v = bd.v; ray[r].sprev = T(0);
+                        ray[r].k0 = bd.k0; ray[r].k1 = bd.k1; ray[r].k2 = bd.k2;
+                        st[r] = 1; xs_[r] = T(0); ys_[r] = T(0);
+                        continue;
+                    }
                 } else {
-                    iy = (unsigned)((uint32_t)jj / (uint32_t)p.nx);
-                    ix = (unsigned)jj - iy * (unsigned)p.nx;
+                    y = p.ly[jj]; x = p.lx[jj];
+                    u = p.lU[jj]; v = p.lV[jj];
+                    if (!p.slopes_given) { u = dev_tan(u); v = dev_tan(v); }   // :38-39
                 }
-                y = p.axes[bd.yoff + iy];
-                x = p.axes[bd.xoff + ix];
-                stopi = bd.stop; hprime = bd.hprime; a_stop = bd.a_stop;
-                if (p.raybasis) {                        // PupilSampling.jl:124-127 (Q8): U = (ybar - y) / z0, V = -x / z0, then
-                    // tan(U), tan(V) (:38-39) — functions of the pupil row and of the pupil column alone: taken once per
-                    // row / column by k_make_slope_axes (ny + nx tangents per bundle instead of 2 ny nx), read here like y, x
-                    const T* sl = p.rb_slopes + (int64_t)b * (p.ny + p.nx);
-                    u = sl[iy];
-                    v = sl[p.ny + ix];
-                } else {                                 // shared field angles: direction cosines are bundle-uniform
-                    ray[r].y = y; ray[r].x = x; ray[r].u = bd.u; ray[r].v = bd.v; ray[r].sprev = T(0);
-                    ray[r].k0 = bd.k0; ray[r].k1 = bd.k1; ray[r].k2 = bd.k2;
-                    st[r] = 1; xs_[r] = T(0); ys_[r] = T(0);
-                    continue;
-                }
-            } else {
-                y = p.ly[jj]; x = p.lx[jj];
-                u = p.lU[jj]; v = p.lV[jj];
-                if (!p.slopes_given) { u = dev_tan(u); v = dev_tan(v); }   // :38-39
-            }
-            ray_init<T, M>(ray[r], y, x, u, v);
-            st[r] = 1;
-            xs_[r] = T(0); ys_[r] = T(0);
-        }
-    };
-    launch_rays(std::integral_constant<int, MATH>{});
-    const bool two = (RPT > 1) && live[RPT - 1];
-    // History stores: one wave-uniform decision, taken once — every lane of the wave owns two live
-    // rays and both row bases keep 16-byte alignment on every surface (ld even) -> plain
-    // 16-byte stores off a scalar row base; otherwise the guarded per-lane path.
-    const int lane_off = tid * RPT;
-    const int64_t blockbase = gbase - lane_off;                  // wave-uniform
-    bool vec_all = false;
-    if (HIST && RPT == 2) {
-        const bool al = ((reinterpret_cast<uintptr_t>(p.xv + gbase) | reinterpret_cast<uintptr_t>(p.yv + gbase)) &
-                         (2 * sizeof(T) - 1)) == 0 && (p.ld & 1) == 0;
-        vec_all = __all(two && al);
-    }
-
-    const int stop_u = __builtin_amdgcn_readfirstlane(stopi);    // bundle-uniform: the stop capture is a scalar branch
-    // The surface loop in arithmetic policy M.  MATH_FAST returns whether a ray of this lane left the domain of
-    // the fast forms (`odd`, ort_device.hpp).
-    auto trace_surfaces = [&](auto math) -> bool {
-        constexpr int M = decltype(math)::value;
-        bool odd = false;
-        if (M == MATH_FAST) {                                    // Inf / NaN launch data: the reference just computes with
-#pragma unroll                                                   // them, and so does its own operation sequence (retrace)
-            for (int r = 0; r < RPT; ++r)
-                odd = odd || t_class(ray[r].x, kClassNonFinite) || t_class(ray[r].y, kClassNonFinite) ||
-                      t_class(ray[r].k0 + ray[r].k1, kClassNonFinite);
-        }
-        for (int i = 0; i < S; ++i) {
-            const SurfRec<T>& rec = s_rec[i];
-            const int cls = __builtin_amdgcn_readfirstlane(rec.cls);     // wave-uniform -> scalar branch
-            // the staged block is laid out for the kernel's own policy; the (cold) MATH_IEEE retrace of a MATH_FAST kernel
-            // reads its pc | dc block from the table itself
-            const T* cf = (M == MATH) ? (s_poly + i * kPolyLds) : (gpoly ? gpoly + i * kPolyRec : nullptr);
-            surface_step_n<T, M, RPT, ARMS>(ray, rec, cf, cls, i == S - 1, odd);
-            if (SUMM || FT) {
-                if (SUMM) {                                          // the full_trace epilogue reads the final NaN-ness only: no count
-#pragma unroll
-                    for (int r = 0; r < RPT; ++r) {
-                        // NaN is sticky (every later transfer propagates it), so the 1-based index of the first
-                        // NaN surface is 1 + the number of surfaces with ordered (x, y): one v_cmp_o + one add.
-                        st[r] += __builtin_isunordered(ray[r].x, ray[r].y) ? 0 : 1;
-                    }
-                }
-                if (i == stop_u) {
-                    const T a2 = a_stop * a_stop, alim = (T)Near<T>::thr * a2;
-#pragma unroll
-                    for (int r = 0; r < RPT; ++r) {
-                        xs_[r] = ray[r].x; ys_[r] = ray[r].y;
-                        // within kNear of the stop's edge the filter r > a_stop (:132) is decided by the reference sequence
-                        if (M == MATH_FAST) odd = odd || near_zero<T>(t_fma<T>(xs_[r], xs_[r], t_fma<T>(ys_[r], ys_[r], -a2)), alim);
-                    }
-                }
-                if (gap2) {                                          // scalar branch: one s_cbranch when off
-                    const T a2 = gap2[i];
-#pragma unroll
-                    for (int r = 0; r < RPT; ++r) {
-                        // bit 17: outside the clear aperture of some surface; bits 20..27 count the surfaces
-                        // passed before that -> 1-based index of the first vignetting surface = count + 1
-                        const T r2 = ray[r].x * ray[r].x + ray[r].y * ray[r].y;
-                        if (M == MATH_FAST) odd = odd || near_zero<T>(r2 - a2, (T)Near<T>::thr * a2);
-                        st[r] |= (r2 > a2) ? kStatusVignetted : 0;
-                        if (SUMM) st[r] += (st[r] & kStatusVignetted) ? 0 : (1 << kStatusVigShift);
-                    }
-                }
-            }
-            if (HIST) {
-                if (vec_all) {
-                    T* rx = p.xv + ((int64_t)i * p.ld + blockbase);  // scalar row base
-                    T* ry = p.yv + ((int64_t)i * p.ld + blockbase);
-                    store_vec2<T>(rx + lane_off, ray[0].x, ray[RPT - 1].x);
-                    store_vec2<T>(ry + lane_off, ray[0].y, ray[RPT - 1].y);
-                } else if (live[0]) {
-                    store_pair<T>(p.xv + (int64_t)i * p.ld, gbase, two, ray[0].x, ray[RPT - 1].x);
-                    store_pair<T>(p.yv + (int64_t)i * p.ld, gbase, two, ray[0].y, ray[RPT - 1].y);
-                }
-            }
-        }
-        return odd;
-    };
-    const bool odd_seen = trace_surfaces(std::integral_constant<int, MATH>{});
-    if (MATH == MATH_FAST && __builtin_expect(__any(odd_seen), 0)) {
-        // A ray of this wave went where the reference's formulas are no longer the geometry the fast forms compute
-        // (a far-cap hit, a direction refracted backward, a polynomial row outside its conic: possible only far
-        // outside any clear aperture).  What the reference does there is defined by its operation sequence, so the
-        // wave traces its rays again with exactly that — MATH_IEEE, bit-identical to the CPU reference; its history
-        // stores land on the same addresses, after the first pass's have completed.
-        __builtin_amdgcn_s_waitcnt(0);
-        launch_rays(std::integral_constant<int, MATH_IEEE>{});
-        trace_surfaces(std::integral_constant<int, MATH_IEEE>{});
-    }
-
-    ORT_PHASE(15);
-    // The stop filter r > a_stop (PupilSampling.jl:131-132).  The reference sequence takes hypot.  MATH_FAST decides by
-    // r^2 against a_stop^2 — the same outcome for every ray farther than kNear from the edge — and only the rays within
-    // kNear of it (their wave has retraced with the reference sequence, see the stop capture above) take the hypot.
-    auto outside_stop = [&](T xs, T ys, T& r2) -> bool {
-        if (MATH == MATH_IEEE) { r2 = T(0); return dev_hypot(xs, ys) > a_stop; }
-        const T a2 = a_stop < T(0) ? T(-1) : a_stop * a_stop;        // a negative radius passes nothing
-        r2 = t_fma<T>(xs, xs, ys * ys);
-        bool out = r2 > a2;
-        if (near_zero<T>(r2 - a2, (T)Near<T>::thr * a2)) out = dev_hypot(xs, ys) > a_stop;
-        return out;
-    };
-
-    if (SUMM) {
-        if (live[0]) {
-            if (p.xf) store_pair<T>(p.xf, gbase, two, ray[0].x, ray[RPT - 1].x);
-            if (p.yf) store_pair<T>(p.yf, gbase, two, ray[0].y, ray[RPT - 1].y);
-            if (p.xs) store_pair<T>(p.xs, gbase, two, xs_[0], xs_[RPT - 1]);
-            if (p.ys) store_pair<T>(p.ys, gbase, two, ys_[0], ys_[RPT - 1]);
-            if (p.status) {
-#pragma unroll
-                for (int r = 0; r < RPT; ++r) {
-                    if (!live[r]) continue;
-                    int32_t s = st[r];
-                    if (stopi >= 0) {
-                        T r2;
-                        if (outside_stop(xs_[r], ys_[r], r2)) s |= (1 << 16);
-                    }
-                    p.status[gbase + r] = s;
-                }
-            }
-        }
-    }
-
-    if (FT) {
-        // stop filter (PupilSampling.jl:129-137).  FT_FULL: the tile's survivors are compacted IN RAY ORDER (two
-        // 64-bit ballots + popcount prefix per wave, wave offsets through LDS) and streamed to the first half of
-        // the bundle's output slab; FT_STATS: per-tile moments only.
-        int cnt = 0; double sx = 0.0, sy = 0.0, rmax = -1.0;
-        T exv[RPT], eyv[RPT], rv[RPT], thv[RPT];
-        bool keep[RPT];
-#pragma unroll
-        for (int r = 0; r < RPT; ++r) {
-            const T xf = ray[r].x, yf = ray[r].y;
-            T r2;
-            const bool outside = outside_stop(xs_[r], ys_[r], r2);                        // :131-132
-            // r itself (rho, :136,142): the reference sequence keeps its hypot; MATH_FAST takes the root of r^2 (seeded from
-            // r^2 + tiny: an on-axis ray gives 0, not 0 * inf), and the statistics-only route needs no r at all
-            T ri = T(0);
-            if (MATH == MATH_IEEE) ri = dev_hypot(xs_[r], ys_[r]);
-            else if (kCompact) ri = r2 * fast_rsqrt(r2 + (sizeof(T) == 8 ? (T)1e-300 : (T)1e-36));
-            const bool drop = outside || t_isnan(xf) || t_isnan(yf) || !live[r] || (st[r] & kStatusVignetted);
-            keep[r] = !drop;
-            if (kCompact) thv[r] = MATH == MATH_FAST ? fast_atan2(ys_[r], xs_[r]) : dev_atan2(ys_[r], xs_[r]);   // :133
-            eyv[r] = yf - hprime;                                    // :134
-            exv[r] = xf;                                             // :135
-            rv[r] = drop ? T(-1) : ri;                               // :136, -1 marks a dropped ray
-            if (!drop) { ++cnt; sx += (double)exv[r]; sy += (double)eyv[r]; rmax = fmax(rmax, (double)ri); }
-        }
-        const int lane = tid & 63, wave = tid >> 6;
-        int rank0 = 0;
-        if (kCompact) {
-            const unsigned long long m0 = __ballot(keep[0]);
-            const unsigned long long m1 = (RPT > 1) ? __ballot(keep[RPT - 1]) : 0ull;
-            const unsigned long long lt = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
-            rank0 = __popcll(m0 & lt) + __popcll(m1 & lt);
-        }
-        // tile aggregates: fixed-shape tree -> bitwise reproducible.  The floating-point sums are taken in ONE order whatever
-        // RPT is — that of the two-rays-per-lane shape: a lane's two rays, a 64-lane shuffle tree over each group of 128
-        // rays (-> s_wsx / s_wsy[group]), the groups in sequence by whoever reads them.  With one ray per lane a group
-        // spans two waves: neighbouring lanes pair up, the pair sums meet in LDS, and the tree continues from its second level.
-        auto tile_sum2 = [&](double x, double y) {
-            if constexpr (RPT == 2) {
-                for (int off = 32; off > 0; off >>= 1) { x += __shfl_down(x, off); y += __shfl_down(y, off); }
-                if (lane == 0) { s_wsx[wave] = x; s_wsy[wave] = y; }
-            } else {
-                x += __shfl_xor(x, 1); y += __shfl_xor(y, 1);            // a + b on both lanes of the pair: the same bits
-                if (!(lane & 1)) { s_px[wave][lane >> 1] = x; s_py[wave][lane >> 1] = y; }
-                __syncthreads();
-                if (wave < kSumWaves) {
-                    double qx = 0.0, qy = 0.0;
-                    if (lane < 32) {                                     // the tree's first level: lanes l and l + 32 of the group
-                        qx = s_px[2 * wave][lane] + s_px[2 * wave + 1][lane];
-                        qy = s_py[2 * wave][lane] + s_py[2 * wave + 1][lane];
-                    }
-                    for (int off = 16; off > 0; off >>= 1) { qx += __shfl_down(qx, off); qy += __shfl_down(qy, off); }
-                    if (lane == 0) { s_wsx[wave] = qx; s_wsy[wave] = qy; }
-                }
+                ray_init<T, M>(ray[r], y, x, u, v);
+                st[r] = 1;
+                xs_[r] = T(0); ys_[r] = T(0);
             }
         };
-        for (int off = 32; off > 0; off >>= 1) {
-            cnt += __shfl_down(cnt, off);
-            rmax = fmax(rmax, __shfl_down(rmax, off));
+        launch_rays(std::integral_constant<int, MATH>{});
+        const bool two = (RPT > 1) && live[RPT - 1];
+        // History stores: one wave-uniform decision, taken once — every lane of the wave owns two live
+        // rays and both row bases keep 16-byte alignment on every surface (ld even) -> plain
+        // 16-byte stores off a scalar row base; otherwise the guarded per-lane path.
+        const int lane_off = tid * RPT;
+        const int64_t blockbase = gbase - lane_off;                  // wave-uniform
+        bool vec_all = false;
+        if (HIST && RPT == 2) {
+            const bool al = ((reinterpret_cast<uintptr_t>(p.xv + gbase) | reinterpret_cast<uintptr_t>(p.yv + gbase)) &
+                             (2 * sizeof(T) - 1)) == 0 && (p.ld & 1) == 0;
+            vec_all = __all(two && al);
         }
-        if (lane == 0) { s_wcnt[wave] = cnt; s_wmax[wave] = rmax; }
-        tile_sum2(sx, sy);
-        __syncthreads();
-        if (kCompact) {
-            __shared__ __attribute__((aligned(16))) T s_cx[kCompact ? kTile : 1], s_cy[kCompact ? kTile : 1], s_cr[kCompact ? kTile : 1], s_ct[kCompact ? kTile : 1];
-            __shared__ long long s_base;
-            int woff = 0, c = 0;
-            for (int w = 0; w < NT / 64; ++w) { woff += (w < wave) ? s_wcnt[w] : 0; c += s_wcnt[w]; }
-            int k = woff + rank0;
+
+        const int stop_u = __builtin_amdgcn_readfirstlane(stopi);    // bundle-uniform: the stop capture is a scalar branch
+        // The surface loop in arithmetic policy M.  MATH_FAST returns whether a ray of this lane left the domain of
+        // the fast forms (`odd`, ort_device.hpp).
+        auto trace_surfaces = [&](auto math) -> bool {
+            constexpr int M = decltype(math)::value;
+            bool odd = false;
+            if (M == MATH_FAST) {                                    // Inf / NaN launch data: the reference just computes with
+#pragma unroll                                                   // them, and so does its own operation sequence (retrace)
+                for (int r = 0; r < RPT; ++r)
+                    odd = odd || t_class(ray[r].x, kClassNonFinite) || t_class(ray[r].y, kClassNonFinite) ||
+                          t_class(ray[r].k0 + ray[r].k1, kClassNonFinite);
+            }
+            for (int i = 0; i < S; ++i) {
+                const SurfRec<T>& rec = s_rec[i];
+                const int cls = __builtin_amdgcn_readfirstlane(rec.cls);     // wave-uniform -> scalar branch
+                // the staged block is laid out for the kernel's own policy; the (cold) MATH_IEEE retrace of a MATH_FAST kernel
+                // reads its pc | dc block from the table itself
+                const T* cf = (M == MATH) ? (s_poly + i * kPolyLds) : (gpoly ? gpoly + i * kPolyRec : nullptr);
+                surface_step_n<T, M, RPT, ARMS>(ray, rec, cf, cls, i == S - 1, odd);
+                if (SUMM || FT) {
+                    if (SUMM) {                                          // the full_trace epilogue reads the final NaN-ness only: no count
 #pragma unroll
-            for (int r = 0; r < RPT; ++r)
-                if (keep[r]) { s_cx[k] = exv[r]; s_cy[k] = eyv[r]; s_cr[k] = rv[r]; s_ct[k] = thv[r]; ++k; }
-            const int tile = (int)(bid - (unsigned)b * (unsigned)p.tiles_per_bundle);
-            if (FT == FT_FULL) {
-                if (tid == 0) {
+                        for (int r = 0; r < RPT; ++r) {
+                            // NaN is sticky (every later transfer propagates it), so the 1-based index of the first
+                            // NaN surface is 1 + the number of surfaces with ordered (x, y): one v_cmp_o + one add.
+                            st[r] += __builtin_isunordered(ray[r].x, ray[r].y) ? 0 : 1;
+                        }
+                    }
+                    if (i == stop_u) {
+                        const T a2 = a_stop * a_stop, alim = (T)Near<T>::thr * a2;
+#pragma unroll
+                        for (int r = 0; r < RPT; ++r) {
+                            xs_[r] = ray[r].x; ys_[r] = ray[r].y;
+                            // within kNear of the stop's edge the filter r > a_stop (:132) is decided by the reference sequence
+                            if (M == MATH_FAST) odd = odd || near_zero<T>(t_fma<T>(xs_[r], xs_[r], t_fma<T>(ys_[r], ys_[r], -a2)), alim);
+                        }
+                    }
+                    if (gap2) {                                          // scalar branch: one s_cbranch when off
+                        const T a2 = gap2[i];
+#pragma unroll
+                        for (int r = 0; r < RPT; ++r) {
+                            // bit 17: outside the clear aperture of some surface; bits 20..27 count the surfaces
+                            // passed before that -> 1-based index of the first vignetting surface = count + 1
+                            const T r2 = ray[r].x * ray[r].x + ray[r].y * ray[r].y;
+                            if (M == MATH_FAST) odd = odd || near_zero<T>(r2 - a2, (T)Near<T>::thr * a2);
+                            st[r] |= (r2 > a2) ? kStatusVignetted : 0;
+                            if (SUMM) st[r] += (st[r] & kStatusVignetted) ? 0 : (1 << kStatusVigShift);
+                        }
+                    }
+                }
+                if (HIST) {
+                    if (vec_all) {
+                        T* rx = p.xv + ((int64_t)i * p.ld + blockbase);  // scalar row base
+                        T* ry = p.yv + ((int64_t)i * p.ld + blockbase);
+                        store_vec2<T>(rx + lane_off, ray[0].x, ray[RPT - 1].x);
+                        store_vec2<T>(ry + lane_off, ray[0].y, ray[RPT - 1].y);
+                    } else if (live[0]) {
+                        store_pair<T>(p.xv + (int64_t)i * p.ld, gbase, two, ray[0].x, ray[RPT - 1].x);
+                        store_pair<T>(p.yv + (int64_t)i * p.ld, gbase, two, ray[0].y, ray[RPT - 1].y);
+                    }
+                }
+            }
+            return odd;
+        };
+        const bool odd_seen = trace_surfaces(std::integral_constant<int, MATH>{});
+#ifdef ORT_COUNT_RETRACE
+        if (MATH == MATH_FAST && (tid & 63) == 0) { atomicAdd(&g_retrace[0], 1ull); if (__any(odd_seen)) atomicAdd(&g_retrace[1], 1ull); }
+#endif
+        if (MATH == MATH_FAST && __builtin_expect(__any(odd_seen), 0)) {
+            // A ray of this wave went where the reference's formulas are no longer the geometry the fast forms compute
+            // (a far-cap hit, a direction refracted backward, a polynomial row outside its conic: possible only far
+            // outside any clear aperture).  What the reference does there is defined by its operation sequence, so the
+            // wave traces its rays again with exactly that — MATH_IEEE, bit-identical to the CPU reference; its history
+            // stores land on the same addresses, after the first pass's have completed.
+            __builtin_amdgcn_s_waitcnt(0);
+            launch_rays(std::integral_constant<int, MATH_IEEE>{});
+            trace_surfaces(std::integral_constant<int, MATH_IEEE>{});
+        }
+
+        ORT_PHASE(15);
+        // The stop filter r > a_stop (PupilSampling.jl:131-132).  The reference sequence takes hypot.  MATH_FAST decides by
+        // r^2 against a_stop^2 — the same outcome for every ray farther than kNear from the edge — and only the rays within
+        // kNear of it (their wave has retraced with the reference sequence, see the stop capture above) take the hypot.
+        auto outside_stop = [&](T xs, T ys, T& r2) -> bool {
+            if (MATH == MATH_IEEE) { r2 = T(0); return dev_hypot(xs, ys) > a_stop; }
+            const T a2 = a_stop < T(0) ? T(-1) : a_stop * a_stop;        // a negative radius passes nothing
+            r2 = t_fma<T>(xs, xs, ys * ys);
+            bool out = r2 > a2;
+            if (near_zero<T>(r2 - a2, (T)Near<T>::thr * a2)) out = dev_hypot(xs, ys) > a_stop;
+            return out;
+        };
+
+        if (SUMM) {
+            if (live[0]) {
+                if (p.xf) store_pair<T>(p.xf, gbase, two, ray[0].x, ray[RPT - 1].x);
+                if (p.yf) store_pair<T>(p.yf, gbase, two, ray[0].y, ray[RPT - 1].y);
+                if (p.xs) store_pair<T>(p.xs, gbase, two, xs_[0], xs_[RPT - 1]);
+                if (p.ys) store_pair<T>(p.ys, gbase, two, ys_[0], ys_[RPT - 1]);
+                if (p.status) {
+#pragma unroll
+                    for (int r = 0; r < RPT; ++r) {
+                        if (!live[r]) continue;
+                        int32_t s = st[r];
+                        if (stopi >= 0) {
+                            T r2;
+                            if (outside_stop(xs_[r], ys_[r], r2)) s |= (1 << 16);
+                        }
+                        p.status[gbase + r] = s;
+                    }
+                }
+            }
+        }
+
+        if (WALK) {
+            // stop filter (PupilSampling.jl:129-137), then straight into the lane's running sums (:169-173): no barrier, no
+            // shuffle, nothing per tile but this
+            bool keep[RPT];
+            double ex[RPT], ey[RPT];
+#pragma unroll
+            for (int r = 0; r < RPT; ++r) {
+                const T xf = ray[r].x, yf = ray[r].y;
+                T r2;
+                const bool outside = outside_stop(xs_[r], ys_[r], r2);                        // :131-132
+                keep[r] = !(outside || t_isnan(xf) || t_isnan(yf) || !live[r] || (st[r] & kStatusVignetted));
+                ex[r] = (double)xf; ey[r] = (double)(yf - hprime);                             // :135, :134
+            }
+            if (!wk_have) {                                                                  // scalar branch: taken until the wave holds a survivor
+#pragma unroll
+                for (int r = RPT - 1; r >= 0; --r) {
+                    const unsigned long long m = __ballot(keep[r]);
+                    if (m) {
+                        const int src = __builtin_ctzll(m);
+                        wk_kx = readlane_f64(ex[r], src); wk_ky = readlane_f64(ey[r], src); wk_have = true;
+                    }
+                }
+            }
+#pragma unroll
+            for (int r = 0; r < RPT; ++r) {
+                const double dx = keep[r] ? ex[r] - wk_kx : 0.0, dy = keep[r] ? ey[r] - wk_ky : 0.0;
+                wk_sx += dx; wk_sy += dy;
+                wk_qx = __builtin_fma(dx, dx, wk_qx); wk_qy = __builtin_fma(dy, dy, wk_qy);
+                wk_n += keep[r] ? 1 : 0;
+            }
+            tile_base += (unsigned)kTile; j0 += kTile; gbase += kTile; ++walk_tile;            // the next tile
+            if (walk_tile % kWalkTiles == 0 || wt == walk_n - 1) {
+                // end of a span (wave-uniform): fold the wave's lanes — one K per wave, so the sums just add; a 64-lane shuffle
+                // tree, fixed shape: bitwise reproducible — and write the wave's partial (n, mean, M2) of this span
+                const int lane = tid & 63, wave = tid >> 6;
+                double n = (double)wk_n;
+                for (int off = 32; off > 0; off >>= 1) {
+                    n += __shfl_down(n, off);
+                    wk_sx += __shfl_down(wk_sx, off); wk_sy += __shfl_down(wk_sy, off);
+                    wk_qx += __shfl_down(wk_qx, off); wk_qy += __shfl_down(wk_qy, off);
+                }
+                if (lane == 0) {
+                    const int64_t o = (((int64_t)b * p.walk_spans + (walk_tile - 1) / kWalkTiles) * (kBlock / 64)) + wave;
+                    const double inv = n > 0.0 ? 1.0 / n : 0.0;
+                    p.tile_cnt[o] = (int32_t)n;
+                    p.tile_sx[o] = __builtin_fma(wk_sx, inv, wk_kx); p.tile_sy[o] = __builtin_fma(wk_sy, inv, wk_ky);
+                    p.tile_m2x[o] = fmax(0.0, __builtin_fma(-wk_sx * inv, wk_sx, wk_qx));   // sum d^2 - (sum d)^2 / n about K ~ the mean
+                    p.tile_m2y[o] = fmax(0.0, __builtin_fma(-wk_sy * inv, wk_sy, wk_qy));
+                    p.tile_rmax[o] = -1.0;                                                   // (statistics only: no r)
+                }
+                wk_n = 0; wk_have = false;
+                wk_kx = wk_ky = wk_sx = wk_sy = wk_qx = wk_qy = 0.0;
+            }
+        }
+        if (FT != FT_NONE && !WALK) {
+            // stop filter (PupilSampling.jl:129-137).  FT_FULL: the tile's survivors are compacted IN RAY ORDER (two
+            // 64-bit ballots + popcount prefix per wave, wave offsets through LDS) and streamed to the first half of
+            // the bundle's output slab; FT_STATS: per-tile moments only.
+            int cnt = 0; double sx = 0.0, sy = 0.0, rmax = -1.0;
+            T exv[RPT], eyv[RPT], rv[RPT], thv[RPT];
+            bool keep[RPT];
+#pragma unroll
+            for (int r = 0; r < RPT; ++r) {
+                const T xf = ray[r].x, yf = ray[r].y;
+                T r2;
+                const bool outside = outside_stop(xs_[r], ys_[r], r2);                        // :131-132
+                // r itself (rho, :136,142): the reference sequence keeps its hypot; MATH_FAST takes the root of r^2 (seeded from
+                // r^2 + tiny: an on-axis ray gives 0, not 0 * inf), and the statistics-only route needs no r at all
+                T ri = T(0);
+                if (MATH == MATH_IEEE) ri = dev_hypot(xs_[r], ys_[r]);
+                else if (kCompact) ri = r2 * fast_rsqrt(r2 + (sizeof(T) == 8 ? (T)1e-300 : (T)1e-36));
+                const bool drop = outside || t_isnan(xf) || t_isnan(yf) || !live[r] || (st[r] & kStatusVignetted);
+                keep[r] = !drop;
+                if (kCompact) thv[r] = MATH == MATH_FAST ? fast_atan2(ys_[r], xs_[r]) : dev_atan2(ys_[r], xs_[r]);   // :133
+                eyv[r] = yf - hprime;                                    // :134
+                exv[r] = xf;                                             // :135
+                rv[r] = drop ? T(-1) : ri;                               // :136, -1 marks a dropped ray
+                if (!drop) { ++cnt; sx += (double)exv[r]; sy += (double)eyv[r]; rmax = fmax(rmax, (double)ri); }
+            }
+            const int lane = tid & 63, wave = tid >> 6;
+            int rank0 = 0;
+            if (kCompact) {
+                const unsigned long long m0 = __ballot(keep[0]);
+                const unsigned long long m1 = (RPT > 1) ? __ballot(keep[RPT - 1]) : 0ull;
+                const unsigned long long lt = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+                rank0 = __popcll(m0 & lt) + __popcll(m1 & lt);
+            }
+            // tile aggregates: fixed-shape tree -> bitwise reproducible.  The floating-point sums are taken in ONE order whatever
+            // RPT is — that of the two-rays-per-lane shape: a lane's two rays, a 64-lane shuffle tree over each group of 128
+            // rays (-> s_wsx / s_wsy[group]), the groups in sequence by whoever reads them.  With one ray per lane a group
+            // spans two waves: neighbouring lanes pair up, the pair sums meet in LDS, and the tree continues from its second level.
+            auto tile_sum2 = [&](double x, double y) {
+                if constexpr (RPT == 2) {
+                    for (int off = 32; off > 0; off >>= 1) { x += __shfl_down(x, off); y += __shfl_down(y, off); }
+                    if (lane == 0) { s_wsx[wave] = x; s_wsy[wave] = y; }
+                } else {
+                    x += __shfl_xor(x, 1); y += __shfl_xor(y, 1);            // a + b on both lanes of the pair: the same bits
+                    if (!(lane & 1)) { s_px[wave][lane >> 1] = x; s_py[wave][lane >> 1] = y; }
+                    __syncthreads();
+                    if (wave < kSumWaves) {
+                        double qx = 0.0, qy = 0.0;
+                        if (lane < 32) {                                     // the tree's first level: lanes l and l + 32 of the group
+                            qx = s_px[2 * wave][lane] + s_px[2 * wave + 1][lane];
+                            qy = s_py[2 * wave][lane] + s_py[2 * wave + 1][lane];
+                        }
+                        for (int off = 16; off > 0; off >>= 1) { qx += __shfl_down(qx, off); qy += __shfl_down(qy, off); }
+                        if (lane == 0) { s_wsx[wave] = qx; s_wsy[wave] = qy; }
+                    }
+                }
+            };
+            for (int off = 32; off > 0; off >>= 1) {
+                cnt += __shfl_down(cnt, off);
+                rmax = fmax(rmax, __shfl_down(rmax, off));
+            }
+            if (lane == 0) { s_wcnt[wave] = cnt; s_wmax[wave] = rmax; }
+            tile_sum2(sx, sy);
+            __syncthreads();
+            if (kCompact) {
+                __shared__ __attribute__((aligned(16))) T s_cx[kCompact ? kTile : 1], s_cy[kCompact ? kTile : 1], s_cr[kCompact ? kTile : 1], s_ct[kCompact ? kTile : 1];
+                __shared__ long long s_base;
+                int woff = 0, c = 0;
+                for (int w = 0; w < NT / 64; ++w) { woff += (w < wave) ? s_wcnt[w] : 0; c += s_wcnt[w]; }
+                int k = woff + rank0;
+#pragma unroll
+                for (int r = 0; r < RPT; ++r)
+                    if (keep[r]) { s_cx[k] = exv[r]; s_cy[k] = eyv[r]; s_cr[k] = rv[r]; s_ct[k] = thv[r]; ++k; }
+                const int tile = (int)(bid - (unsigned)b * (unsigned)p.tiles_per_bundle);
+                if (FT == FT_FULL) {
+                    if (tid == 0) {
+                        double ax = 0.0, ay = 0.0, mx = -1.0;
+                        for (int w = 0; w < kSumWaves; ++w) { ax += s_wsx[w]; ay += s_wsy[w]; }
+                        for (int w = 0; w < NT / 64; ++w) mx = fmax(mx, s_wmax[w]);
+                        p.tile_cnt[bid] = c; p.tile_sx[bid] = ax; p.tile_sy[bid] = ay; p.tile_rmax[bid] = mx;
+                    }
+                } else if (wave == 0) {
+                    // Exclusive offset of this tile among its bundle's survivors: decoupled look-back (Merrill & Garland) over
+                    // the bundle's earlier tiles, 64 at a time.  One 8-byte word per tile carries everything, so relaxed
+                    // agent-scope atomics suffice: state 1 = the tile's own count, state 2 = inclusive prefix.
                     double ax = 0.0, ay = 0.0, mx = -1.0;
                     for (int w = 0; w < kSumWaves; ++w) { ax += s_wsx[w]; ay += s_wsy[w]; }
                     for (int w = 0; w < NT / 64; ++w) mx = fmax(mx, s_wmax[w]);
-                    p.tile_cnt[bid] = c; p.tile_sx[bid] = ax; p.tile_sy[bid] = ay; p.tile_rmax[bid] = mx;
-                }
-            } else if (wave == 0) {
-                // Exclusive offset of this tile among its bundle's survivors: decoupled look-back (Merrill & Garland) over
-                // the bundle's earlier tiles, 64 at a time.  One 8-byte word per tile carries everything, so relaxed
-                // agent-scope atomics suffice: state 1 = the tile's own count, state 2 = inclusive prefix.
-                double ax = 0.0, ay = 0.0, mx = -1.0;
-                for (int w = 0; w < kSumWaves; ++w) { ax += s_wsx[w]; ay += s_wsy[w]; }
-                for (int w = 0; w < NT / 64; ++w) mx = fmax(mx, s_wmax[w]);
-                const unsigned long long ep = (unsigned long long)(p.ft_epoch & 0x3fffffffu) << 32;
-                unsigned long long* stw = p.ft_state + (size_t)b * p.tiles_per_bundle;
-                if (lane == 0) {
-                    p.tile_cnt[bid] = c; p.tile_sx[bid] = ax; p.tile_sy[bid] = ay; p.tile_rmax[bid] = mx;
-                    __hip_atomic_store(stw + tile, ((tile == 0 ? 2ull : 1ull) << 62) | ep | (unsigned)c, __ATOMIC_RELAXED,
-                                       __HIP_MEMORY_SCOPE_AGENT);
-                }
-                long long excl = 0;
-#if ORT_FT_DEBUG & 1            /* A/B only: no look-back, every tile writes at its dense position (wrong offsets, same traffic) */
-                int hi = -1; excl = (long long)tile * kTile * 3 / 4;
-#else
-                int hi = tile - 1;                               // next predecessor to look at
-#endif
-                constexpr int kLook = 4;                         // predecessors per lane and round: windows of 256 tiles
-                while (hi >= 0) {
-                    // lane l looks at tiles hi - kLook l - j, j = 0 .. kLook-1 (nearest first); every tile with a lower
-                    // ticket is running or done, so the waits end; the cap is a guard against a host-side bookkeeping
-                    // error only: it raises the fault word and the whole call returns an error
-                    long long part = 0;                          // sum of this lane's words up to its first inclusive one
-                    bool found = false;
-#pragma unroll
-                    for (int j = 0; j < kLook; ++j) {
-                        const int t = hi - kLook * lane - j;
-                        unsigned long long wd = 2ull << 62 | ep; // beyond the first tile: an inclusive prefix of 0
-                        if (t >= 0) {
-                            bool got = false;
-                            for (int spin = 0; spin < (1 << 22) && !got; ++spin) {
-                                wd = __hip_atomic_load(stw + t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                                got = (wd >> 62) != 0 && (wd & (0x3fffffffull << 32)) == ep;
-                                if (!got) {
-                                    // a fault already recorded (tickets outside the grid: predecessors that never run): stop waiting
-                                    if ((spin & 255) == 255 && __hip_atomic_load(p.ft_err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) break;
-                                    __builtin_amdgcn_s_sleep(1);
-                                }
-                            }
-                            if (!got) { atomicOr(p.ft_err, 1); wd = 2ull << 62 | ep; }   // cap hit: the call fails (run_full_trace)
-                        }
-                        if (!found) part += (long long)(wd & 0xffffffffull);
-                        found = found || ((wd >> 62) == 2);
-                    }
-                    const unsigned long long incl = __ballot(found);
-                    const int first = incl ? __builtin_ctzll(incl) : 64;       // nearest lane holding an inclusive prefix
-                    long long v = (lane <= first) ? part : 0;
-                    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off);
-                    excl += __shfl(v, 0);
-                    if (incl) break;
-                    hi -= 64 * kLook;
-                }
-                if (lane == 0) {
-                    if (tile != 0)
-                        __hip_atomic_store(stw + tile, (2ull << 62) | ep | (unsigned long long)(unsigned)(excl + c), __ATOMIC_RELAXED,
+                    const unsigned long long ep = (unsigned long long)(p.ft_epoch & 0x3fffffffu) << 32;
+                    unsigned long long* stw = p.ft_state + (size_t)b * p.tiles_per_bundle;
+                    if (lane == 0) {
+                        p.tile_cnt[bid] = c; p.tile_sx[bid] = ax; p.tile_sy[bid] = ay; p.tile_rmax[bid] = mx;
+                        __hip_atomic_store(stw + tile, ((tile == 0 ? 2ull : 1ull) << 62) | ep | (unsigned)c, __ATOMIC_RELAXED,
                                            __HIP_MEMORY_SCOPE_AGENT);
-                    s_base = excl;
+                    }
+                    long long excl = 0;
+#if ORT_FT_DEBUG & 1            /* A/B only: no look-back, every tile writes at its dense position (wrong offsets, same traffic) */
+                    int hi = -1; excl = (long long)tile * kTile * 3 / 4;
+#else
+                    int hi = tile - 1;                               // next predecessor to look at
+#endif
+                    constexpr int kLook = 4;                         // predecessors per lane and round: windows of 256 tiles
+                    while (hi >= 0) {
+                        // lane l looks at tiles hi - kLook l - j, j = 0 .. kLook-1 (nearest first); every tile with a lower
+                        // ticket is running or done, so the waits end; the cap is a guard against a host-side bookkeeping
+                        // error only: it raises the fault word and the whole call returns an error
+                        long long part = 0;                          // sum of this lane's words up to its first inclusive one
+                        bool found = false;
+#pragma unroll
+                        for (int j = 0; j < kLook; ++j) {
+                            const int t = hi - kLook * lane - j;
+                            unsigned long long wd = 2ull << 62 | ep; // beyond the first tile: an inclusive prefix of 0
+                            if (t >= 0) {
+                                bool got = false;
+                                for (int spin = 0; spin < (1 << 22) && !got; ++spin) {
+                                    wd = __hip_atomic_load(stw + t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                                    got = (wd >> 62) != 0 && (wd & (0x3fffffffull << 32)) == ep;
+                                    if (!got) {
+                                        // a fault already recorded (tickets outside the grid: predecessors that never run): stop waiting
+                                        if ((spin & 255) == 255 && __hip_atomic_load(p.ft_err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) break;
+                                        __builtin_amdgcn_s_sleep(1);
+                                    }
+                                }
+                                if (!got) { atomicOr(p.ft_err, 1); wd = 2ull << 62 | ep; }   // cap hit: the call fails (run_full_trace)
+                            }
+                            if (!found) part += (long long)(wd & 0xffffffffull);
+                            found = found || ((wd >> 62) == 2);
+                        }
+                        const unsigned long long incl = __ballot(found);
+                        const int first = incl ? __builtin_ctzll(incl) : 64;       // nearest lane holding an inclusive prefix
+                        long long v = (lane <= first) ? part : 0;
+                        for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off);
+                        excl += __shfl(v, 0);
+                        if (incl) break;
+                        hi -= 64 * kLook;
+                    }
+                    if (lane == 0) {
+                        if (tile != 0)
+                            __hip_atomic_store(stw + tile, (2ull << 62) | ep | (unsigned long long)(unsigned)(excl + c), __ATOMIC_RELAXED,
+                                               __HIP_MEMORY_SCOPE_AGENT);
+                        s_base = excl;
+                    }
                 }
-            }
-            __syncthreads();
-            if (FT == FT_FULL) {
-                // the tile's own slot of the workspace [tiles][kTile]: 16-byte aligned, so whole vectors go out (the
-                // entries past c inside the slot are never read)
-                constexpr int V = 16 / (int)sizeof(T);
-                typedef T vec_t __attribute__((ext_vector_type(V)));
-                const int64_t o0 = (int64_t)bid * kTile;
-                for (int j = tid * V; j < c; j += NT * V) {
-                    *reinterpret_cast<vec_t*>(p.out_ex + o0 + j) = *reinterpret_cast<const vec_t*>(s_cx + j);
-                    *reinterpret_cast<vec_t*>(p.out_ey + o0 + j) = *reinterpret_cast<const vec_t*>(s_cy + j);
-                    *reinterpret_cast<vec_t*>(p.out_r + o0 + j) = *reinterpret_cast<const vec_t*>(s_cr + j);
-                    *reinterpret_cast<vec_t*>(p.out_th + o0 + j) = *reinterpret_cast<const vec_t*>(s_ct + j);
+                __syncthreads();
+                if (FT == FT_FULL) {
+                    // the tile's own slot of the workspace [tiles][kTile]: 16-byte aligned, so whole vectors go out (the
+                    // entries past c inside the slot are never read)
+                    constexpr int V = 16 / (int)sizeof(T);
+                    typedef T vec_t __attribute__((ext_vector_type(V)));
+                    const int64_t o0 = (int64_t)bid * kTile;
+                    for (int j = tid * V; j < c; j += NT * V) {
+                        *reinterpret_cast<vec_t*>(p.out_ex + o0 + j) = *reinterpret_cast<const vec_t*>(s_cx + j);
+                        *reinterpret_cast<vec_t*>(p.out_ey + o0 + j) = *reinterpret_cast<const vec_t*>(s_cy + j);
+                        *reinterpret_cast<vec_t*>(p.out_r + o0 + j) = *reinterpret_cast<const vec_t*>(s_cr + j);
+                        *reinterpret_cast<vec_t*>(p.out_th + o0 + j) = *reinterpret_cast<const vec_t*>(s_ct + j);
+                    }
+                } else {
+                    // FT_LOOKBACK: its place in the bundle's output slab [2 rpb], any alignment
+                    const int64_t o0 = (int64_t)b * 2 * p.rpb + s_base;
+                    auto same = [](T v) { return v; };
+                    stream_out<T>(p.out_ex + o0, s_cx, c, tid, same); stream_out<T>(p.out_ey + o0, s_cy, c, tid, same);
+                    stream_out<T>(p.out_r + o0, s_cr, c, tid, same);  stream_out<T>(p.out_th + o0, s_ct, c, tid, same);
                 }
             } else {
-                // FT_LOOKBACK: its place in the bundle's output slab [2 rpb], any alignment
-                const int64_t o0 = (int64_t)b * 2 * p.rpb + s_base;
-                auto same = [](T v) { return v; };
-                stream_out<T>(p.out_ex + o0, s_cx, c, tid, same); stream_out<T>(p.out_ey + o0, s_cy, c, tid, same);
-                stream_out<T>(p.out_r + o0, s_cr, c, tid, same);  stream_out<T>(p.out_th + o0, s_ct, c, tid, same);
-            }
-        } else {
-            // FT_STATS: two-pass INSIDE the tile (the tile's survivors are still in registers): tile means,
-            // then squared deviations about them; tiles are merged with Chan's update in k_ft_stats_reduce —
-            // as stable as the reference's two-pass sigma (:169-173), without a second pass over memory.
-            int c = 0; double ax = 0.0, ay = 0.0, mx = -1.0;
-            for (int w = 0; w < kSumWaves; ++w) { ax += s_wsx[w]; ay += s_wsy[w]; }
-            for (int w = 0; w < NT / 64; ++w) { c += s_wcnt[w]; mx = fmax(mx, s_wmax[w]); }
-            const double mux = c ? ax / (double)c : 0.0, muy = c ? ay / (double)c : 0.0;
-            double qx = 0.0, qy = 0.0;
+                // FT_STATS: two-pass INSIDE the tile (the tile's survivors are still in registers): tile means,
+                // then squared deviations about them; tiles are merged with Chan's update in k_ft_stats_reduce —
+                // as stable as the reference's two-pass sigma (:169-173), without a second pass over memory.
+                int c = 0; double ax = 0.0, ay = 0.0, mx = -1.0;
+                for (int w = 0; w < kSumWaves; ++w) { ax += s_wsx[w]; ay += s_wsy[w]; }
+                for (int w = 0; w < NT / 64; ++w) { c += s_wcnt[w]; mx = fmax(mx, s_wmax[w]); }
+                const double mux = c ? ax / (double)c : 0.0, muy = c ? ay / (double)c : 0.0;
+                double qx = 0.0, qy = 0.0;
 #pragma unroll
-            for (int r = 0; r < RPT; ++r) {
-                if (!(rv[r] < T(0))) {
-                    const double dx = (double)exv[r] - mux, dy = (double)eyv[r] - muy;
-                    qx += dx * dx; qy += dy * dy;
+                for (int r = 0; r < RPT; ++r) {
+                    if (!(rv[r] < T(0))) {
+                        const double dx = (double)exv[r] - mux, dy = (double)eyv[r] - muy;
+                        qx += dx * dx; qy += dy * dy;
+                    }
                 }
-            }
-            __syncthreads();                                     // s_wsx / s_wsy are reused below
-            tile_sum2(qx, qy);
-            __syncthreads();
-            if (tid == 0) {
-                double tx = 0.0, ty = 0.0;
-                for (int w = 0; w < kSumWaves; ++w) { tx += s_wsx[w]; ty += s_wsy[w]; }
-                p.tile_cnt[blockIdx.x] = c; p.tile_sx[blockIdx.x] = mux; p.tile_sy[blockIdx.x] = muy;
-                p.tile_m2x[blockIdx.x] = tx; p.tile_m2y[blockIdx.x] = ty; p.tile_rmax[blockIdx.x] = mx;
+                __syncthreads();                                     // s_wsx / s_wsy are reused below
+                tile_sum2(qx, qy);
+                __syncthreads();
+                if (tid == 0) {
+                    double tx = 0.0, ty = 0.0;
+                    for (int w = 0; w < kSumWaves; ++w) { tx += s_wsx[w]; ty += s_wsy[w]; }
+                    p.tile_cnt[blockIdx.x] = c; p.tile_sx[blockIdx.x] = mux; p.tile_sy[blockIdx.x] = muy;
+                    p.tile_m2x[blockIdx.x] = tx; p.tile_m2y[blockIdx.x] = ty; p.tile_rmax[blockIdx.x] = mx;
+                }
             }
         }
     }

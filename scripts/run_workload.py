@@ -5,6 +5,9 @@ thing interleaved A/B timings call.  Prints one JSON line.
   python scripts/run_workload.py config3 --mode stats|full|lookback [--policy fast|ieee] [--pupil 2048] [--reps 5]
   python scripts/run_workload.py config2 --mode summary|history|stats|full
   python scripts/run_workload.py config1 --mode full|stats [--field 1.0]      (one-call pipeline, host buffers)
+  python scripts/run_workload.py config5 --mode stats|hits [--dtype f32|f64] [--instances 10000] [--retrace]
+        stats: ort_spot_batch_f32 (one C call, host arrays in, 16 B per (instance, field) out: the statistics kernel);
+        hits:  the same number of rays through the Float32 summary kernel (image-plane hits, 8 B per ray out)
 """
 import argparse
 import ctypes as C
@@ -19,7 +22,10 @@ import numpy as np
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("workload", choices=["config1", "config2", "config3"])
+    ap.add_argument("workload", choices=["config1", "config2", "config3", "config5"])
+    ap.add_argument("--dtype", default="f32", choices=["f32", "f64"], help="config5: arithmetic of the pupil trace")
+    ap.add_argument("--instances", type=int, default=10000, help="config5: perturbed instances")
+    ap.add_argument("--retrace", action="store_true", help="print the retrace counters of an -DORT_COUNT_RETRACE build")
     ap.add_argument("--mode", default="stats")
     ap.add_argument("--policy", default="fast", choices=["fast", "ieee"])
     ap.add_argument("--pupil", type=int, default=0)
@@ -65,6 +71,39 @@ def main():
             res.update(rms=r[1][0]["rms"], count=r[1][0]["count"])
         else:
             res.update(rms=float(r["rms"][0, 0]), count=int(r["count"][0, 0]))
+        print(json.dumps(res), flush=True)
+        return
+
+    if a.workload == "config5":
+        # BASELINE config 5: 10^4 perturbed Double-Gauss instances x 2 fields x 256 x 128 half pupil (stats) — or the same
+        # 6.55e8 rays as instances / 2 x 2 fields x 256 x 256 full pupil through the summary kernel (hits)
+        k5 = a.pupil or 256
+        dt = np.float32 if a.dtype == "f32" else np.float64
+        mats = workloads.config5(None, ninst=a.instances)
+        if a.mode == "stats":
+            fn = lambda: batch.spot_batch(mats, workloads.DG_A, workloads.DG_H, (0.0, 1.0), k5, engine=eng, dtype=dt)
+            rays = a.instances * 2 * k5 * (k5 // 2)
+        else:
+            plan = batch.ImageHitsPlan(mats[:a.instances // 2], workloads.DG_A, workloads.DG_H, (0.0, 1.0), k5, engine=eng, dtype=dt)
+            hits = plan.new_hits()
+            fn = lambda: (plan.trace(hits), eng.ctx.synchronize())
+            rays = plan.n_rays
+        fn(); eng.ctx.synchronize()
+        if a.retrace:
+            cnt = (C.c_ulonglong * 2)()
+            lib.ort_debug_retrace_counts.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
+            lib.ort_debug_retrace_counts.restype = C.c_int
+            _capi.check(lib.ort_debug_retrace_counts(h, cnt, 1))
+        ts = []
+        for _ in range(a.reps):
+            t0 = time.perf_counter(); r = fn(); eng.ctx.synchronize(); ts.append(time.perf_counter() - t0)
+        res.update(dtype=a.dtype, instances=a.instances, rays=rays, intersections=rays * 12, wall_ms_median=float(np.median(ts)) * 1e3,
+                   wall_ms_min=float(np.min(ts)) * 1e3, intersections_per_s=rays * 12 / float(np.median(ts)))
+        if a.mode == "stats":
+            res.update(mean_rms=float(np.nanmean(r["rms"])), count_mean=float(r["count"].mean()))
+        if a.retrace:
+            _capi.check(lib.ort_debug_retrace_counts(h, cnt, 0))
+            res.update(tile_waves=int(cnt[0]), tile_waves_retraced=int(cnt[1]), retrace_fraction=cnt[1] / max(1, cnt[0]))
         print(json.dumps(res), flush=True)
         return
 
