@@ -110,6 +110,21 @@ class HipEngine:
                                               ptr(xv), ptr(yv), N, ptr(st), flags))
         return (xv, yv, st) if want_status else (xv, yv)
 
+    def skew_f32(self, pres: Prescription, y, x, u, v, isys: int = 0, nrays: Optional[int] = None):
+        """The Float32 build of `skew` (`ort_trace_skew_f32`, BASELINE config 5's arithmetic; the reference itself is
+        Float64-only, Q21) over an explicit ray list with SLOPES u = tan U, v = tan V given.  Returns xv, yv [S][N] float32
+        and status.  nrays < N traces a prefix of the list into the same [S][N] buffers (ld = N)."""
+        y, x, u, v = np.broadcast_arrays(*(np.atleast_1d(np.asarray(a, dtype=np.float32)) for a in (y, x, u, v)))
+        y, x, u, v = (np.ascontiguousarray(a) for a in (y, x, u, v))
+        N = y.size
+        S = pres.rows - 1
+        xv = np.full((S, N), np.nan, dtype=np.float32); yv = np.full((S, N), np.nan, dtype=np.float32)
+        st = np.zeros(N, dtype=np.int32)
+        sysd = self.system(pres)
+        check(self.ctx.lib.ort_trace_skew_f32(self.ctx.h, sysd.h, isys, N if nrays is None else int(nrays), ptr(y), ptr(x), ptr(u), ptr(v),
+                                              ptr(xv), ptr(yv), N, ptr(st), self.base_flags | _capi.ORT_INPUT_SLOPES))
+        return xv, yv, st
+
     # ---- grid bundles: PupilSampling.jl:121-138 -----------------------------------------
     def grid(self, pres: Prescription, bundles: Sequence[dict], axes, ny: int, nx: int,
              history: bool = True, summary: bool = True, raybasis: bool = False):

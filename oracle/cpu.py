@@ -50,6 +50,7 @@ def lib():
     L.orc_trace_skew_grid_f32.argtypes = [_i, _fp, _fp, _fp, _fp, _fp, _i, _i, _fp, _i, _fp, C.c_float, C.c_float,
                                           _fp, _fp, _l, _ip, _i]
     L.orc_trace_skew_grid_f32.restype = _l
+    L.orc_trace_skew_batch_f32.argtypes = [_i, _fp, _fp, _fp, _fp, _fp, _i, _l, _fp, _fp, _fp, _fp, _fp, _fp, _l, _ip, _i]
     L.orc_trace_meridional.argtypes = [_i, _dp, _dp, _dp, _dp, _dp, _i, _i, _d, _d, _dp, _dp, _dp]
     L.orc_trace_meridional.restype = _i
     L.orc_lens_from_surfaces.argtypes = [_i, _dp, _dp, _dp, _dp, _dp]; L.orc_lens_from_surfaces.restype = _i
@@ -165,6 +166,22 @@ class OracleEngine:
             self.L.orc_trace_skew_batch(*s.args(), N, _p(y), _p(x), _p(U), _p(V), _p(xv), _p(yv), N,
                                         st.ctypes.data_as(_ip), self.nthreads)
         return (xv, yv, st) if want_status else (xv, yv)
+
+    def skew_f32(self, pres, y, x, u, v, isys: int = 0):
+        """The Float32 build of the same loop over an explicit ray list, SLOPES in (orc_trace_skew_batch_f32): the
+        prescription and the rays are rounded to binary32 once, as ort_system_create / the caller do.  Returns xv, yv
+        [S][N] float32 and status."""
+        s = _Sys(pres, isys)
+        f = lambda a: None if a is None else np.ascontiguousarray(a, dtype=np.float32)
+        fp = lambda a: None if a is None else a.ctypes.data_as(_fp)
+        R, t, n, K, coef = f(s.R), f(s.t), f(s.n), f(s.K), f(s.coef)
+        y, x, u, v = np.broadcast_arrays(*(np.atleast_1d(np.asarray(a, dtype=np.float32)) for a in (y, x, u, v)))
+        y, x, u, v = (np.ascontiguousarray(a) for a in (y, x, u, v))
+        N, S = y.size, s.rows - 1
+        xv = np.empty((S, N), dtype=np.float32); yv = np.empty((S, N), dtype=np.float32); st = np.empty(N, dtype=np.int32)
+        self.L.orc_trace_skew_batch_f32(s.rows, fp(R), fp(t), fp(n), fp(K), fp(coef), s.ncoef, N, fp(y), fp(x), fp(u), fp(v),
+                                        fp(xv), fp(yv), N, st.ctypes.data_as(_ip), self.nthreads)
+        return xv, yv, st
 
     def skew_margins(self, pres, y, x, u, v, isys: int = 0) -> np.ndarray:
         """[nrays, 4] conditioning probe of orc_skew_margins (slopes in): min normalised sag discriminant,

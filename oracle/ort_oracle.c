@@ -154,6 +154,30 @@ static double tilt2(double y, double R, double K, const double *c, int ncoef)
     return sgn_f64(R) * y / sqrt(R * R - y * y * (1.0 + K)) + dpoly_f64(c, ncoef, y);
 }
 
+/* The list form of the same Float32 build (ort_trace_skew_f32): ray r = (y[r], x[r]) launched with the SLOPES
+ * u[r] = tan U, v[r] = tan V (taken by the caller: no libm call on either side).                         */
+void orc_trace_skew_batch_f32(int rows, const float *R, const float *t, const float *n,
+                              const float *K, const float *coef, int ncoef,
+                              int64_t nrays, const float *y, const float *x, const float *u, const float *v,
+                              float *xv, float *yv, int64_t ld, int32_t *status, int nthreads)
+{
+    const int S = rows - 1;
+    if (nthreads < 1) nthreads = 1;
+#pragma omp parallel for num_threads(nthreads) schedule(static)
+    for (int64_t r = 0; r < nrays; ++r) {
+        float bx[ORC_MAX_ROWS], by[ORC_MAX_ROWS];
+        skew_f32(rows, R, t, n, K, coef, ncoef, y[r], x[r], u[r], v[r], bx, by, 0);
+        if (xv && yv)
+            for (int s = 0; s < S; ++s) { xv[s * ld + r] = bx[s]; yv[s * ld + r] = by[s]; }
+        if (status) {
+            int st = S + 1;
+            for (int s = 0; s < S; ++s)
+                if (isnan(bx[s]) || isnan(by[s])) { st = s + 1; break; }
+            status[r] = st;
+        }
+    }
+}
+
 /* src/RayTracing.jl:145-169 */
 int orc_trace_meridional(int rows, const double *R, const double *t, const double *n,
                          const double *K, const double *coef, int ncoef,

@@ -146,6 +146,11 @@ int64_t orc_trace_skew_grid_f32(int rows, const float *R, const float *t, const 
                                 float u, float v,
                                 float *xv, float *yv, int64_t ld, int32_t *status,
                                 int nthreads);
+/* ... and of the explicit ray list (slopes u = tan U, v = tan V given).                */
+void orc_trace_skew_batch_f32(int rows, const float *R, const float *t, const float *n,
+                              const float *K, const float *coef, int ncoef,
+                              int64_t nrays, const float *y, const float *x, const float *u, const float *v,
+                              float *xv, float *yv, int64_t ld, int32_t *status, int nthreads);
 
 #ifdef __cplusplus
 }

@@ -98,6 +98,13 @@ from opticalraytracing_jl_amd.workloads import (DG_A, DG_H, double_gauss,  # noq
                                                 double_gauss_aspheric)
 
 
+REPORT = []          # lines the parity tests want in the run's output (tests/conftest.py prints them in the terminal summary)
+
+
+def report(line: str) -> None:
+    REPORT.append(line)
+
+
 def rel_err(got, ref, scale):
     """|got - ref| / max(|ref|, scale): coordinates legitimately cross 0."""
     got = np.asarray(got, dtype=np.float64)

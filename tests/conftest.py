@@ -22,3 +22,12 @@ def oracle_engine():
 def hip_engine():
     import opticalraytracing_jl_amd as ort
     return ort.default_engine()
+
+
+def pytest_terminal_summary(terminalreporter):
+    """Measured figures the parity tests record (rays past 1e-10 under the FAST policy, worst deviations): printed with -q too."""
+    from tests import common
+    if common.REPORT:
+        terminalreporter.section("parity report")
+        for line in common.REPORT:
+            terminalreporter.write_line(line)
