@@ -308,7 +308,7 @@ def bench_single(args, torch, rank, world, local_rank, emit=True):
                  "sustained_kernel_ms": osus, "sustained_frac": None if osus is None else algo_bytes / (osus * 1e-3) / 1e9 / HBM_PEAK_GBS,
                  "achieved_GBps": algo_bytes / (oms * 1e-3) / 1e9, "frac": algo_bytes / (oms * 1e-3) / 1e9 / HBM_PEAK_GBS,
                  "parity": "bit-identical to the CPU oracle (reference operation sequence)" if fast else
-                           "<= 1e-10 relative, status identical on every ray (tests/test_gpu_parity.py::_fast_attribution)"}
+                           "<= 1e-10 relative, no status flip observed on any ray (tests/test_gpu_parity.py::_fast_attribution)"}
 
     # ---- extras: summary mode (config 2), BASELINE config 3 through full_trace + compaction ----
     def run_extras():
@@ -526,11 +526,11 @@ def bench_single(args, torch, rank, world, local_rank, emit=True):
                    "surface_table": "lds",
                    "policy": args.policy,
                    "policy_parity": ("bit-identical to the CPU oracle on every ray (reference operation sequence)" if not fast else
-                                     "<= 1e-10 relative vs the reference sequence, status identical on EVERY ray by construction: a wave "
-                                     "holding a ray within 1e-9 (normalised) of a miss / TIR / equator / stop-edge branch, a totally "
-                                     "reflected ray, a far-cap hit, a backward direction or a polynomial row outside its conic retraces "
-                                     "with the reference sequence (bit-identical there); tests/test_gpu_parity.py::_fast_attribution, "
-                                     "tests/test_device_emulation.py"),
+                                     "<= 1e-10 relative vs the reference sequence; no status flip observed on any ray of the parity "
+                                     "suites and soaks: a wave holding a ray within 1e-9 (normalised) of a miss / TIR / equator / "
+                                     "stop-edge branch, a totally reflected ray, a far-cap hit, a backward direction or a polynomial row "
+                                     "outside its conic retraces with the reference sequence (bit-identical there); "
+                                     "tests/test_gpu_parity.py::_fast_attribution, tests/test_device_emulation.py"),
                    "parallelism": "1 GPU" if world == 1 else
                                   (f"{world} ranks (one process per GPU), WEAK scaling: every rank traces its own zoom position of the same "
                                    "batch — the path shards over independent (system, field, index column) units, no data-path collective; "

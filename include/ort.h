@@ -55,14 +55,18 @@ extern "C" {
 #define ORT_LAYOUT_INPUT  (1u << 3) /* meridional: input was a Layout -> always atan (Q16) */
 #define ORT_CLIP          (1u << 4) /* paraxial: clip = true (RayTracing.jl:135) */
 #define ORT_FAST_MATH     (1u << 5) /* direction-cosine / fused arithmetic: coordinates within 1e-10 relative of the
-                                       reference sequence (measured <= 5e-12), status IDENTICAL on every ray by construction:
-                                       a wave holding a ray within 1e-9 (normalised) of a branch of the reference loop (surface
+                                       reference sequence (measured <= 5e-12 on well-conditioned paths).  Status: a wave
+                                       holding a ray within 1e-9 (normalised) of a branch of the reference loop (surface
                                        miss, total reflection, a sphere's equator, the stop filter's or a clear aperture's edge),
                                        a totally reflected ray, or a ray on which the reference's formulas are not the geometry
                                        (hit beyond the equator, direction refracted backward, polynomial row outside its conic)
-                                       retraces with the reference sequence and is bit-identical there.  Default: the op-for-op
-                                       IEEE sequence of the reference loop, bit-identical to a non-fused CPU evaluation.  Both
-                                       policies run the same entry points (tests/test_gpu_parity.py) */
+                                       retraces with the reference sequence and is bit-identical there.  That margin is 100 x
+                                       the deviation measured on ordinary paths; an ill-conditioned path could in principle
+                                       amplify a rounding difference past it at a LATER surface, so identical status is an
+                                       observation, not a theorem: no flip on any ray of the parity suites and soaks (> 1e7 rays
+                                       of adversarial random systems, profiles/r0*_soak_*; every ray of configs 2 and 3).
+                                       Default: the op-for-op IEEE sequence of the reference loop, bit-identical to a non-fused
+                                       CPU evaluation.  Both policies run the same entry points (tests/test_gpu_parity.py) */
 #define ORT_NO_SMALL_PATH (1u << 8) /* testing aid: small problems (<= 256 (system, field) pairs; full_trace bundles of <= 32 tiles)
                                        normally run their setup and their finish as ONE launch each (k_small_prepare,
                                        k_ft_small_finish); this takes the general multi-launch route instead — same device
@@ -242,6 +246,11 @@ int ort_ctx_domain_error(ort_ctx *ctx, int64_t *ray, int *surface, int64_t *coun
  * caller uploads as `rev`, built as :267-277 incl. quirk Q17) and the edge-ray search of
  * src/PupilSampling.jl:67-83 (Optim.BFGS in the reference — a third-party optimiser, parity unpinned; restated as
  * the same FD-Newton), giving the aiming scalars of src/PupilSampling.jl:94-103 that ort_full_trace_f64 consumes.
+ * Every trace inside the loops is the reference's meridional sequence (tan / asin / atan, src/RayTracing.jl:151-167).
+ * With ORT_FAST_MATH a prescription of spheres and planes only is traced there in direction-vector form without a
+ * trigonometric call — the same function of the launch data to rounding; since the loops stop at |residual| <=
+ * sqrt(eps) (RayTracing.jl:1) the two forms may end on iterates a few 1e-9 apart (U, y1, y2, y_EP, and with them the
+ * one-call pipelines' outputs to ~1e-7; the latency of a single small call is what it buys: DESIGN.md section 7).
  * FITTED TO ONE DOCS FIGURE, not a restatement: an edge-ray search that ends outside the stop's edge takes one more
  * step to atol inside, so y1 / y2 are biased inward by <= atol and the grid's two edge rays pass the filter
  * r > a_stop of :132.  The reference's published Tessar spot size (0.11975, real_spot_diagram.png) comes out with

@@ -223,6 +223,7 @@ int check_sys(ort_ctx* ctx, const ort_system* sys)
 }
 
 int sync_comm_streams(ort_ctx* ctx);    // (defined beside ort_comm, below)
+void detach_comm(struct ort_comm* c);
 
 // copy a host array into a scratch slot (synchronous with respect to the host buffer)
 template <typename T>
@@ -727,7 +728,8 @@ int spot_batch_impl(ort_ctx* ctx, int nsys, int rows, const double* R, const dou
     if (na <= kSmallPairs && !(flags & ORT_NO_SMALL_PATH)) {
         // a few pairs: all of it in ONE launch, one wave per pair (k_small_prepare; the same device functions)
         hipLaunchKernelGGL((k_small_prepare<T>), dim3((unsigned)na), dim3(64), 0, st, nsys, nfields, rows, dR, dt, dn, dK, coefp, ncoef,
-                           da, dh, dfields, k_rays, k2, layout ? 1 : 0, 587.5618e-6, d_fo, d_rec, d_poly, d_bd, d_axes, d_flag);
+                           da, dh, dfields, k_rays, k2, layout ? 1 : 0, 587.5618e-6, d_fo, d_rec, d_poly, d_bd, d_axes, d_flag,
+                           (flags & ORT_FAST_MATH) ? 1 : 0);
     } else {
         MerSurf *d_mf, *d_mr; double *d_tlf, *d_tlr, *d_ends, *d_crev = nullptr; AimIn* d_ain; AimOut* d_aout;
         if (ncoef > 0) { rc = dev_out<double>(ctx, SL_SB_CREV, n_c, &d_crev); if (rc) return rc; }
@@ -744,7 +746,7 @@ int spot_batch_impl(ort_ctx* ctx, int nsys, int rows, const double* R, const dou
                            coefp, ncoef, d_fo, d_rec, d_poly, d_mf, d_mr, d_crev, d_tlf, d_tlr);
         hipLaunchKernelGGL(k_build_aim, nblk(na, kBlock), dim3(kBlock), 0, st, nsys, nfields, rows, d_fo, da, dfields, layout ? 1 : 0, d_ain);
         hipLaunchKernelGGL(k_aim, nblk((int64_t)na * 4, 64), dim3(64), 0, st, na, d_ain, d_mf, coefp, d_tlf,
-                           d_mr, (const double*)d_crev, d_tlr, rows - 1, ncoef, d_aout, 1);
+                           d_mr, (const double*)d_crev, d_tlr, rows - 1, ncoef, d_aout, 1, (flags & ORT_FAST_MATH) ? 1 : 0);
         hipLaunchKernelGGL((k_build_bundles<T>), nblk(na, kBlock), dim3(kBlock), 0, st, na, k_rays, k2, d_ain, d_aout, d_bd, d_ends, d_flag);
         hipLaunchKernelGGL((k_make_axes<T>), nblk((int64_t)na * (k_rays + k2), kBlock), dim3(kBlock), 0, st, na, k_rays, k2, d_ends, d_axes);
     }
@@ -767,6 +769,12 @@ int spot_batch_impl(ort_ctx* ctx, int nsys, int rows, const double* R, const dou
         HIP_TRY(hipStreamSynchronize(st));
         memcpy(count, hpin + o_cnt, (size_t)na * sizeof(int64_t));
         memcpy(rms, hpin + o_rms, (size_t)na * sizeof(double));
+        // the stages ran with device pointers, where a faulted look-back shows as count = -1 (k_ft_finalize): a host caller
+        // is promised an error code instead (ort.h)
+        if (ex && (flags & ORT_FT_LOOKBACK))
+            for (int b = 0; b < na; ++b)
+                if (count[b] < 0)
+                    return fail(ORT_EHIP, "full_trace look-back fault: the survivors' offsets are not trustworthy, nothing was returned");
         if (ex) {
             const T* hv = reinterpret_cast<const T*>(hpin + o_vec);
             for (int b = 0; b < na; ++b) {                           // the valid entries of every slab
@@ -830,6 +838,11 @@ int ort_ctx_destroy(ort_ctx* ctx)
     if (!ctx) return ORT_OK;
     hipError_t e = hipSetDevice(ctx->device); (void)e;
     e = hipStreamSynchronize(ctx->stream); (void)e;
+    // communicators that outlive their context (a garbage collector's order): their streams may still hold this context's
+    // scratch in flight — drain them — and they must not reach back into freed memory: detach them (their entry points then
+    // fail with "null context"; ort_comm_destroy still releases them)
+    (void)sync_comm_streams(ctx);
+    for (ort_comm* c : ctx->comms) detach_comm(c);
     for (auto& s : ctx->slot) s.release();
     if (ctx->pin) { e = hipHostFree(ctx->pin); (void)e; }
     if (ctx->ev0) { e = hipEventDestroy(ctx->ev0); (void)e; }
@@ -1308,7 +1321,7 @@ int ort_aim_f64(ort_ctx* ctx, const ort_system* fwd, const ort_system* rev, int 
     }
     hipLaunchKernelGGL(k_aim, dim3((unsigned)(((int64_t)n * 4 + 63) / 64)), dim3(64), 0, ctx->stream, n, din,
                        fwd->mer, fwd->coef64, fwd->d_tlast, rev->mer, rev->coef64, rev->d_tlast, S, fwd->ncoef, dout,
-                       (flags & ORT_AIM_EDGE_AS_FOUND) ? 0 : 1);
+                       (flags & ORT_AIM_EDGE_AS_FOUND) ? 0 : 1, (flags & ORT_FAST_MATH) ? 1 : 0);
     HIP_TRY(hipGetLastError());
     if (!devp) {
         rc = from_device<AimOut>(ctx, reinterpret_cast<AimOut*>(out), dout, (size_t)n); if (rc) return rc;
@@ -1563,7 +1576,8 @@ int rccl_load()
 // stream (an event), so that the reassembly of one shard overlaps the trace of the next; ort_comm_wait orders the
 // context's stream after them again, ort_comm_synchronize blocks the host.
 struct ort_comm {
-    ort_ctx* ctx = nullptr;
+    ort_ctx* ctx = nullptr;          // null once the context has been destroyed ahead of the communicator (ort_ctx_destroy)
+    int device = 0;
     void* comm = nullptr;
     int nranks = 0, rank = 0;
     hipStream_t stream = nullptr;
@@ -1582,6 +1596,7 @@ int sync_comm_streams(ort_ctx* ctx)
         if (c && c->stream) HIP_TRY(hipStreamSynchronize(c->stream));
     return ORT_OK;
 }
+void detach_comm(ort_comm* c) { if (c) c->ctx = nullptr; }
 int comm_begin(ort_comm* c)          // comm stream waits for everything queued on the context's stream so far
 {
     HIP_TRY(hipEventRecord(c->ev_in, c->ctx->stream));
@@ -1616,7 +1631,7 @@ int ort_comm_create(ort_ctx* ctx, int nranks, int rank, const void* id128, ort_c
     memcpy(id.b, id128, ORT_UNIQUE_ID_BYTES);
     ort_comm* c = new (std::nothrow) ort_comm();
     if (!c) return fail(ORT_ENOMEM, "out of host memory");
-    c->ctx = ctx; c->nranks = nranks; c->rank = rank;
+    c->ctx = ctx; c->device = ctx->device; c->nranks = nranks; c->rank = rank;
     hipError_t e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
     if (e == hipSuccess) e = hipEventCreateWithFlags(&c->ev_in, hipEventDisableTiming);
     for (int i = 0; i < ort_comm::kRing && e == hipSuccess; ++i) e = hipEventCreateWithFlags(&c->ev_ring[i], hipEventDisableTiming);
@@ -1633,10 +1648,12 @@ int ort_comm_create(ort_ctx* ctx, int nranks, int rank, const void* id128, ort_c
 int ort_comm_destroy(ort_comm* comm)
 {
     if (!comm) return ORT_OK;
-    for (auto& q : comm->ctx->comms) if (q == comm) q = nullptr;
-    hipError_t e = hipSetDevice(comm->ctx->device); (void)e;
+    hipError_t e = hipSetDevice(comm->device); (void)e;
     if (comm->stream) { e = hipStreamSynchronize(comm->stream); (void)e; }
-    e = hipStreamSynchronize(comm->ctx->stream); (void)e;
+    if (comm->ctx) {                                             // (a context destroyed first has detached itself, ort_ctx_destroy)
+        for (auto& q : comm->ctx->comms) if (q == comm) q = nullptr;
+        e = hipStreamSynchronize(comm->ctx->stream); (void)e;
+    }
     if (comm->comm && g_rccl.CommDestroy) g_rccl.CommDestroy(comm->comm);
     if (comm->d_counts) { e = hipFree(comm->d_counts); (void)e; }
     if (comm->h_counts) { e = hipHostFree(comm->h_counts); (void)e; }

@@ -1482,12 +1482,14 @@ __device__ __forceinline__ void pair_newton(F&& trace, double& v, double target,
 // request's forward / reversed tables, cF / cR their coefficient rows (or null).  Returns the result on every lane.
 __device__ inline AimOut aim_group(const AimIn& a, int role, const MerSurf* __restrict__ F, const double* __restrict__ cF, double tlF,
                                    const MerSurf* __restrict__ Rv, const double* __restrict__ cR, double tlR, int S, int ncoef,
-                                   bool edge_inside = true)
+                                   bool edge_inside = true, bool fast = false)
 {
     const int pair = role >> 1, pairbase = pair * 2;
     const int rows = S + 1;
-    // plain prescription (spheres and planes only, both ways): the trig-free trace (mer_plain_trace_to)
-    bool plain = true;
+    // ORT_FAST_MATH and a plain prescription (spheres and planes only, both ways): the trig-free trace (mer_plain_trace_to).
+    // The default policy keeps the reference's own sequence (mer_trace_to: tan / asin / atan, RayTracing.jl:151-167) — the
+    // loops stop at |residual| <= sqrt(eps), so two forms of the same function may end on iterates a few 1e-9 apart
+    bool plain = fast;
     for (int i = 0; i < S; ++i) plain = plain && F[i].K == 0.0 && F[i].ncoef == 0 && Rv[i].K == 0.0 && Rv[i].ncoef == 0;
     int iters = 0, ok = 1;
     // ---- phase 1: real chief ray on the reversed system (RayTracing.jl:278-286) | real marginal ray (:225-233)
@@ -1557,7 +1559,7 @@ __device__ inline AimOut aim_group(const AimIn& a, int role, const MerSurf* __re
 __global__ __launch_bounds__(64) void k_aim(int n, const AimIn* __restrict__ in,
                                             const MerSurf* __restrict__ fwd, const double* __restrict__ cfwd, const double* __restrict__ tl_fwd,
                                             const MerSurf* __restrict__ rev, const double* __restrict__ crev, const double* __restrict__ tl_rev,
-                                            int S, int ncoef, AimOut* __restrict__ out, int edge_inside)
+                                            int S, int ncoef, AimOut* __restrict__ out, int edge_inside, int fast)
 {
     const int g = blockIdx.x * 64 + threadIdx.x;
     const int aim = g >> 2, role = g & 3;
@@ -1566,7 +1568,7 @@ __global__ __launch_bounds__(64) void k_aim(int n, const AimIn* __restrict__ in,
     const int rows = S + 1;
     const AimOut o = aim_group(a, role, fwd + (int64_t)a.system * S, cfwd ? cfwd + (int64_t)a.system * rows * ncoef : nullptr,
                                tl_fwd[a.system], rev + (int64_t)a.system * S, crev ? crev + (int64_t)a.system * rows * ncoef : nullptr,
-                               tl_rev[a.system], S, ncoef, edge_inside != 0);
+                               tl_rev[a.system], S, ncoef, edge_inside != 0, fast != 0);
     if (valid && role == 0) out[aim] = o;
 }
 
@@ -2057,7 +2059,7 @@ __global__ __launch_bounds__(64) void k_small_prepare(int nsys, int nf, int rows
                                                       int k_rays, int k2, int layout_fwd, double lam,
                                                       FirstOrderOut* __restrict__ fo, SurfRec<T>* __restrict__ rec_ext,
                                                       T* __restrict__ poly_ext, DevBundle<T>* __restrict__ bd, T* __restrict__ axes,
-                                                      int* __restrict__ fail_flag)
+                                                      int* __restrict__ fail_flag, int fast)
 {
     __shared__ double s_work[8][kMaxRows + 2];
     __shared__ double s_in[4][kMaxRows];                                 // the system's R, t, n, a columns
@@ -2116,7 +2118,7 @@ __global__ __launch_bounds__(64) void k_small_prepare(int nsys, int nf, int rows
     ORT_PHASE(2);
     const double tlF = ts[rows - 1], tlR = !__builtin_isfinite(ts[0]) ? 0.0 : ts[0];
     const AimIn q = make_aim_in(s, o1, s_in[3][o1.stop - 1], field_f, layout_fwd);
-    const AimOut o = aim_group(q, lane & 3, s_mf, cs, tlF, s_mr, cs ? s_crev : nullptr, tlR, rows - 1, ncoef);
+    const AimOut o = aim_group(q, lane & 3, s_mf, cs, tlF, s_mr, cs ? s_crev : nullptr, tlR, rows - 1, ncoef, true, fast != 0);
     ORT_PHASE(6);
     if (lane == 0) {
         if (!o.ok) *fail_flag = 1;                                       // (a plain store: the flag may live in host memory)
