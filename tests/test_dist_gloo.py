@@ -36,10 +36,10 @@ def test_row_segments_cover_every_slab_in_order():
             assert seen == list(range(nb * k)), (nb, k, world)
 
 
-def _worker_config4(rank, world, port, out_q):
+def _worker_config4(rank, world, port, out_q, nbundles=5):
     """BASELINE config 4's sharding at oracle size: (zoom position x index column) systems x fields x pupil rows,
-    split (a) by bundle with an UNEVEN count (5 bundles over 2 ranks -> the ragged route) and (b) by pupil row
-    (15 rows each: a slab that ends inside a bundle); each rank traces its slab with the CPU oracle, the hits are
+    split (a) by bundle with an UNEVEN count (5 bundles over 2 ranks, 7 over 4 -> the ragged route) and (b) by pupil row
+    (slabs that end inside a bundle); each rank traces its slab with the CPU oracle, the hits are
     reassembled with the package's collectives and compared with the single-process trace."""
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
     dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -50,9 +50,9 @@ def _worker_config4(rank, world, port, out_q):
         eng = OracleEngine()
         k = 6
         systems = [ort.solve(workloads.double_gauss(line, gap), workloads.DG_A, workloads.DG_H, engine=eng)
-                   for gap in (-0.5, 0.5) for line in (0, 1)][:3]
+                   for gap in (-0.5, 0.5) for line in (0, 1)][:(nbundles + 1) // 2]
         pres, bundles, axes = workloads.square_pupil_bundles(api, systems, k, fields=(0.0, 1.0))
-        bundles = bundles[:5]                                    # 5 bundles: not divisible by 2
+        bundles = bundles[:nbundles]                             # 5 bundles: not divisible by 2; 7: not by 4
         full = eng.grid(pres, bundles, axes, k, k, history=False)
         # (a) bundle-level slabs, uneven: allgather_hits detects it and takes the ragged route
         mine = odist.shard(bundles, rank, world)
@@ -85,6 +85,21 @@ def test_two_rank_config4_uneven_bundle_and_row_shards():
         p.join(timeout=180)
         assert p.exitcode == 0
     assert q.get(timeout=5) == (True, True, 5 * 36)
+
+
+def test_four_rank_config4_seven_bundles():
+    """The same at world 4 with 7 bundles: bundle slabs of 2, 2, 2, 1 (ragged route) and row slabs of 11, 11, 10, 10 pupil
+    rows, three of which start or end inside a bundle."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_config4, args=(r, 4, port, q, 7)) for r in range(4)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(timeout=240)
+        assert p.exitcode == 0
+    assert q.get(timeout=5) == (True, True, 7 * 36)
 
 
 def _free_port():
@@ -150,8 +165,56 @@ def test_bench_launches_its_own_ranks():
     assert len(lines) == 1
     d = json.loads(lines[0])
     assert d == {"selftest": True, "world": 2, "rank_sum": 3, "spawned": True}
+    # --gpus 8, the shape of the driver's scaling run: eight ranks rendezvous and agree
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "8", "--selftest-ranks"],
+                       capture_output=True, text=True, timeout=600, env=env)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1 and json.loads(lines[0]) == {"selftest": True, "world": 8, "rank_sum": 36, "spawned": True}
     # a failing rank's return code comes back through the launcher: --gpus 2 under a launcher that started ONE rank
     env1 = dict(env, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0")
     r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--selftest-ranks"],
                        capture_output=True, text=True, timeout=120, env=env1)
     assert r.returncode != 0 and "launcher started 1 rank" in (r.stderr + r.stdout)
+
+
+def test_bench_launcher_deadline_kills_a_hung_rank_tree():
+    """A rank stuck ahead of a collective keeps its peers inside it and the launcher's pipe open: `spawn_ranks` must not wait
+    on that pipe.  With a 12 s deadline and rank 1 asleep, `bench.py --gpus 2` ends by itself with its own exit code (7),
+    says why, and leaves no process of the tree behind."""
+    import subprocess
+    import sys
+    import time
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env.update(ORT_BENCH_SELFTEST_HANG="1", ORT_BENCH_RANKS_TIMEOUT_S="12")
+    t0 = time.time()
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--selftest-ranks"],
+                       capture_output=True, text=True, timeout=120, env=env)
+    assert r.returncode == 7, (r.returncode, r.stderr[-1000:])
+    assert time.time() - t0 < 60 and "did not finish within 12 s" in r.stderr
+    assert not [l for l in r.stdout.splitlines() if l.startswith("{")]
+    time.sleep(1.0)
+    left = subprocess.run(["ps", "-eo", "pid,args"], capture_output=True, text=True).stdout
+    assert "--selftest-ranks" not in left, left
+
+
+def test_exchange_leg_is_surfaced_at_top_level():
+    """The N > 1 line carries copies of the exchange leg's figures (extra.config4_allgather) at its top level — value, ms per
+    step, the all-gather's implementation and rate, the ranks it spanned, verified — and a failed leg reads as failed."""
+    import importlib.util
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(root, "bench.py"))
+    bench = importlib.util.module_from_spec(spec); spec.loader.exec_module(bench)
+    leg = {"value": 1.5e11, "ms_per_step": 16.8, "verified": True, "nranks_seen": 8,
+           "allgather": {"impl": "ort_allgather_hits_packed_f64 (native RCCL)", "alone_GBps_per_rank": 210.0, "alone_ms": 15.9}}
+    res = {}
+    bench.surface_exchange_leg(res, leg)
+    assert res["exchange_value"] == 1.5e11 and res["exchange_ms_per_step"] == 16.8 and res["exchange_nranks_seen"] == 8
+    assert res["allgather_impl"].startswith("ort_allgather") and res["allgather_GBps_per_rank"] == 210.0
+    assert res["exchange_verified"] is True and res["exchange_leg_ok"] is True
+    bad = {}
+    bench.surface_exchange_leg(bad, {"error": "RCCL rendezvous timeout"})
+    assert bad["exchange_verified"] is False and bad["exchange_leg_ok"] is False and "timeout" in bad["exchange_error"]
+    assert bad["exchange_value"] is None
+    assert len({bench.EXIT_EXCHANGE_TIMEOUT, bench.EXIT_EXCHANGE_TIMEOUT_WITH_HEADLINE, bench.EXIT_EXCHANGE_FAILED, bench.EXIT_RANKS_TIMEOUT, 0}) == 5
