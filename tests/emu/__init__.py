@@ -7,7 +7,7 @@ import numpy as np
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(os.path.dirname(HERE))
-LIB = os.path.join(HERE, "libemu_device.so")
+LIB = os.environ.get("ORT_EMU_LIB") or os.path.join(HERE, "libemu_device.so")     # (tests/test_sanitizers.py: an ASan + UBSan build)
 _SRC = [os.path.join(HERE, "emu_device.cpp"), os.path.join(HERE, "stub", "hip", "hip_runtime.h"),
         os.path.join(ROOT, "opticalraytracing.jl_amd", "csrc", "ort_device.hpp")]
 _lib = None
@@ -17,7 +17,7 @@ _dp = C.POINTER(C.c_double)
 def lib():
     global _lib
     if _lib is None:
-        if not os.path.exists(LIB) or any(os.path.getmtime(s) > os.path.getmtime(LIB) for s in _SRC):
+        if not os.environ.get("ORT_EMU_LIB") and (not os.path.exists(LIB) or any(os.path.getmtime(s) > os.path.getmtime(LIB) for s in _SRC)):
             subprocess.run(["g++", "-O2", "-ffp-contract=off", "-std=c++17", "-shared", "-fPIC", "-I" + os.path.join(HERE, "stub"),
                             "-o", LIB, _SRC[0]], check=True)
         _lib = C.CDLL(LIB)
