@@ -551,6 +551,81 @@ __device__ __forceinline__ void surface_step_fast_poly(Ray<T>& r, const SurfRec<
     odd = odd || (r.k2 < Near<T>::root);
 }
 
+// The same row for the TWO rays of a lane in lockstep (A/B build, ORT_POLY_INTERLEAVE): the arm is one dependent chain per ray
+// through five hardware seeds (v_rcp / v_rsq: the longest latencies of the loop), and the compiler, left alone, lays ray 0's
+// whole chain ahead of ray 1's (register pressure decides).  Here the chain is cut right after every seed issue and the
+// stages alternate between the rays — stage k of ray 1 runs while the seed of ray 0's stage k is in flight — with a
+// scheduling barrier between stages so they stay where they are put.  Same operations on the same values as
+// surface_step_fast_poly (finite rows): same bits.
+template <typename T> __device__ __forceinline__ T seed_rcp(T a);
+template <> __device__ __forceinline__ double seed_rcp<double>(double a) { return __builtin_amdgcn_rcp(a); }
+template <> __device__ __forceinline__ float seed_rcp<float>(float a) { return __builtin_amdgcn_rcpf(a); }
+template <typename T> __device__ __forceinline__ T seed_rsq(T a);
+template <> __device__ __forceinline__ double seed_rsq<double>(double a) { return __builtin_amdgcn_rsq(a); }
+template <> __device__ __forceinline__ float seed_rsq<float>(float a) { return __builtin_amdgcn_rsqf(a); }
+__device__ __forceinline__ double refine_rcp(double a, double r0) { return __builtin_fma(r0, __builtin_fma(-a, r0, 1.0), r0); }
+__device__ __forceinline__ float refine_rcp(float, float r0) { return r0; }
+__device__ __forceinline__ double refine_sqrt(double a, double r0)          // sqrt_core from its seed
+{
+    const double g = a * r0, h = 0.5 * r0;
+    return __builtin_fma(g, __builtin_fma(-h, g, 0.5), g);
+}
+__device__ __forceinline__ float refine_sqrt(float a, float) { return __builtin_amdgcn_sqrtf(a); }
+__device__ __forceinline__ double refine_rsqrt(double a, double r0)         // fast_rsqrt from its seed
+{
+    const double t = a * r0, h = 0.5 * r0;
+    return __builtin_fma(h, __builtin_fma(-t, r0, 1.0), r0);
+}
+__device__ __forceinline__ float refine_rsqrt(float, float r0) { return r0; }
+
+template <typename T, int FORM, bool TIR>
+__device__ __forceinline__ void surface_step_fast_poly2(Ray<T> (&r)[2], const SurfRec<T>& s, const T* __restrict__ pl, bool& odd)
+{
+#define ORT_STAGE(...) { _Pragma("unroll") for (int q = 0; q < 2; ++q) { __VA_ARGS__ } __builtin_amdgcn_sched_barrier(0); }
+    T sd[2], u[2], v[2], pv[2], beta[2], r2[2], D[2], den[2], rad[2], tx[2], ty[2], n2[2], gu[2], W[2], sd2[2];
+    ORT_STAGE(sd[q] = seed_rcp<T>(r[q].k2);)
+    ORT_STAGE(
+        const T ik = refine_rcp(r[q].k2, sd[q]);
+        u[q] = r[q].k1 * ik; v[q] = r[q].k0 * ik;                  // :59-60
+        const T tcur = s.t - r[q].sprev;
+        r[q].y = t_fma<T>(u[q], tcur, r[q].y);
+        r[q].x = t_fma<T>(v[q], tcur, r[q].x);
+        pv[q] = poly_value_fast<T, FORM>(pl, r[q].y);
+        beta[q] = t_fma<T>(-r[q].x, v[q], t_fma<T>(-r[q].y, u[q], s.R));
+        r2[q] = t_fma<T>(r[q].x, r[q].x, r[q].y * r[q].y);
+        const T A = t_fma<T>(v[q], v[q], t_fma<T>(u[q], u[q], s.opk));
+        D[q] = t_fma<T>(beta[q], beta[q], -(r2[q] * A));
+        odd = odd || near_zero<T>(D[q], s.dlim);
+        sd[q] = seed_rsq<T>(D[q]);)
+    ORT_STAGE(
+        den[q] = t_fma<T>(s.sgn, refine_sqrt(D[q], sd[q]), beta[q]);
+        sd[q] = seed_rcp<T>(den[q]);)
+    ORT_STAGE(
+        const T sg = t_fma<T>(r2[q], refine_rcp(den[q], sd[q]), pv[q]);
+        r[q].y = t_fma<T>(sg, u[q], r[q].y);
+        r[q].x = t_fma<T>(sg, v[q], r[q].x);
+        r[q].sprev = sg;
+        const T xx = r[q].x * r[q].x, yy = r[q].y * r[q].y;
+        rad[q] = t_fma<T>(-(xx + yy), s.opk, s.R2);
+        odd = odd || (rad[q] < s.dlim);
+        sd[q] = seed_rsq<T>(rad[q]);)
+    ORT_STAGE(
+        const T is = s.sgn * refine_rsqrt(rad[q], sd[q]);
+        poly_tilt_fast<T, FORM>(pl, r[q].x, r[q].y, r[q].x * r[q].x, r[q].y * r[q].y, is, tx[q], ty[q]);
+        n2[q] = t_fma<T>(tx[q], tx[q], t_fma<T>(ty[q], ty[q], T(1)));
+        gu[q] = t_fma<T>(-r[q].k1, ty[q], t_fma<T>(-r[q].k0, tx[q], r[q].k2));
+        W[q] = t_fma<T>(s.eta2 * gu[q], gu[q], s.ome2 * n2[q]);
+        if (TIR) odd = odd || (W[q] < Near<T>::thr * n2[q]);
+        sd[q] = seed_rsq<T>(W[q]); sd2[q] = seed_rcp<T>(n2[q]);)
+    ORT_STAGE(
+        const T cf = t_fma<T>(s.eta, gu[q], -refine_sqrt(W[q], sd[q])) * refine_rcp(n2[q], sd2[q]);
+        r[q].k0 = t_fma<T>(cf, tx[q], s.eta * r[q].k0);
+        r[q].k1 = t_fma<T>(cf, ty[q], s.eta * r[q].k1);
+        r[q].k2 = t_fma<T>(s.eta, r[q].k2, -cf);
+        odd = odd || (r[q].k2 < Near<T>::root);)
+#undef ORT_STAGE
+}
+
 // MATH_FAST, conic row (sphere, flat, conic) in direction-cosine form.  With the ray point
 // P0 = (x, y, z0) relative to the row's vertex and unit direction k (k0 <-> x, k1 <-> y,
 // k2 <-> z), the conic  c (x^2 + y^2 + (1+K) z^2) - 2 z = 0  is met at path length
@@ -829,10 +904,20 @@ __device__ __forceinline__ void surface_step_n(Ray<T> (&r)[N], const SurfRec<T>&
         if (ARMS == ARMS_EVEN) {
             // even aspheres on a curved base (the usual case): four independent arms, nothing else in the loop
             const bool big = cls & CLS_PBIG;
+#if defined(ORT_POLY_INTERLEAVE) && ORT_POLY_INTERLEAVE
+            if constexpr (N == 2) {                              // A/B build: the two rays' seed chains in lockstep
+                if (kind == KIND_POLY && !big && !tir) surface_step_fast_poly2<T, 0, false>(r, s, pl, odd);
+                if (kind == KIND_POLY && !big && tir)  surface_step_fast_poly2<T, 0, true>(r, s, pl, odd);
+                if (kind == KIND_POLY && big && !tir)  surface_step_fast_poly2<T, 1, false>(r, s, pl, odd);
+                if (kind == KIND_POLY && big && tir)   surface_step_fast_poly2<T, 1, true>(r, s, pl, odd);
+            } else
+#endif
+            {
             if (kind == KIND_POLY && !big && !tir) { ORT_ALL_RAYS((surface_step_fast_poly<T, 0, true, false>(r[q], s, pl, odd))) }
             if (kind == KIND_POLY && !big && tir)  { ORT_ALL_RAYS((surface_step_fast_poly<T, 0, true, true>(r[q], s, pl, odd))) }
             if (kind == KIND_POLY && big && !tir)  { ORT_ALL_RAYS((surface_step_fast_poly<T, 1, true, false>(r[q], s, pl, odd))) }
             if (kind == KIND_POLY && big && tir)   { ORT_ALL_RAYS((surface_step_fast_poly<T, 1, true, true>(r[q], s, pl, odd))) }
+            }
         }
         if ((ARMS == ARMS_GENERAL || ARMS == ARMS_POLY) &&
             ((!kF32 && kind == KIND_SPHERE) || kind == KIND_CONIC || (ARMS == ARMS_POLY && kind == KIND_POLY)))
