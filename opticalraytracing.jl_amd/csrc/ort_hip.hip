@@ -195,8 +195,13 @@ int launch_trace(ort_ctx* ctx, const TraceParams<T>& p, int64_t blocks, unsigned
 }
 
 template <typename T, bool GRID>
-int launch_trace_modes(ort_ctx* ctx, const TraceParams<T>& p, int64_t blocks, bool hist, bool summ, unsigned flags)
+int launch_trace_modes(ort_ctx* ctx, const TraceParams<T>& p0, int64_t blocks, bool hist, bool summ, unsigned flags)
 {
+    TraceParams<T> p = p0;
+    if (kSummaryWalks<T> && GRID && summ && !hist) {               // summary only: walk_group tiles of a bundle per workgroup (k_trace, SWALK)
+        p.walk_group = (int)std::min<int64_t>(p.tiles_per_bundle, std::max<int64_t>(1, blocks / kWalkTargetGroups));
+        blocks = (blocks / p.tiles_per_bundle) * ((p.tiles_per_bundle + p.walk_group - 1) / p.walk_group);
+    }
     if (hist && summ)  return launch_trace<T, GRID, true, true, FT_NONE>(ctx, p, blocks, flags);
     if (hist && !summ) return launch_trace<T, GRID, true, false, FT_NONE>(ctx, p, blocks, flags);
     if (!hist && summ) return launch_trace<T, GRID, false, true, FT_NONE>(ctx, p, blocks, flags);

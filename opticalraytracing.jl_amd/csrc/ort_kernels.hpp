@@ -225,6 +225,10 @@ enum { FT_NONE = 0, FT_FULL = 1, FT_STATS = 2, FT_LOOKBACK = 3, FT_WALK = 4 };
 #define ORT_WALK_TILES 8     // tiles per span of the FT_WALK route
 #endif
 constexpr int kWalkTiles = ORT_WALK_TILES;
+#ifndef ORT_SUMM_WALK_F64
+#define ORT_SUMM_WALK_F64 0   // A/B build: the Float64 summary kernels walk tiles as the Float32 ones do
+#endif
+template <typename T> constexpr bool kSummaryWalks = sizeof(T) == 4 || ORT_SUMM_WALK_F64;
 constexpr int kStatusVignetted = 1 << 17, kStatusVigShift = 20;
 // ------------------------------------------------------------------------------------
 // ARMS: the row classes this build carries (surface_step_n): the batch's highest row decides (ort_system::arms).
@@ -241,6 +245,10 @@ void k_trace(TraceParams<T> p)   // both outputs, look-back epilogue, Float64 ru
     static_assert(RPT == 1 || RPT == 2, "one or two rays per lane");
     constexpr bool POLY = ARMS >= ARMS_EVEN;
     constexpr bool WALK = FT == FT_WALK;
+    // Float32 summary-mode grid launches walk walk_group consecutive tiles of a bundle per workgroup too (a tile's output does
+    // not depend on it): BASELINE config 5's hit payload 12.5 -> 10.5 ms.  Float64: measured, no gain (the per-tile trace is
+    // twice as long, the workgroup's start-up hides behind it; profiles/r04_ab_summary_walk.log)
+    constexpr bool SWALK = kSummaryWalks<T> && GRID && SUMM && !HIST && FT == FT_NONE && RPT == kRPT;
     static_assert(!WALK || (GRID && !HIST && !SUMM && RPT == kRPT), "FT_WALK: grid source, no other output");
     __shared__ SurfRec<T> s_rec[kMaxRows];
     __shared__ __attribute__((aligned(16))) T s_poly[POLY ? kMaxRows * kPolyLds : 1];
@@ -290,6 +298,11 @@ void k_trace(TraceParams<T> p)   // both outputs, look-back epilogue, Float64 ru
             tile = (bid - b * groups) * p.walk_group * kWalkTiles;
             walk_n = min(p.walk_group * kWalkTiles, p.tiles_per_bundle - tile);
             walk_tile = tile;
+        } else if (SWALK) {
+            const int groups = (p.tiles_per_bundle + p.walk_group - 1) / p.walk_group;      // workgroups per bundle
+            b = bid / groups;
+            tile = (bid - b * groups) * p.walk_group;
+            walk_n = min(p.walk_group, p.tiles_per_bundle - tile);
         } else {
             b = bid / p.tiles_per_bundle;
             tile = bid - b * p.tiles_per_bundle;
@@ -515,6 +528,7 @@ void k_trace(TraceParams<T> p)   // both outputs, look-back epilogue, Float64 ru
                     }
                 }
             }
+            if (SWALK) { tile_base += (unsigned)kTile; j0 += kTile; gbase += kTile; }      // the next tile
         }
 
         if (WALK) {

@@ -22,7 +22,7 @@ import numpy as np
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("workload", choices=["config1", "config2", "config3", "config5"])
+    ap.add_argument("workload", choices=["config1", "config2", "config3", "config4", "config5"])
     ap.add_argument("--dtype", default="f32", choices=["f32", "f64"], help="config5: arithmetic of the pupil trace")
     ap.add_argument("--instances", type=int, default=10000, help="config5: perturbed instances")
     ap.add_argument("--retrace", action="store_true", help="print the retrace counters of an -DORT_COUNT_RETRACE build")
@@ -71,6 +71,19 @@ def main():
             res.update(rms=r[1][0]["rms"], count=r[1][0]["count"])
         else:
             res.update(rms=float(r["rms"][0, 0]), count=int(r["count"][0, 0]))
+        print(json.dumps(res), flush=True)
+        return
+
+    if a.workload == "config4":
+        # BASELINE config 4 on one GPU: 32 zoom positions x 5 index columns x 5 fields x 512^2 pupil, summary trace into the
+        # packed [2][n] hit slab
+        k4 = a.pupil or 512
+        mats = np.array([workloads.double_gauss(line, -1.5 + 3.0 * z / 31) for z in range(32) for line in (0, 1, 2, 1, 2)])
+        plan = batch.ImageHitsPlan(mats, workloads.DG_A, workloads.DG_H, (0.0, 0.5, 0.7, 0.85, 1.0), k4, engine=eng)
+        hits = plan.new_hits()
+        ms = timed(lambda: plan.trace(hits))
+        res.update(rays=plan.n_rays, intersections=plan.n_rays * 12, ms=ms, intersections_per_s=plan.n_rays * 12 / (ms * 1e-3),
+                   checksum=float(torch.nan_to_num(hits).sum().item()))
         print(json.dumps(res), flush=True)
         return
 

@@ -2040,3 +2040,46 @@ def test_four_host_threads_four_contexts():
         assert rc == -1 and f"system index {1000 + i} " in msg, (i, rc, msg)
     cm.report(f"thread safety: {nthreads} host threads x {iters} rounds x 4 calls (full_trace default / look-back / statistics-only, "
               f"spot_batch), own context each, all bit-identical to the serial run; ort_last_error per thread")
+
+
+def test_f32_summary_walk_is_launch_shape_only():
+    """Float32 summary-mode grid launches let a workgroup walk several consecutive tiles of a bundle (k_trace, SWALK: the
+    table staged once per workgroup).  What a tile writes must not depend on it: 40 bundles x 716 x 716 rays (1,002 tiles each, a
+    ragged last tile; 40,080 tiles -> two tiles per workgroup) in summary mode equal, bit for bit, the same launch with the
+    history also requested (one tile per workgroup), in both policies."""
+    import ctypes as C
+    import torch
+    from opticalraytracing_jl_amd import _capi
+    dev = torch.device("cuda:0")
+    k, nb = 716, 40
+    M = _ext(cm.double_gauss(), 57.8)
+    pres = Prescription.from_matrix(M)
+    rng = np.random.default_rng(9)
+    axes = np.concatenate([np.concatenate([np.linspace(-13 - b * 0.01, 13, k), np.linspace(-12, 12 + b * 0.01, k)]) for b in range(nb)]).astype(np.float32)
+    bundles = [dict(system=0, stop=6, U=float(rng.uniform(-0.1, 0.1)), V=float(rng.uniform(-0.05, 0.05)), a_stop=10.0,
+                    yaxis_off=2 * k * b, xaxis_off=2 * k * b + k) for b in range(nb)]
+    N, S = nb * k * k, pres.rows - 1
+    d_axes = torch.from_numpy(axes).to(dev)
+    for policy in ("ieee", "fast"):
+        eng = _engine(policy)
+        sysd = eng.system(pres)
+        res = []
+        for hist in (False, True):
+            bufs = [torch.full((N,), float("nan"), dtype=torch.float32, device=dev) for _ in range(4)]
+            st = torch.zeros(N, dtype=torch.int32, device=dev)
+            out = _capi.ort_grid_out_f32()
+            out.xf, out.yf, out.xs, out.ys = (b.data_ptr() for b in bufs)
+            out.status = st.data_ptr()
+            if hist:
+                xv = torch.empty((S, N), dtype=torch.float32, device=dev); yv = torch.empty_like(xv)
+                out.xv, out.yv, out.ld = xv.data_ptr(), yv.data_ptr(), N
+            _capi.check(eng.ctx.lib.ort_trace_grid_f32(eng.ctx.h, sysd.h, nb, _capi.make_bundles(bundles), d_axes.data_ptr(), axes.size, k, k,
+                                                       C.byref(out), eng.base_flags | _capi.ORT_DEVICE_PTRS))
+            eng.ctx.synchronize()
+            res.append([b.cpu().numpy() for b in bufs] + [st.cpu().numpy()])
+            if hist:
+                assert np.array_equal(xv[-1].cpu().numpy(), res[-1][0], equal_nan=True)
+                del xv, yv
+        for a, b in zip(*res):
+            assert np.array_equal(a, b, equal_nan=True), policy
+        assert np.isfinite(res[0][0]).mean() > 0.5 and (res[0][4] & (1 << 16)).any()
