@@ -1848,11 +1848,13 @@ def test_wavegrad_device_and_host(hip_engine, oracle_engine):
     rho = torch.zeros_like(ex); th = torch.zeros_like(ex)
     cnt = torch.empty(nb, dtype=torch.int64, device=dev); rms = torch.empty(nb, dtype=torch.float64, device=dev)
     sysd = hip_engine.system(pres)
+    torch.cuda.synchronize(dev)                                   # torch's fills (its stream) before the engine's launches (its own)
     _capi.check(hip_engine.ctx.lib.ort_full_trace_f64(hip_engine.ctx.h, sysd.h, nb, _capi.make_bundles(bundles), d_axes.data_ptr(), axes.size,
                                                       k, k, ex.data_ptr(), ey.data_ptr(), rho.data_ptr(), th.data_ptr(), cnt.data_ptr(),
                                                       rms.data_ptr(), _capi.ORT_DEVICE_PTRS))
     nu = torch.linspace(-0.21, -0.17, nb, dtype=torch.float64, device=dev)
     lam = 587.5618e-6
+    hip_engine.ctx.synchronize(); torch.cuda.synchronize(dev)     # ... and the other way round
     gx, gy = hip_engine.wavegrad(ex, ey, cnt, nu, lam)
     hip_engine.ctx.synchronize()
     c = cnt.cpu().numpy()
@@ -1894,6 +1896,7 @@ def test_lookback_fault_is_reported(oracle_engine):
     vec = [torch.zeros((nb, cap), dtype=torch.float64, device=dev) for _ in range(4)]
     cnt = torch.zeros(nb, dtype=torch.int64, device=dev); rms = torch.zeros(nb, dtype=torch.float64, device=dev)
     sysd = eng.system(pres)
+    torch.cuda.synchronize(dev)                                   # torch's fills (its stream) before the engine's launches (its own)
     _capi.check(lib.ort_full_trace_f64(h, sysd.h, nb, _capi.make_bundles(bundles), d_axes.data_ptr(), axes.size, 40, 40,
                                        *(v.data_ptr() for v in vec), cnt.data_ptr(), rms.data_ptr(),
                                        _capi.ORT_DEVICE_PTRS | _capi.ORT_FT_LOOKBACK))
@@ -2073,6 +2076,7 @@ def test_f32_summary_walk_is_launch_shape_only():
             if hist:
                 xv = torch.empty((S, N), dtype=torch.float32, device=dev); yv = torch.empty_like(xv)
                 out.xv, out.yv, out.ld = xv.data_ptr(), yv.data_ptr(), N
+            torch.cuda.synchronize(dev)                           # the fills above ran on torch's stream, the trace runs on the engine's
             _capi.check(eng.ctx.lib.ort_trace_grid_f32(eng.ctx.h, sysd.h, nb, _capi.make_bundles(bundles), d_axes.data_ptr(), axes.size, k, k,
                                                        C.byref(out), eng.base_flags | _capi.ORT_DEVICE_PTRS))
             eng.ctx.synchronize()
@@ -2083,3 +2087,47 @@ def test_f32_summary_walk_is_launch_shape_only():
         for a, b in zip(*res):
             assert np.array_equal(a, b, equal_nan=True), policy
         assert np.isfinite(res[0][0]).mean() > 0.5 and (res[0][4] & (1 << 16)).any()
+
+
+@pytest.mark.parametrize("rows,units,pad", [(40, 5, 3), (64, 8, 6)])
+def test_deep_prescriptions_other_kernels(hip_engine, oracle_engine, rows, units, pad):
+    """The kernels beside the skew trace on prescriptions of 40 and 64 rows (ORT_MAX_ROWS; tables of up to 63 loop iterations
+    in LDS): meridional trace (plain and Layout dispatch), paraxial y-nu with clip and the ABCD product (bit-exact), the
+    batched first-order solve + Seidel sums against the C oracle."""
+    from opticalraytracing_jl_amd import _capi, batch
+    from oracle import cpu
+    rng = np.random.default_rng(100 + rows)
+    for variant in ("sph", "mixed"):
+        M, coef = _cooke_relay(units, variant, pad)
+        asph = variant != "sph"
+        pres = Prescription(M[:, 0], M[:, 1], M[:, 2], M[:, 3] if asph else None, coef[None] if asph else None)
+        y = rng.uniform(-5, 5, 400); U = rng.uniform(-0.01, 0.01, 400)
+        g = hip_engine.meridional(pres, y, U, layout_mode=asph)
+        o = oracle_engine.meridional(pres, y, U, layout_mode=asph)
+        assert (hip_engine.last_domain_error is None) == (oracle_engine.last_domain_error is None)
+        for a, b in zip(g, o):
+            assert np.array_equal(np.isnan(a), np.isnan(b)), (rows, variant)
+            assert cm.rel_err(a, b, 1.0).max() <= TOL, (rows, variant, cm.rel_err(a, b, 1.0).max())
+        assert np.isfinite(o[0][-1]).mean() > 0.9
+    M, _ = _cooke_relay(units, "sph", pad)
+    L = ort.Lens(M[:, :3].copy())
+    k = L.M.shape[0]
+    assert k >= rows - 2
+    yy = rng.uniform(-5, 5, 300); ww = rng.uniform(-0.01, 0.01, 300)
+    a_ap = rng.uniform(4.0, 12.0, k)
+    for clip in (False, True):
+        gp = hip_engine.paraxial(L.M[:, 0], L.M[:, 1], yy, ww, a_ap, clip)
+        op = oracle_engine.paraxial(L.M[:, 0], L.M[:, 1], yy, ww, a_ap, clip)
+        assert np.array_equal(gp[0], op[0], equal_nan=True) and np.array_equal(gp[1], op[1], equal_nan=True)
+    assert np.array_equal(hip_engine.abcd(L.M[:, 0], L.M[:, 1]), oracle_engine.abcd(L.M[:, 0], L.M[:, 1]))
+    # first-order solve + Seidel sums of the deep system (semi-diameters: the Cooke triplet's, unit after unit)
+    Ms = M[:-1, :3].copy()                                       # without the image row: ends in image space (t[end] = 0)
+    Ms[-1, 1] = 0.0
+    nrow = Ms.shape[0]
+    a = np.resize(np.concatenate([cm.COOKE_A, cm.COOKE_A[::-1]]), nrow - 1).astype(np.float64)
+    a[np.isinf(Ms[1:, 0]) & (a > 12.0)] = 12.0
+    fo = batch.first_order_arrays(hip_engine, Ms[None], a, cm.COOKE_H)
+    ref = cpu.solve_aberrations(Ms, a, cm.COOKE_H)
+    for key in ("f", "EBFD", "W040", "W131", "W222", "W311", "H"):     # (8 units: the chain ends collimated, f = -inf on both sides)
+        assert fo[key][0] == ref[key] or abs(fo[key][0] - ref[key]) <= 1e-12 * max(1.0, abs(ref[key])), (key, fo[key][0], ref[key])
+    assert int(fo["stop"][0]) == int(ref["stop"])
