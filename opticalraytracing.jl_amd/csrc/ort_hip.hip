@@ -491,8 +491,12 @@ int run_full_trace(ort_ctx* ctx, TraceParams<T>& p, int nb, T* ex, T* ey, T* rho
             rc = launch_trace<T, true, false, false, FT_WALK>(ctx, p, (int64_t)nb * groups, flags);
         }
         if (rc) return rc;
-        hipLaunchKernelGGL(k_ft_stats_reduce, dim3((unsigned)nb), dim3(kBlock), 0, ctx->stream,
-                           p.tile_cnt, p.tile_sx, p.tile_sy, p.tile_m2x, p.tile_m2y, p.tile_rmax, parts, dcount, drms);
+        if (parts <= 64 && !(flags & ORT_NO_SMALL_PATH))           // one wave per bundle: the same merges in the same order (bit-identical)
+            hipLaunchKernelGGL(k_ft_stats_reduce_wave, dim3((unsigned)((nb + kBlock / 64 - 1) / (kBlock / 64))), dim3(kBlock), 0, ctx->stream,
+                               p.tile_cnt, p.tile_sx, p.tile_sy, p.tile_m2x, p.tile_m2y, p.tile_rmax, parts, nb, dcount, drms);
+        else
+            hipLaunchKernelGGL(k_ft_stats_reduce, dim3((unsigned)nb), dim3(kBlock), 0, ctx->stream,
+                               p.tile_cnt, p.tile_sx, p.tile_sy, p.tile_m2x, p.tile_m2y, p.tile_rmax, parts, dcount, drms);
         HIP_TRY(hipGetLastError());
         if (!devp) {
             rc = from_device<int64_t>(ctx, count, dcount, (size_t)nb); if (rc) return rc;

@@ -832,6 +832,34 @@ __global__ __launch_bounds__(kBlock) void k_ft_stats_reduce(const int32_t* __res
     }
 }
 
+// The same merge for bundles of at most 64 partials (BASELINE config 5: 2 x 10^4 bundles of 32): ONE WAVE per bundle, the
+// tree of k_ft_stats_reduce — partial l pairs with l + 1, then l + 2, l + 4, ... in index order; an empty slot is the identity of
+// chan_merge — walked with shuffles instead of LDS and barriers: the same merges in the same order, the same bits, a fifth of
+// the time (78 -> 16 us there).
+__global__ __launch_bounds__(kBlock) void k_ft_stats_reduce_wave(const int32_t* __restrict__ tile_cnt, const double* __restrict__ tile_mx,
+                                                                 const double* __restrict__ tile_my, const double* __restrict__ tile_m2x,
+                                                                 const double* __restrict__ tile_m2y, const double* __restrict__ tile_rmax,
+                                                                 int parts, int nb, int64_t* __restrict__ count, double* __restrict__ rms)
+{
+    const int lane = threadIdx.x & 63;
+    const int b = blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6);
+    if (b >= nb) return;                                           // wave-uniform
+    const int64_t base = (int64_t)b * parts;
+    Moments m = {0.0, 0.0, 0.0, 0.0, 0.0, -1.0};
+    if (lane < parts)
+        m = Moments{(double)tile_cnt[base + lane], tile_mx[base + lane], tile_my[base + lane], tile_m2x[base + lane], tile_m2y[base + lane],
+                    tile_rmax[base + lane]};
+    for (int off = 1; off < 64; off <<= 1) {
+        const Moments o = {__shfl_down(m.n, off), __shfl_down(m.mx, off), __shfl_down(m.my, off), __shfl_down(m.qx, off),
+                           __shfl_down(m.qy, off), __shfl_down(m.rmax, off)};
+        if ((lane & (2 * off - 1)) == 0) m = chan_merge(m, o);    // (lanes past 64 - off read their own value: never merged)
+    }
+    if (lane == 0) {
+        count[b] = 2 * (int64_t)m.n;
+        rms[b] = m.n > 0.0 ? sqrt(((m.qx + m.n * m.mx * m.mx) + m.qy) / m.n) : __builtin_nan("");
+    }
+}
+
 // ------------------------------------------------------------------------------------
 // full_trace, stage B: per bundle, exclusive scan of the tile survivor counts (tile_off, FT_FULL route; may be
 // null) and the bundle aggregates (count, centroid, max radius).  One workgroup per bundle; fixed shapes:
