@@ -5,7 +5,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 F = os.path.join(ROOT, "gpurun_out", "final")
 P = os.path.join(ROOT, "profiles")
 os.makedirs(P, exist_ok=True)
-tag = os.environ.get("ORT_ROUND", "r03")
+tag = os.environ.get("ORT_ROUND", "r04")
 
 
 def counters(sub):

@@ -20,10 +20,10 @@ for route in place lookback; do
   timeout -k 10 300 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/ft_write_$route -- python3 /root/repo/bench.py $Q --mode full_trace $extra > $OUT/ft_write_$route.log 2>&1 || exit 1
 done
 timeout -k 10 300 rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_BUSY_CU_CYCLES SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY --kernel-trace --output-format csv -d $OUT/sq_both -- python3 /root/repo/bench.py $Q --policy fast > $OUT/sq_both.log 2>&1 || exit 1
-ORT_ROUND=${ORT_ROUND:-r03} python3 /root/repo/scripts/collect_final.py
+ORT_ROUND=${ORT_ROUND:-r04} python3 /root/repo/scripts/collect_final.py
 # the rest of the round's judged artefacts, same box: config 3 / config 1 kernel statistics, the plain-C caller's wall time, the
 # counter + clock pass of the config-3 trace kernel, the 2-rank rehearsal of `bench.py --gpus 2` (gloo; both ranks on this GPU)
-T=${ORT_ROUND:-r03}
+T=${ORT_ROUND:-r04}
 cd /root/repo
 bash scripts/config3_kernels.sh ${T}_c3k > /dev/null 2>&1; cp gpurun_out/${T}_c3k.log profiles/${T}_config3_kernels.log 2>/dev/null
 bash scripts/config1_kernels.sh > gpurun_out/${T}_c1k.log 2>&1; cp gpurun_out/${T}_c1k.log profiles/${T}_config1_kernels.log
@@ -31,5 +31,12 @@ bash scripts/config1_kernels.sh > gpurun_out/${T}_c1k.log 2>&1; cp gpurun_out/${
 bash scripts/clock_config3.sh ${T}_clk > gpurun_out/${T}_clk.log 2>&1
 cd /root/repo
 ORT_BENCH_BACKEND=gloo timeout -k 10 600 python bench.py --gpus 2 --steps 5 --warmup 2 > gpurun_out/${T}_n2_gloo.json 2> gpurun_out/${T}_n2_gloo.err || echo "n2 rehearsal rc=$?"
+# round 4: counter + clock pass of the Float32 kernels of config 5 (statistics kernel and summary kernel), the kernel statistics of
+# one ort_spot_batch_f32 call, the GPU suite with its parity report, one parity soak of the final build
+bash scripts/clock_config5.sh ${T}_clk5 > gpurun_out/${T}_clk5.log 2>&1; cp gpurun_out/${T}_clk5/summary.json profiles/${T}_sq_config5_final.json 2>/dev/null
+(cd /tmp && export TMPDIR=/tmp && rocprofv3 --kernel-trace --stats --output-format csv -d /root/repo/gpurun_out/${T}_c5_kstats -- python3 /root/repo/scripts/run_workload.py config5 --mode stats --reps 6 > /root/repo/gpurun_out/${T}_c5_kstats.log 2>&1)
+cp $(ls -t gpurun_out/${T}_c5_kstats/*/*kernel_stats.csv | head -1) profiles/${T}_config5_kernel_stats.csv 2>/dev/null
+python -m pytest tests -m gpu -q > gpurun_out/${T}_gpu_suite.log 2>&1; cp gpurun_out/${T}_gpu_suite.log profiles/${T}_gpu_suite_parity_report.log
+timeout -k 10 600 python scripts/soak_parity.py 900 4242 > gpurun_out/${T}_soak_parity_seed4242.log 2>&1; cp gpurun_out/${T}_soak_parity_seed4242.log profiles/
 # the exchange leg alone with the native RCCL communicator of the C ABI (ort_comm_*), one rank: the code path the N > 1 line takes
 timeout -k 10 300 python bench.py --workload config4 --steps 5 --warmup 2 > gpurun_out/${T}_config4_world1_native_rccl.json 2> gpurun_out/${T}_config4_world1.err || echo "config4 world1 rc=$?"
