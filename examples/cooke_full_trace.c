@@ -16,8 +16,11 @@
 
 static int cmp_double(const void *a, const void *b) { return (*(const double *)a > *(const double *)b) - (*(const double *)a < *(const double *)b); }
 
-/* `cooke_full_trace --time [H]`: wall time of the reference's own call, full_trace(system, H, 64) (test/runtests.jl:364-372 shape:
- * one system, one field, 64 x 32 half pupil), through the C ABI — error vectors back in host memory — 300 times. */
+/* `cooke_full_trace --time [H] [fast]`: wall time of the reference's own call, full_trace(system, H, 64) (test/runtests.jl:364-372
+ * shape: one system, one field, 64 x 32 half pupil), through the C ABI — error vectors back in host memory — 300 times, in the
+ * default arithmetic policy (the reference's operation sequence, aiming loops through the meridional trig sequence) or, with
+ * `fast`, under ORT_FAST_MATH (direction-cosine forms; the aiming loops trace this plain prescription without trigonometric
+ * calls: their serial latency is most of a call this small). */
 int main(int argc, char **argv)
 {
     /* surfaces = [R t n] (test/runtests.jl:19-29), clear semi-diameters a (:31-33), image height h' (:35) */
@@ -45,21 +48,22 @@ int main(int argc, char **argv)
     }
     if (argc > 1 && strcmp(argv[1], "--time") == 0) {
         const double H = argc > 2 ? atof(argv[2]) : 1.0;
+        const unsigned fl = (argc > 3 && strcmp(argv[3], "fast") == 0) ? ORT_FAST_MATH : 0u;
         enum { REPS = 300 };
         static double us[REPS];
         for (int full = 1; full >= 0; --full) {
             for (int i = -20; i < REPS; ++i) {
                 struct timespec t0, t1;
                 clock_gettime(CLOCK_MONOTONIC, &t0);
-                rc = full ? ort_full_trace_batch_f64(ctx, 1, ROWS, R, t, n, a, &hprime, 1, &H, K, &fo, ex, ey, rho, theta, count, rms, 0)
-                          : ort_spot_batch_f64(ctx, 1, ROWS, R, t, n, a, &hprime, 1, &H, K, &fo, count, rms, 0);
+                rc = full ? ort_full_trace_batch_f64(ctx, 1, ROWS, R, t, n, a, &hprime, 1, &H, K, &fo, ex, ey, rho, theta, count, rms, fl)
+                          : ort_spot_batch_f64(ctx, 1, ROWS, R, t, n, a, &hprime, 1, &H, K, &fo, count, rms, fl);
                 clock_gettime(CLOCK_MONOTONIC, &t1);
                 if (rc != ORT_OK) { fprintf(stderr, "timed call: %s\n", ort_last_error()); return 3; }
                 if (i >= 0) us[i] = (t1.tv_sec - t0.tv_sec) * 1e6 + (t1.tv_nsec - t0.tv_nsec) * 1e-3;
             }
             qsort(us, REPS, sizeof(double), cmp_double);
-            printf("{\"call\": \"%s\", \"H\": %.2f, \"rays\": %lld, \"rms\": %.9f, \"wall_us_median\": %.1f, \"wall_us_min\": %.1f, \"wall_us_p90\": %.1f}\n",
-                   full ? "ort_full_trace_batch_f64 (vectors back)" : "ort_spot_batch_f64 (count, RMS)", H, (long long)count[0], rms[0],
+            printf("{\"policy\": \"%s\", \"call\": \"%s\", \"H\": %.2f, \"rays\": %lld, \"rms\": %.9f, \"wall_us_median\": %.1f, \"wall_us_min\": %.1f, \"wall_us_p90\": %.1f}\n",
+                   fl ? "fast" : "reference sequence (default)", full ? "ort_full_trace_batch_f64 (vectors back)" : "ort_spot_batch_f64 (count, RMS)", H, (long long)count[0], rms[0],
                    us[REPS / 2], us[0], us[REPS * 9 / 10]);
         }
     }

@@ -27,7 +27,8 @@ T=${ORT_ROUND:-r04}
 cd /root/repo
 bash scripts/config3_kernels.sh ${T}_c3k > /dev/null 2>&1; cp gpurun_out/${T}_c3k.log profiles/${T}_config3_kernels.log 2>/dev/null
 bash scripts/config1_kernels.sh > gpurun_out/${T}_c1k.log 2>&1; cp gpurun_out/${T}_c1k.log profiles/${T}_config1_kernels.log
-[ -x build/cooke_full_trace ] && (./build/cooke_full_trace --time 0.0; ./build/cooke_full_trace --time 1.0) > gpurun_out/${T}_c1_cabi.log 2>&1
+gcc -O2 -Wall -Iinclude examples/cooke_full_trace.c -o build/cooke_full_trace -Lopticalraytracing.jl_amd/csrc -lort_hip -Wl,-rpath,$PWD/opticalraytracing.jl_amd/csrc -Wl,-rpath,/opt/rocm/lib -Wl,-rpath-link,/opt/rocm/lib -lm
+[ -x build/cooke_full_trace ] && (./build/cooke_full_trace --time 0.0; ./build/cooke_full_trace --time 1.0; ./build/cooke_full_trace --time 0.0 fast; ./build/cooke_full_trace --time 1.0 fast) > gpurun_out/${T}_c1_cabi.log 2>&1
 bash scripts/clock_config3.sh ${T}_clk > gpurun_out/${T}_clk.log 2>&1
 cd /root/repo
 ORT_BENCH_BACKEND=gloo timeout -k 10 600 python bench.py --gpus 2 --steps 5 --warmup 2 > gpurun_out/${T}_n2_gloo.json 2> gpurun_out/${T}_n2_gloo.err || echo "n2 rehearsal rc=$?"
