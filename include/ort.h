@@ -204,7 +204,10 @@ int ort_make_axes_f64(ort_ctx *ctx, int nb, int ny, int nx, const double *ends, 
  * ex, ey, rho, theta : [nb][2*ny*nx] (bundle b starts at b*2*ny*nx; count[b] entries valid)
  * count : [nb] = 2*survivors;  rms : [nb].
  * ex = ey = rho = theta = NULL: spot statistics only (count, rms) — nothing but 16 B per bundle
- * leaves the device (the all-reduce-of-moments alternative to gathering hits).      */
+ * leaves the device (the all-reduce-of-moments alternative to gathering hits).  The RMS
+ * there is the reference's sigma (:169-173) from merged (n, mean, M2) partials, within 1e-12 relative
+ * of its two-pass form; a bundle's (count, rms) depend on the bundle alone — never on what else is in
+ * the call, nor on how the launch is cut into workgroups.                                         */
 int ort_full_trace_f64(ort_ctx *ctx, const ort_system *sys, int nb, const ort_bundle *bundles,
                        const double *axes, int64_t axes_len, int ny, int nx,
                        double *ex, double *ey, double *rho, double *theta,
