@@ -456,8 +456,8 @@ int run_full_trace(ort_ctx* ctx, TraceParams<T>& p, int nb, T* ex, T* ey, T* rho
     const bool small_f64 = sizeof(T) == 8 && ((p.tiles_per_bundle <= kSmallTiles && tiles <= kSmallGridTiles && !(flags & ORT_NO_SMALL_PATH)) ||
                                               (ORT_POLY_RPT1 && p.arms >= ARMS_EVEN));
     int rc;
-    // per-tile aggregates — or, on the statistics-only walk route, four partials per span of kWalkTiles tiles
-    const size_t npart = std::max<size_t>((size_t)tiles, (size_t)nb * (size_t)((p.tiles_per_bundle + kWalkTiles - 1) / kWalkTiles) * (kBlock / 64));
+    // per-tile aggregates — or, on the statistics-only walk route, four partials per span (of one tile at the least)
+    const size_t npart = (size_t)tiles * (stats_only ? kBlock / 64 : 1);
     rc = dev_out<int32_t>(ctx, SL_TCNT, npart, &p.tile_cnt); if (rc) return rc;
     rc = dev_out<double>(ctx, SL_TSX, npart, &p.tile_sx); if (rc) return rc;
     rc = dev_out<double>(ctx, SL_TSY, npart, &p.tile_sy); if (rc) return rc;
@@ -471,25 +471,20 @@ int run_full_trace(ort_ctx* ctx, TraceParams<T>& p, int nb, T* ex, T* ey, T* rho
         // one pass: trace + stop filter + per-tile (n, mean, M2), merged per bundle — no ray-sized buffer at all
         rc = dev_out<double>(ctx, SL_TOFF, npart, &p.tile_m2x); if (rc) return rc;
         rc = dev_out<double>(ctx, SL_TSQ, npart, &p.tile_m2y); if (rc) return rc;
-        // Which kernel is a function of the BUNDLE's shape and of T alone, so a bundle's statistics never depend on what else is
-        // in the launch: Float64 bundles of a few tiles (the reference's own call) take the per-tile epilogue, whose one-ray-per-
-        // lane form (a handful of waves, each alone on its SIMD: half the instruction stream) is bit-identical to the general
-        // one; everything else walks spans of kWalkTiles tiles per workgroup and reduces once per span (k_trace, FT_WALK)
-        int parts = p.tiles_per_bundle;                             // (n, mean, M2) partials per bundle
-        if (sizeof(T) == 8 && p.tiles_per_bundle <= kSmallTiles) {
-            if (small_f64) rc = launch_trace<T, true, false, false, FT_STATS, sizeof(T) == 8 ? 1 : kRPT>(ctx, p, tiles, flags);
-            else rc = launch_trace<T, true, false, false, FT_STATS>(ctx, p, tiles, flags);
-        } else {
-            // spans of kWalkTiles tiles, four partials (one per wave) each; a workgroup walks walk_group consecutive spans of
-            // its bundle: as many as leave the launch ~8 workgroups per resident slot (the partials, and so the results, do not
-            // depend on it)
-            p.walk_spans = (p.tiles_per_bundle + kWalkTiles - 1) / kWalkTiles;
-            parts = p.walk_spans * (kBlock / 64);
-            const int64_t spans = (int64_t)nb * p.walk_spans;
-            p.walk_group = (int)std::min<int64_t>(p.walk_spans, std::max<int64_t>(1, spans / kWalkTargetGroups));
-            const int groups = (p.walk_spans + p.walk_group - 1) / p.walk_group;
-            rc = launch_trace<T, true, false, false, FT_WALK>(ctx, p, (int64_t)nb * groups, flags);
-        }
+        // ONE route (k_trace, FT_WALK): a workgroup walks spans of tiles of its bundle, four partials (one per wave) per span.
+        // The span length is a function of the BUNDLE's shape alone — one tile for bundles of a few tiles (the reference's
+        // own call), kWalkTiles beyond — so a bundle's statistics never depend on what else is in the launch; how many
+        // consecutive spans a workgroup walks (walk_group) is a launch-shape choice that no result depends on: as many as
+        // leave the launch ~8 workgroups per resident slot, down to ONE tile per workgroup for a call of a few tiles
+        // (latency: 4 workgroups for the reference's own 2,048 rays)
+        const int span = p.tiles_per_bundle <= kSmallTiles ? 1 : kWalkTiles;
+        p.walk_spans = (p.tiles_per_bundle + span - 1) / span;
+        const int parts = p.walk_spans * (kBlock / 64);             // (n, mean, M2) partials per bundle
+        const int64_t spans = (int64_t)nb * p.walk_spans;
+        p.walk_group = (int)std::min<int64_t>(p.walk_spans, std::max<int64_t>(1, spans / kWalkTargetGroups));
+        const int groups = (p.walk_spans + p.walk_group - 1) / p.walk_group;
+        rc = span == 1 ? launch_trace<T, true, false, false, FT_WALK1>(ctx, p, (int64_t)nb * groups, flags)
+                       : launch_trace<T, true, false, false, FT_WALK>(ctx, p, (int64_t)nb * groups, flags);
         if (rc) return rc;
         if (parts <= 64 && !(flags & ORT_NO_SMALL_PATH))           // one wave per bundle: the same merges in the same order (bit-identical)
             hipLaunchKernelGGL(k_ft_stats_reduce_wave, dim3((unsigned)((nb + kBlock / 64 - 1) / (kBlock / 64))), dim3(kBlock), 0, ctx->stream,

@@ -117,8 +117,8 @@ struct TraceParams {
     unsigned ft_epoch;                  // launch number: words of earlier launches read as "not yet written"
     int* ft_err;                        // look-back fault word: bit 0 = a wait hit its poll cap, bit 1 = a ticket outside the grid
     int32_t* tile_cnt; double* tile_sx; double* tile_sy; double* tile_rmax;
-    double* tile_m2x; double* tile_m2y;     // FT_STATS: sums of squared deviations about the tile means
-    int walk_spans;                         // FT_WALK: spans (of kWalkTiles consecutive tiles) per bundle
+    double* tile_m2x; double* tile_m2y;     // FT_WALK: a partial's sums of squared deviations about its means
+    int walk_spans;                         // FT_WALK / FT_WALK1: spans (of kWalkTiles tiles / of one tile) per bundle
     int walk_group;                         //          consecutive spans of one bundle a workgroup walks (launch shape only: no result depends on it)
 };
 
@@ -210,19 +210,21 @@ __device__ __forceinline__ float dev_atan2(float a, float b) { return ::atan2f(a
 //                bundle's earlier tiles (tiles taken in ticket order); k_ft_mirror adds the second half — least
 //                HBM traffic (84 vs 103 B/ray measured), but every tile waits for its predecessors' counts and the kernel holds
 //                4 waves per SIMD instead of 5 (ORT_FT_LOOKBACK; 5 % slower);
-//   FT_STATS     per-tile (count, mean, M2, max r) only — nothing ray-sized is written: the statistics-only route of
-//                bundles of a few tiles (the reference's own call), bit-identical between RPT = 1 and RPT = 2;
-//   FT_WALK      the statistics-only route of everything else: a workgroup WALKS consecutive tiles of its bundle with the
-//                table staged once and no barrier after that; every lane carries (n, sum d, sum d^2) of its survivors about
-//                the first survivor its wave met, and every SPAN of kWalkTiles tiles each wave folds its lanes (one shuffle
-//                tree) and writes ONE partial (n, mean, M2) — four per span, merged by k_ft_stats_reduce.  What a partial
-//                holds is fixed by kWalkTiles alone, so a bundle's statistics do not depend on how many spans a workgroup
-//                walks (walk_group: chosen per launch to keep the chip full) nor on what else is in the launch.  Per
-//                workgroup — not per tile — is what the per-tile route paid: staging + three dependent round trips before
-//                the first ray moves, 1.28 M times on BASELINE config 5 (profiles/r04_ab_walk.log).
-enum { FT_NONE = 0, FT_FULL = 1, FT_STATS = 2, FT_LOOKBACK = 3, FT_WALK = 4 };
+//   FT_WALK, FT_WALK1   the statistics-only route: nothing ray-sized is written.  A workgroup WALKS consecutive tiles of its bundle
+//                with the table staged once and no barrier after that; every lane carries (n, sum d, sum d^2) of its
+//                survivors about the first survivor its wave met, and every SPAN of kSpan tiles each wave folds its lanes
+//                (one shuffle tree) and writes ONE partial (n, mean, M2) — four per span, merged by k_ft_stats_reduce.  The span
+//                length is a function of the bundle's shape alone (one tile for bundles of <= 32 tiles — the reference's own
+//                call: any number of tiles per workgroup, down to one for a call that small —, kWalkTiles beyond: the fold
+//                costs 7-11 % when taken per tile on BASELINE configs 3 and 5), so what a partial holds, and with it a bundle's
+//                statistics, depends neither on how many spans a workgroup walks (walk_group: chosen per launch to keep the
+//                chip full) nor on what else is in the launch.  Per workgroup — not per tile — is what a one-tile-per-
+//                workgroup route pays: staging + three dependent round trips before the first ray moves, 1.28 M times on
+//                BASELINE config 5 (profiles/r04_ab_walk_tiles_per_workgroup.log).
+enum { FT_NONE = 0, FT_FULL = 1, FT_WALK1 = 2, FT_LOOKBACK = 3, FT_WALK = 4 };   // FT_WALK1: FT_WALK with spans of ONE tile (compile-time: the
+                                                                               // span test of the long-span kernel stays a constant)
 #ifndef ORT_WALK_TILES
-#define ORT_WALK_TILES 8     // tiles per span of the FT_WALK route
+#define ORT_WALK_TILES 8     // tiles per span of the FT_WALK route for bundles of more than kSmallTiles tiles (a power of two)
 #endif
 constexpr int kWalkTiles = ORT_WALK_TILES;
 #ifndef ORT_SUMM_WALK_F64
@@ -237,14 +239,15 @@ constexpr int kStatusVignetted = 1 << 17, kStatusVigShift = 20;
 // one wave's instruction stream, and RPT = 1 — the same 512-ray tile on 512 threads — halves it.  Same results bit for
 // bit (the tile sums are taken in the RPT = 2 order, tile_sum2 below).
 template <typename T, int MATH, int ARMS, bool GRID, bool HIST, bool SUMM, int FT, int RPT = kRPT>
-__global__ __launch_bounds__(kTile / RPT, ARMS >= ARMS_EVEN ? ORT_POLY_WAVES : ((HIST && SUMM) || FT == 3 /* FT_LOOKBACK */ || (FT == 4 /* FT_WALK */ && sizeof(T) == 8)) ? ORT_MIN_WAVES - 1 : HIST ? ORT_MIN_WAVES : sizeof(T) == 4 ? ORT_WAVES_F32 : ORT_WAVES_NOHIST)
+__global__ __launch_bounds__(kTile / RPT, ARMS >= ARMS_EVEN ? ORT_POLY_WAVES : ((HIST && SUMM) || FT == 3 /* FT_LOOKBACK */ || ((FT == 4 || FT == 2) /* FT_WALK, FT_WALK1 */ && sizeof(T) == 8)) ? ORT_MIN_WAVES - 1 : HIST ? ORT_MIN_WAVES : sizeof(T) == 4 ? ORT_WAVES_F32 : ORT_WAVES_NOHIST)
 void k_trace(TraceParams<T> p)   // both outputs, look-back epilogue, Float64 running sums, polynomial arms: 128 VGPRs (at 96 they park tens of values per row in scratch)
 {
     constexpr int NT = kTile / RPT;                              // threads per workgroup: one tile of kTile rays
     constexpr int kSumWaves = kBlock / 64;                       // waves of the RPT = 2 shape: the order the tile sums are taken in
     static_assert(RPT == 1 || RPT == 2, "one or two rays per lane");
     constexpr bool POLY = ARMS >= ARMS_EVEN;
-    constexpr bool WALK = FT == FT_WALK;
+    constexpr bool WALK = FT == FT_WALK || FT == FT_WALK1;
+    constexpr int kSpan = FT == FT_WALK1 ? 1 : kWalkTiles;       // tiles per span of the statistics-only route
     // Float32 summary-mode grid launches walk walk_group consecutive tiles of a bundle per workgroup too (a tile's output does
     // not depend on it): BASELINE config 5's hit payload 12.5 -> 10.5 ms.  Float64: measured, no gain (the per-tile trace is
     // twice as long, the workgroup's start-up hides behind it; profiles/r04_ab_summary_walk.log)
@@ -295,8 +298,8 @@ void k_trace(TraceParams<T> p)   // both outputs, look-back epilogue, Float64 ru
         if (WALK) {
             const int groups = (p.walk_spans + p.walk_group - 1) / p.walk_group;      // workgroups per bundle
             b = bid / groups;
-            tile = (bid - b * groups) * p.walk_group * kWalkTiles;
-            walk_n = min(p.walk_group * kWalkTiles, p.tiles_per_bundle - tile);
+            tile = (bid - b * groups) * p.walk_group * kSpan;
+            walk_n = min(p.walk_group * kSpan, p.tiles_per_bundle - tile);
             walk_tile = tile;
         } else if (SWALK) {
             const int groups = (p.tiles_per_bundle + p.walk_group - 1) / p.walk_group;      // workgroups per bundle
@@ -562,7 +565,7 @@ void k_trace(TraceParams<T> p)   // both outputs, look-back epilogue, Float64 ru
                 wk_n += keep[r] ? 1 : 0;
             }
             tile_base += (unsigned)kTile; j0 += kTile; gbase += kTile; ++walk_tile;            // the next tile
-            if (walk_tile % kWalkTiles == 0 || wt == walk_n - 1) {
+            if (walk_tile % kSpan == 0 || wt == walk_n - 1) {
                 // end of a span (wave-uniform): fold the wave's lanes — one K per wave, so the sums just add; a 64-lane shuffle
                 // tree, fixed shape: bitwise reproducible — and write the wave's partial (n, mean, M2) of this span
                 const int lane = tid & 63, wave = tid >> 6;
@@ -573,7 +576,7 @@ void k_trace(TraceParams<T> p)   // both outputs, look-back epilogue, Float64 ru
                     wk_qx += __shfl_down(wk_qx, off); wk_qy += __shfl_down(wk_qy, off);
                 }
                 if (lane == 0) {
-                    const int64_t o = (((int64_t)b * p.walk_spans + (walk_tile - 1) / kWalkTiles) * (kBlock / 64)) + wave;
+                    const int64_t o = (((int64_t)b * p.walk_spans + (walk_tile - 1) / kSpan) * (kBlock / 64)) + wave;
                     const double inv = n > 0.0 ? 1.0 / n : 0.0;
                     p.tile_cnt[o] = (int32_t)n;
                     p.tile_sx[o] = __builtin_fma(wk_sx, inv, wk_kx); p.tile_sy[o] = __builtin_fma(wk_sy, inv, wk_ky);
@@ -585,10 +588,10 @@ void k_trace(TraceParams<T> p)   // both outputs, look-back epilogue, Float64 ru
                 wk_kx = wk_ky = wk_sx = wk_sy = wk_qx = wk_qy = 0.0;
             }
         }
-        if (FT != FT_NONE && !WALK) {
-            // stop filter (PupilSampling.jl:129-137).  FT_FULL: the tile's survivors are compacted IN RAY ORDER (two
-            // 64-bit ballots + popcount prefix per wave, wave offsets through LDS) and streamed to the first half of
-            // the bundle's output slab; FT_STATS: per-tile moments only.
+        if (kCompact) {
+            // stop filter (PupilSampling.jl:129-137); the tile's survivors are compacted IN RAY ORDER (two 64-bit ballots +
+            // popcount prefix per wave, wave offsets through LDS) and streamed to the tile's workspace slot (FT_FULL) or to
+            // their final place in the first half of the bundle's output slab (FT_LOOKBACK).
             int cnt = 0; double sx = 0.0, sy = 0.0, rmax = -1.0;
             T exv[RPT], eyv[RPT], rv[RPT], thv[RPT];
             bool keep[RPT];
@@ -746,31 +749,6 @@ void k_trace(TraceParams<T> p)   // both outputs, look-back epilogue, Float64 ru
                     auto same = [](T v) { return v; };
                     stream_out<T>(p.out_ex + o0, s_cx, c, tid, same); stream_out<T>(p.out_ey + o0, s_cy, c, tid, same);
                     stream_out<T>(p.out_r + o0, s_cr, c, tid, same);  stream_out<T>(p.out_th + o0, s_ct, c, tid, same);
-                }
-            } else {
-                // FT_STATS: two-pass INSIDE the tile (the tile's survivors are still in registers): tile means,
-                // then squared deviations about them; tiles are merged with Chan's update in k_ft_stats_reduce —
-                // as stable as the reference's two-pass sigma (:169-173), without a second pass over memory.
-                int c = 0; double ax = 0.0, ay = 0.0, mx = -1.0;
-                for (int w = 0; w < kSumWaves; ++w) { ax += s_wsx[w]; ay += s_wsy[w]; }
-                for (int w = 0; w < NT / 64; ++w) { c += s_wcnt[w]; mx = fmax(mx, s_wmax[w]); }
-                const double mux = c ? ax / (double)c : 0.0, muy = c ? ay / (double)c : 0.0;
-                double qx = 0.0, qy = 0.0;
-#pragma unroll
-                for (int r = 0; r < RPT; ++r) {
-                    if (!(rv[r] < T(0))) {
-                        const double dx = (double)exv[r] - mux, dy = (double)eyv[r] - muy;
-                        qx += dx * dx; qy += dy * dy;
-                    }
-                }
-                __syncthreads();                                     // s_wsx / s_wsy are reused below
-                tile_sum2(qx, qy);
-                __syncthreads();
-                if (tid == 0) {
-                    double tx = 0.0, ty = 0.0;
-                    for (int w = 0; w < kSumWaves; ++w) { tx += s_wsx[w]; ty += s_wsy[w]; }
-                    p.tile_cnt[blockIdx.x] = c; p.tile_sx[blockIdx.x] = mux; p.tile_sy[blockIdx.x] = muy;
-                    p.tile_m2x[blockIdx.x] = tx; p.tile_m2y[blockIdx.x] = ty; p.tile_rmax[blockIdx.x] = mx;
                 }
             }
         }

@@ -15,8 +15,8 @@ KERNELS = {"history": "_ZN3ort7k_traceIdLi1ELi0ELb1ELb1ELb0ELi0ELi2EEEvNS_11Trac
            "summary": "_ZN3ort7k_traceIdLi1ELi0ELb1ELb0ELb1ELi0ELi2EEEvNS_11TraceParamsIT_EE",
            # the even-asphere build (ARMS_EVEN), statistics-only full_trace (config 3): its sphere arms may end in the copy
            # of one ray's (x, y) for the stop capture, nothing more
-           "even_stats": "_ZN3ort7k_traceIdLi1ELi2ELb1ELb0ELb0ELi2ELi2EEEvNS_11TraceParamsIT_EE"}
-MOV_ALLOWANCE = {"even_stats": 2}
+           "even_stats": "_ZN3ort7k_traceIdLi1ELi2ELb1ELb0ELb0ELi4ELi2EEEvNS_11TraceParamsIT_EE"}   # (FT_WALK)
+MOV_ALLOWANCE = {"even_stats": 4}      # the tile-walking kernel: the ray state lives across the tile loop, its sphere arms end in two merge copies per ray
 with tempfile.TemporaryDirectory(dir=os.path.join(ROOT, "build") if os.path.isdir(os.path.join(ROOT, "build")) else None) as td:
     asm = os.path.join(td, "ort.s")
     subprocess.run(["hipcc", "--offload-arch=gfx950", "-O3", "-ffp-contract=off", "-std=c++17", "-fno-slp-vectorize",
@@ -40,7 +40,12 @@ for tag, name in KERNELS.items():
     blocks.append((lab, hdr, cur))
     n_inst = sum(len(b) for _, _, b in blocks)
     arms = [(lab, h, b) for lab, h, b in blocks if sum(x.startswith("v_rsq_f64") for x in b) == 4 and not any(x.startswith("v_rcp_f64") for x in b)]
-    hot = arms[0][1] if arms else None                     # header of the loop the fast arms sit in = the hot surface loop
+    # header of the loop the fast arms sit in = the hot surface loop (an arm that IS the loop's header block carries the annotation
+    # on its following lines — nested loops of the tile-walking kernels —: take it from the arm that names its header)
+    hot = next((h for _, h, _ in arms if h), None)
+    for k_, (lab_, h_, b_) in enumerate(blocks):
+        if lab_ == hot:
+            blocks[k_] = (lab_, hot, b_)
     hot_blocks = [(lab, b) for lab, h, b in blocks if h == hot]
     seeds = lambda b: sum(x.startswith(("v_rsq_f64", "v_rcp_f64")) for x in b)
     first_poly = next((i for i, (_, b) in enumerate(hot_blocks) if seeds(b) >= 12), len(hot_blocks))
