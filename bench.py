@@ -515,8 +515,11 @@ def bench_single(args, torch, rank, world, local_rank, emit=True):
                         "instructions_per_intersection": c5["valu_per_intersection"], "effective_clock_GHz": c5["clock_GHz"],
                         "wait_inst_any_share_of_wave_cycles": c5["wait_share"], "kernel_ms_under_counters": c5["kernel_ms"],
                         "fp32_issue_floor_ms": c5["valu_per_intersection"] * rays5 * 12 / 64 / 1024 * 2 / (c5["clock_GHz"] * 1e9) * 1e3,
+                        "fp32_issue_floor_ms_at_measured_rate": c5["valu_per_intersection"] * rays5 * 12 / (84.7 * 256) / (c5["clock_GHz"] * 1e9) * 1e3,
                         "note": "floor = VALU wave-instructions / 1024 SIMDs x 2 cycles (a wave64 FP32 instruction issues over 2 cycles, "
-                                "guide: 'v_fma_f32 (wave64) 2 cyc'; transcendentals 4) at the measured clock",
+                                "guide: 'v_fma_f32 (wave64) 2 cyc'; transcendentals 4) at the measured clock; ..._at_measured_rate: the same "
+                                "instructions at the 84.7 lane-instructions per clock and CU an FMA microbenchmark sustains on this part "
+                                "(tools/ubench_f32.hip, profiles/r02_f32_packed_math.log)",
                         "source": f"profiles/{os.path.basename(sq5)} (static; scripts/clock_config5.sh)"}
             except Exception:                                       # noqa: BLE001 — an optional annotation
                 pass
