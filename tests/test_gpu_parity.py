@@ -781,6 +781,28 @@ def test_native_rccl_allgather_single_rank():
     comm.close()
 
 
+def test_context_destroyed_ahead_of_its_communicator():
+    """A garbage collector may destroy a context before the communicator created on it: ort_ctx_destroy
+    drains the communicator's stream and detaches it, the communicator's entry points then fail with a message instead of
+    reaching into freed memory, and ort_comm_destroy still releases it."""
+    import torch
+    from opticalraytracing_jl_amd import _capi, dist as odist
+    eng = ort.HipEngine(0)
+    comm = odist.RcclComm(eng, 1, 0, odist.RcclComm.unique_id())
+    hits = torch.randn((2, 50001), dtype=torch.float64, device="cuda:0")
+    torch.cuda.synchronize()
+    g = comm.allgather_hits_packed(hits, wait=False)             # a collective still in flight on the communicator's stream
+    lib = eng.ctx.lib
+    eng._systems.clear()
+    eng.ctx.close()                                               # the context goes first
+    assert torch.equal(g[0], hits)                                # ... after draining the communicator's stream
+    rc = lib.ort_comm_synchronize(comm.h)
+    assert rc == -1 and b"null context" in lib.ort_last_error()
+    assert lib.ort_comm_size(comm.h) == 1                         # plain queries still answer
+    assert lib.ort_comm_destroy(comm.h) == 0
+    comm.h = None
+
+
 def test_error_codes(hip_engine):
     """Error behaviour at the boundary: bad arguments -> ORT_EINVAL with a message, |H| > 1 ->
     ORT_EDOMAIN (the reference's DomainError, src/PupilSampling.jl:88-89); no exceptions cross the ABI."""
