@@ -37,7 +37,10 @@
 extern "C" {
 #endif
 
-#define ORT_VERSION 300            /* 0.3.0: ort_wavegrad_f64; ORT_NO_LDS dropped; look-back faults are reported */
+#define ORT_VERSION 400            /* 0.4.0: no new entry point; statistics-only full_trace walks tiles per workgroup (results within 1e-12 of
+                                      0.3.0's); the device-side aiming loops trace without trigonometric calls only under ORT_FAST_MATH;
+                                      the one-call pipelines report look-back faults to host callers; a context may be destroyed ahead of
+                                      its communicators (0.3.0: ort_wavegrad_f64; ORT_NO_LDS dropped; look-back faults are reported) */
 #define ORT_MAX_ROWS 64            /* surface-matrix rows per system, object row included */
 #define ORT_MAX_NCOEF 12           /* polynomial coefficients per surface */
 
