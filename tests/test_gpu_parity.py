@@ -1218,6 +1218,17 @@ def test_random_bundles_grid_and_full_trace(oracle_engine, policy):
                 assert abs(a["rms"] - b["rms"]) <= TOL * max(b["rms"], 1e-6), case
             else:
                 assert math.isnan(a["rms"])
+        # the statistics-only route on the same ragged shapes (one-tile spans, a last tile of a few rays, bundles with no
+        # survivor): counts equal, RMS within 1e-10 of the oracle's two-pass sigma; Float32: counts and RMS track the Float64 call
+        gs = hip_engine.full_trace_grid(pres, bundles, axes, ny, nx, stats_only=True)
+        g32 = hip_engine.full_trace_grid(pres, bundles, axes, ny, nx, stats_only=True, dtype=np.float32)
+        for a, a32, b in zip(gs, g32, of):
+            assert a["count"] == b["count"], case
+            if b["count"]:
+                assert abs(a["rms"] - b["rms"]) <= TOL * max(b["rms"], 1e-6), case
+                assert abs(a32["count"] - b["count"]) <= max(4, 0.02 * b["count"]) and (a32["count"] == 0 or abs(a32["rms"] - b["rms"]) <= 2e-2 * max(b["rms"], 1e-3)), case
+            else:
+                assert math.isnan(a["rms"]) and a["count"] == 0
 
 
 def test_tolerance_run_config5_pipeline(hip_engine, oracle_engine):
