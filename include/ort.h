@@ -68,8 +68,14 @@ extern "C" {
                                        amplify a rounding difference past it at a LATER surface, so identical status is an
                                        observation, not a theorem: no flip on any ray of the parity suites and soaks (> 1e7 rays
                                        of adversarial random systems, profiles/r0*_soak_*; every ray of configs 2 and 3).
-                                       Default: the op-for-op IEEE sequence of the reference loop, bit-identical to a non-fused
-                                       CPU evaluation.  Both policies run the same entry points (tests/test_gpu_parity.py) */
+                                       Prescriptions deeper than ORT_FAST_MAX_SURFACES are traced with the reference sequence
+                                       whatever the flag (below).  Default: the op-for-op IEEE sequence of the reference loop,
+                                       bit-identical to a non-fused CPU evaluation.  Both policies run the same entry points
+                                       (tests/test_gpu_parity.py) */
+#define ORT_FAST_MAX_SURFACES 48    /* ORT_FAST_MATH applies to prescriptions of at most this many loop iterations (rows - 1, the appended
+                                       image plane included); deeper ones — where the path amplifies the fast forms' rounding differences
+                                       towards the 1e-10 bar: worst 3.5e-11 at 47, a few rays of 60,000 past 1e-10 from 54 on,
+                                       profiles/r04_fast_depth.log — are traced with the reference sequence under either flag */
 #define ORT_NO_SMALL_PATH (1u << 8) /* testing aid: small problems (<= 256 (system, field) pairs; full_trace bundles of <= 32 tiles)
                                        normally run their setup and their finish as ONE launch each (k_small_prepare,
                                        k_ft_small_finish); this takes the general multi-launch route instead — same device

@@ -181,7 +181,12 @@ int launch_trace(ort_ctx* ctx, const TraceParams<T>& p, int64_t blocks, unsigned
 {
     if (blocks <= 0) return ORT_OK;
     if (blocks > 0x7fffffffLL) return fail(ORT_EINVAL, "launch too large: %lld workgroups", (long long)blocks);
-    const bool fast = flags & ORT_FAST_MATH;
+    // ORT_FAST_MATH promises <= 1e-10 and the reference's status.  Its rounding differences (hardware seeds + one Newton step:
+    // ~2^-49 per root / reciprocal, ~10 x an IEEE operation's) grow with the DEPTH of the prescription as the path amplifies
+    // them: measured on relay chains (scripts/fast_depth.py, profiles/r04_fast_depth.log) worst 3.5e-11 at 47 loop iterations, a
+    // few rays of 60,000 past 1e-10 from 54 on, one or two of them well-conditioned at 63.  Beyond ORT_FAST_MAX_SURFACES the
+    // promise is kept by the reference sequence itself: such systems run MATH_IEEE under either flag.
+    const bool fast = (flags & ORT_FAST_MATH) && p.S <= ORT_FAST_MAX_SURFACES;
     dim3 g((unsigned)blocks), b(kTile / RPT);
     // the build that carries the arms this batch's rows need (p.arms: ort_system::arms64 / arms32, surface_step_n)
 #define ORT_LAUNCH(M, A) hipLaunchKernelGGL((k_trace<T, M, A, GRID, HIST, SUMM, FT, RPT>), g, b, 0, ctx->stream, p)

@@ -1046,13 +1046,15 @@ def _cooke_relay(units, variant, pad):
     return np.array(rows), np.array(coefs)
 
 
-@pytest.mark.parametrize("rows,units,pad", [(24, 3, 1), (40, 5, 3), (63, 8, 5), (64, 8, 6)])
+@pytest.mark.parametrize("rows,units,pad", [(24, 3, 1), (40, 5, 3), (49, 6, 5), (50, 6, 6), (63, 8, 5), (64, 8, 6)])
 def test_deep_prescriptions_both_policies(hip_engine, oracle_engine, rows, units, pad):
     """Prescriptions of 24, 40, 63 and 64 rows (ORT_MAX_ROWS: the kernel stages up to 63 records) — relay chains mixing
     spheres, planes, conics and even / odd aspheres — against the oracle, src/PupilSampling.jl:45-63 iterated up to 63
     times per ray.  Reference-sequence policy: status and NaN patterns identical, coordinates BIT-identical (polynomial
     rows: <= 1e-11, analytic against complex-step p').  FAST policy: through _fast_attribution unchanged — status
-    identical on every ray, every ray within the bar; the worst deviation is reported."""
+    identical on every ray, every ray within the bar; the worst deviation is reported.  The fast forms' rounding differences
+    grow with depth (profiles/r04_fast_depth.log), so beyond ORT_FAST_MAX_SURFACES = 48 loop iterations (49 rows: the deepest FAST
+    case here; 50 rows: the first past it) an ORT_FAST_MATH call is traced with the reference sequence: identical to the default engine's, bit for bit."""
     fast = ort.HipEngine(0, fast_math=True)
     rng = np.random.default_rng(rows)
     m = 3000
@@ -1074,6 +1076,9 @@ def test_deep_prescriptions_both_policies(hip_engine, oracle_engine, rows, units
             assert max(cm.rel_err(gx, ox, 1.0).max(), cm.rel_err(gy, oy, 1.0).max()) <= 1e-11, variant
         worst = [0.0]
         n, nill, nfar = _fast_attribution(fast, oracle_engine, pres, y, x, u, v, (rows, variant), worst)
+        if rows - 1 > 48:                                         # past ORT_FAST_MAX_SURFACES: the reference sequence under either flag
+            fx, fy, fs = fast.skew(pres, y, x, u, v, slopes=True, want_status=True)
+            assert np.array_equal(fs, gs) and np.array_equal(fx, gx, equal_nan=True) and np.array_equal(fy, gy, equal_nan=True), (rows, variant)
         cm.report(f"deep prescription, {rows} rows ({variant}): FAST rays {n}, past 1e-10 (amplified bar) {nill}, far-cap rays {nfar}, "
                   f"worst deviation {worst[0]:.2e}; reached the last row {float((os_ == rows).mean()):.2f}")
 
