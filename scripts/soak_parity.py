@@ -1,6 +1,6 @@
-"""One-off soak on the GPU box: N random prescriptions x M random skew rays, IEEE policy vs the CPU oracle,
+"""One-off soak on the GPU box: N random prescriptions (2 .. maxrows - 1 rows) x M random skew rays, IEEE policy vs the CPU oracle,
 bit for bit (status and coordinates; polynomial rows to 1e-11), different seed from the test suite; also
-extreme inputs (huge / tiny radii, grazing rays).  python scripts/soak_parity.py [nsys] [seed]"""
+extreme inputs (huge / tiny radii, grazing rays).  python scripts/soak_parity.py [nsys] [seed] [maxrows]"""
 import math, sys
 sys.path.insert(0, __import__("os").path.dirname(__import__("os").path.dirname(__import__("os").path.abspath(__file__))))
 import numpy as np
@@ -12,11 +12,12 @@ from tests.test_gpu_parity import _random_system
 
 nsys = int(sys.argv[1]) if len(sys.argv) > 1 else 1500
 seed = int(sys.argv[2]) if len(sys.argv) > 2 else 777
+maxrows = int(sys.argv[3]) if len(sys.argv) > 3 else 20        # prescriptions of 2 .. maxrows - 1 rows (ORT_MAX_ROWS = 64)
 rng = np.random.default_rng(seed)
 hip = ort.HipEngine(0); fast = ort.HipEngine(0, fast_math=True); orc = OracleEngine(nthreads=8)
-bad = worst_fast = 0; nfr = ntot = 0
+bad = worst_fast = 0; nfr = ntot = 0; worst_asph = 0.0; n_asph_11 = 0; n_wild = 0; worst_wild = 0.0
 for case in range(nsys):
-    rows = int(rng.integers(2, 20))
+    rows = int(rng.integers(2, maxrows))
     aspheric = (True, "even", False)[case % 3]
     R, t, n, K, coef = _random_system(rng, rows, aspheric)
     if case % 7 == 0:                       # extremes: very strong and very weak curvatures
@@ -31,7 +32,21 @@ for case in range(nsys):
     ok = np.array_equal(gs, os_)
     if aspheric:
         fin = np.isfinite(ox) & np.isfinite(gx)
-        ok = ok and np.array_equal(np.isnan(gx), np.isnan(ox)) and cm.rel_err(gx, ox, 1.0).max() <= 1e-11 and cm.rel_err(gy, oy, 1.0).max() <= 1e-11
+        # polynomial rows: the device takes p' analytically, the reference (and the oracle) by a complex step of 2^-26 — equal to
+        # ~2^-52 relative, a rounding-sized difference that the path amplifies like any other.  Random polynomial coefficients sized
+        # for a +-6 mm bundle explode once a ray wanders tens of mm off axis (a 10th-order term: metres of "sag"); from there the
+        # coordinates are 1e4 .. 1e10 mm and mean nothing.  The bar (north_star's 1e-10 relative; 1e-11 holds up to ~20 rows) is
+        # applied to the rays that stay inside 1e3 mm on every surface (`sane`, as for the FAST check below); the NaN patterns must
+        # agree on every ray; the others are counted and their worst relative deviation reported
+        pat = np.array_equal(np.isnan(gx), np.isnan(ox)) and np.array_equal(np.isnan(gy), np.isnan(oy))
+        per_ray = np.maximum(cm.rel_err(gx, ox, 1.0).max(axis=0), cm.rel_err(gy, oy, 1.0).max(axis=0))
+        sane_a = (np.nanmax(np.abs(ox), axis=0, initial=0.0) < 1e3) & (np.nanmax(np.abs(oy), axis=0, initial=0.0) < 1e3)
+        da = float(per_ray[sane_a].max()) if sane_a.any() else 0.0
+        worst_asph = max(worst_asph, da)
+        n_asph_11 += int(da > 1e-11)
+        n_wild += int((~sane_a).sum())
+        worst_wild = max(worst_wild, float(per_ray[~sane_a].max()) if (~sane_a).any() else 0.0)
+        ok = ok and pat and da <= 1e-10
     else:
         ok = ok and np.array_equal(gx, ox, equal_nan=True) and np.array_equal(gy, oy, equal_nan=True)
     if not ok:
@@ -52,6 +67,6 @@ for case in range(nsys):
         worst_fast = max(worst_fast, med)
     if case % 250 == 0:
         print(f"case {case}: mismatching systems so far {bad}, fast fringe {nfr}/{ntot}", flush=True)
-print(f"DONE {nsys} systems x 800 rays, seed {seed}: IEEE mismatching systems {bad}; FAST fringe (status flip or > 1e-9) {nfr}/{ntot} = {nfr / ntot:.2e}; "
-      f"worst median FAST deviation {worst_fast:.2e}")
+print(f"DONE {nsys} systems of 2..{maxrows - 1} rows x 800 rays, seed {seed}: IEEE mismatching systems {bad}; FAST fringe (status flip or > 1e-9) {nfr}/{ntot} = {nfr / ntot:.2e}; "
+      f"worst median FAST deviation {worst_fast:.2e}; aspheric systems (analytic vs complex-step p'): worst deviation {worst_asph:.2e}, {n_asph_11} systems past 1e-11 on rays inside 1e3 mm; {n_wild} rays beyond 1e3 mm (exploding polynomial terms), worst relative deviation there {worst_wild:.2e}")
 sys.exit(1 if bad else 0)
