@@ -977,6 +977,56 @@ def test_random_systems_property(hip_engine, oracle_engine):
     assert nill <= 1e-4 * ntot, (nill, ntot)             # rays beyond 1e-10 (ill-conditioned paths, within 100 x sens): rare
 
 
+def test_random_deep_systems_property(hip_engine, oracle_engine):
+    """The random-prescription property test at DEPTH: 60 systems of 15 .. 63 rows (the suites above draw 2 .. 14) x 1000 rays.
+    Reference-sequence policy: status identical on every ray; spherical / conic systems bit-identical; polynomial systems (analytic
+    against complex-step p') within 1e-10 on every ray that stays inside 1e3 mm — random coefficients sized for a +-6 mm bundle
+    explode once a ray is tens of mm off axis (metres of "sag"; coordinates of 1e4 .. 1e9 mm mean nothing and are compared for their
+    NaN pattern only).  FAST policy (the reference sequence past ORT_FAST_MAX_SURFACES): status identical on every ray, the rays
+    inside 1e3 mm within max(1e-10, 100 x their conditioning)."""
+    rng = np.random.default_rng(4096)
+    fast = ort.HipEngine(0, fast_math=True)
+    ntot = nill = nwild = 0
+    worst_poly = 0.0
+    for case in range(60):
+        rows = int(rng.integers(15, 64))
+        aspheric = (True, "even", False)[case % 3]
+        R, t, n, K, coef = _random_system(rng, rows, aspheric)
+        pres = Prescription(R, t, n, K if aspheric else None, coef[None] if aspheric else None)
+        m = 1000
+        y = rng.uniform(-6, 6, m); x = rng.uniform(-6, 6, m)
+        u = np.tan(rng.uniform(-0.1, 0.1, m)); v = np.tan(rng.uniform(-0.1, 0.1, m))
+        ox, oy, os_ = oracle_engine.skew(pres, y, x, u, v, slopes=True, want_status=True)
+        gx, gy, gs = hip_engine.skew(pres, y, x, u, v, slopes=True, want_status=True)
+        assert np.array_equal(gs, os_), (case, rows)
+        sane = (np.nanmax(np.abs(ox), axis=0, initial=0.0) < 1e3) & (np.nanmax(np.abs(oy), axis=0, initial=0.0) < 1e3)
+        nwild += int((~sane).sum())
+        if aspheric:
+            assert np.array_equal(np.isnan(gx), np.isnan(ox)) and np.array_equal(np.isnan(gy), np.isnan(oy)), (case, rows)
+            if sane.any():
+                dp = max(cm.rel_err(gx[:, sane], ox[:, sane], 1.0).max(), cm.rel_err(gy[:, sane], oy[:, sane], 1.0).max())
+                worst_poly = max(worst_poly, float(dp))
+                assert dp <= 1e-10, (case, rows, dp)
+        else:
+            assert np.array_equal(gx, ox, equal_nan=True) and np.array_equal(gy, oy, equal_nan=True), (case, rows)
+        fx, fy, fs = fast.skew(pres, y, x, u, v, slopes=True, want_status=True)
+        assert np.array_equal(fs, os_), (case, rows, "FAST status")
+        if rows - 1 > 48:
+            assert np.array_equal(fx, gx, equal_nan=True) and np.array_equal(fy, gy, equal_nan=True), (case, rows)
+        elif sane.any():
+            d13 = 1e-13
+            px, py = oracle_engine.skew(pres, y * (1 + d13), x * (1 - d13), u * (1 + d13), v * (1 - d13), slopes=True)
+            sens = _deviation(px, py, ox, oy)
+            err = _deviation(fx, fy, ox, oy)
+            bad = sane & ~(err <= np.maximum(FAST_TOL, FAST_AMP * sens))
+            assert not bad.any(), (case, rows, int(bad.sum()), float(err[bad].max()), float(sens[bad].max()))
+            nill += int((sane & (err > FAST_TOL)).sum())
+        ntot += m
+    cm.report(f"test_random_deep_systems_property (15 .. 63 rows): rays {ntot}, beyond 1e3 mm {nwild}, FAST rays past 1e-10 (amplified bar) {nill}, "
+              f"polynomial systems (reference-sequence policy, analytic vs complex-step p') worst {worst_poly:.2e}")
+    assert nill <= 2e-3 * ntot, (nill, ntot)
+
+
 def test_fast_policy_baseline_fixtures_need_no_amplified_bar(oracle_engine):
     """The amplified bar of _fast_attribution (100 x the oracle's own response to a 1e-13 perturbation) exists for the
     ill-conditioned rays of the adversarial random systems.  On the prescriptions of the BASELINE configs — Cooke triplet
