@@ -21,13 +21,26 @@ from .api import DomainError, EPS, LAMBDA, SPOT_RAYS, _eng
 from .engine import Prescription
 
 _FO_FIELDS = [f[0] for f in _capi.ort_first_order._fields_]
+_FO_DTYPE = np.dtype([(k, np.float64) for k in _FO_FIELDS[:-2]] + [("stop", np.int32), ("k", np.int32)])
+
+
+def split_columns(mats):
+    """[ninst][rows][3] = [R t n] -> the three contiguous [ninst][rows] arrays the C ABI takes (include/ort.h: R, t, n :
+    [nsys][rows]).  numpy takes ~0.5 ms to pull the columns of 10^4 x 12 x 3 apart; a caller that runs many batches (a tolerance
+    loop, bench.py) does it once and passes the tuple (R, t, n) wherever this module takes `mats`."""
+    if isinstance(mats, (tuple, list)) and len(mats) == 3 and all(np.ndim(m) == 2 for m in mats):
+        return tuple(np.ascontiguousarray(m, dtype=np.float64) for m in mats)
+    mats = np.asarray(mats, dtype=np.float64)
+    if mats.ndim == 2:
+        mats = mats[None]
+    cols = np.ascontiguousarray(mats[:, :, :3].transpose(2, 0, 1))
+    return cols[0], cols[1], cols[2]
 
 
 def first_order_arrays(engine, mats: np.ndarray, a, hprime, dn=None, lam: float = LAMBDA) -> Dict[str, np.ndarray]:
-    """ort_first_order_f64 over [ninst][rows][3] -> dict of [ninst] arrays."""
-    mats = np.ascontiguousarray(mats, dtype=np.float64)
-    ninst, rows, _ = mats.shape
-    R = np.ascontiguousarray(mats[:, :, 0]); t = np.ascontiguousarray(mats[:, :, 1]); n = np.ascontiguousarray(mats[:, :, 2])
+    """ort_first_order_f64 over [ninst][rows][3] (or the pre-split (R, t, n)) -> dict of [ninst] arrays."""
+    R, t, n = split_columns(mats)
+    ninst, rows = R.shape
     a = np.ascontiguousarray(np.broadcast_to(np.asarray(a, dtype=np.float64), (ninst, rows - 1)))
     hp = np.ascontiguousarray(np.broadcast_to(np.asarray(hprime, dtype=np.float64), (ninst,)))
     dnp = None if dn is None else np.ascontiguousarray(np.broadcast_to(np.asarray(dn, dtype=np.float64), (ninst, rows)))
@@ -35,9 +48,8 @@ def first_order_arrays(engine, mats: np.ndarray, a, hprime, dn=None, lam: float 
     _capi.check(engine.ctx.lib.ort_first_order_f64(engine.ctx.h, ninst, rows, _capi.ptr(R), _capi.ptr(t), _capi.ptr(n),
                                                    _capi.ptr(a), _capi.ptr(dnp), _capi.ptr(hp), float(lam), out,
                                                    engine.base_flags))
-    dt = np.dtype([(k, np.float64) for k in _FO_FIELDS[:-2]] + [("stop", np.int32), ("k", np.int32)])
-    arr = np.frombuffer(out, dtype=dt, count=ninst)
-    return {k: np.array(arr[k]) for k in _FO_FIELDS}
+    arr = np.frombuffer(out, dtype=_FO_DTYPE, count=ninst)
+    return {k: arr[k] for k in _FO_FIELDS}                        # views into the struct array the call filled
 
 
 _AIM_OUT = np.dtype([(k, np.float64) for k in ("U", "y1", "y2", "y_EP", "hprime", "EP_t", "Ubar", "XP_t")] +
@@ -187,11 +199,10 @@ def spot_batch(mats: np.ndarray, a, hprime, fields: Sequence[float] = (0.0,), k_
     (BASELINE config 5); solve, aiming and the statistics stay binary64."""
     eng = _eng(engine)
     fn = eng.ctx.lib.ort_spot_batch_f64 if np.dtype(dtype) == np.float64 else eng.ctx.lib.ort_spot_batch_f32
-    mats = np.ascontiguousarray(mats, dtype=np.float64)
-    ninst, rows, _ = mats.shape
+    R, t, n = split_columns(mats)
+    ninst, rows = R.shape
     fields = np.ascontiguousarray(np.abs(np.asarray(fields, dtype=np.float64)))
     nf = len(fields)
-    R = np.ascontiguousarray(mats[:, :, 0]); t = np.ascontiguousarray(mats[:, :, 1]); n = np.ascontiguousarray(mats[:, :, 2])
     a_arr = np.ascontiguousarray(np.broadcast_to(np.asarray(a, dtype=np.float64), (ninst, rows - 1)))
     hp = np.ascontiguousarray(np.broadcast_to(np.asarray(hprime, dtype=np.float64), (ninst,)))
     fo = (_capi.ort_first_order * ninst)()
@@ -202,9 +213,8 @@ def spot_batch(mats: np.ndarray, a, hprime, fields: Sequence[float] = (0.0,), k_
     if rc == _capi.ORT_EDOMAIN:
         raise DomainError(eng.ctx.lib.ort_last_error().decode('utf-8', 'replace'))
     _capi.check(rc)
-    dt = np.dtype([(k, np.float64) for k in _FO_FIELDS[:-2]] + [("stop", np.int32), ("k", np.int32)])
-    arr = np.frombuffer(fo, dtype=dt, count=ninst)
-    out = {k: np.array(arr[k]) for k in _FO_FIELDS}
+    arr = np.frombuffer(fo, dtype=_FO_DTYPE, count=ninst)   # views into the one struct array the call filled (no per-field copies)
+    out = {k: arr[k] for k in _FO_FIELDS}
     out["rms"] = rms.reshape(ninst, nf)
     out["count"] = count.reshape(ninst, nf)
     return out
@@ -251,9 +261,8 @@ def full_trace_systems(mats: np.ndarray, a, hprime, fields: Sequence[float] = (0
     if rc == _capi.ORT_EDOMAIN:
         raise DomainError(lib.ort_last_error().decode('utf-8', 'replace'))
     _capi.check(rc)
-    dt = np.dtype([(k, np.float64) for k in _FO_FIELDS[:-2]] + [("stop", np.int32), ("k", np.int32)])
-    arr = np.frombuffer(fo, dtype=dt, count=ninst)
-    first = {k: np.array(arr[k]) for k in _FO_FIELDS}
+    arr = np.frombuffer(fo, dtype=_FO_DTYPE, count=ninst)
+    first = {k: arr[k] for k in _FO_FIELDS}
     out = []
     for b in range(na):
         c = int(count[b])

