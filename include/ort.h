@@ -100,7 +100,11 @@ typedef struct ort_system ort_system; /* device-resident batch of prescriptions 
 /* ---- context ---------------------------------------------------------------------- */
 int ort_version(void);
 const char *ort_last_error(void);
-/* stream: a hipStream_t to launch on, or NULL for a stream owned by the context. */
+/* stream: a hipStream_t to launch on, or NULL for a stream owned by the context (created non-blocking: it does NOT wait
+ * for work on the legacy default stream).  With ORT_DEVICE_PTRS the calls are asynchronous on that stream and read / write the
+ * caller's device buffers there: a caller that fills or reads those buffers on another stream (an array library's own) orders
+ * the two itself — hand its stream to ort_ctx_create / ort_ctx_set_stream, or synchronise it before the call and
+ * ort_ctx_synchronize after (tests/test_gpu_parity.py does the latter around torch's fills). */
 int ort_ctx_create(int device, void *stream, ort_ctx **out);
 int ort_ctx_destroy(ort_ctx *ctx);
 int ort_ctx_set_stream(ort_ctx *ctx, void *stream);
