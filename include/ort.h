@@ -37,7 +37,8 @@
 extern "C" {
 #endif
 
-#define ORT_VERSION 400            /* 0.4.0: no new entry point; statistics-only full_trace walks tiles per workgroup (results within 1e-12 of
+#define ORT_VERSION 401            /* 0.4.1: ORT_FT_FUSED (full_trace's second pass inside the trace launch; bit-identical results) and its
+                                      testing aid ort_ctx_test_fused_no_scan.  0.4.0: no new entry point; statistics-only full_trace walks tiles per workgroup (results within 1e-12 of
                                       0.3.0's); the device-side aiming loops trace without trigonometric calls only under ORT_FAST_MATH;
                                       the one-call pipelines report look-back faults to host callers; a context may be destroyed ahead of
                                       its communicators (0.3.0: ort_wavegrad_f64; ORT_NO_LDS dropped; look-back faults are reported) */
@@ -84,6 +85,10 @@ extern "C" {
 #define ORT_AIM_EDGE_AS_FOUND (1u << 9) /* ort_aim_f64, diagnostic: leave the two edge-ray searches where the FD-Newton ends (either side
                                         of the stop's edge) instead of applying the fitted "end inside the edge" rule described at
                                         ort_aim_f64 */
+#define ORT_FT_FUSED      (1u << 10) /* full_trace, two or more bundles: the second pass (offsets, placement in both halves, squared
+                                        deviations) runs INSIDE the trace launch — a workgroup that has traced its tile places a tile of
+                                        an earlier, complete bundle — so the HBM-bound pass overlaps the issue-bound one.  Same device
+                                        functions: bit-identical results */
 #define ORT_FT_LOOKBACK   (1u << 7) /* full_trace: the trace kernel writes the survivors' first half at its final place
                                        (decoupled look-back over the bundle's tiles) instead of staging compacted tiles in
                                        a workspace: 82 instead of 100 B/ray of HBM traffic, but tiles wait for their
@@ -241,6 +246,9 @@ int ort_wavegrad_f64(ort_ctx *ctx, int nb, int64_t cap, const int64_t *count, co
 /* Testing aid: shift the context's look-back ticket base against the device counter, the bookkeeping fault that
  * ort_full_trace_* with ORT_FT_LOOKBACK must report (ORT_EHIP; device-pointer callers see count = -1, rms = NaN). */
 int ort_ctx_test_skew_tickets(ort_ctx *ctx, int64_t delta);
+/* Testing aid: with on != 0 an ORT_FT_FUSED launch names no workgroup for the bundles' scans and polls briefly, so every
+ * placement waits in vain — the in-launch hand-off fault that ort_full_trace_* must report the same way. */
+int ort_ctx_test_fused_no_scan(ort_ctx *ctx, int on);
 
 /* ---- meridional real-ray trace: raytrace(surfaces, y, U, RealRay; K, p) ---------------
  * src/RayTracing.jl:145-169.  y_out, U_out, ts_out : [rows][ld] (row 0 = input ray;

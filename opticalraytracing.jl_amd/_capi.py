@@ -24,6 +24,7 @@ ORT_LAYOUT_INPUT = 1 << 3
 ORT_CLIP = 1 << 4
 ORT_FAST_MATH = 1 << 5
 ORT_FT_LOOKBACK = 1 << 7
+ORT_FT_FUSED = 1 << 10
 ORT_NO_SMALL_PATH = 1 << 8
 ORT_AIM_EDGE_AS_FOUND = 1 << 9
 ORT_STATUS_STOPPED = 1 << 16
@@ -128,6 +129,7 @@ SIGNATURES = {
     "ort_full_trace_f32": (_i, [_p, _p, _i, C.POINTER(ort_bundle), _p, _l, _i, _i, _p, _p, _p, _p, _p, _p, _u]),
     "ort_wavegrad_f64": (_i, [_p, _i, _l, _p, _p, C.c_double, _p, _p, _p, _p, _u]),
     "ort_ctx_test_skew_tickets": (_i, [_p, _l]),
+    "ort_ctx_test_fused_no_scan": (_i, [_p, _i]),
     "ort_aim_f64": (_i, [_p, _p, _p, _i, C.POINTER(ort_aim_in), C.POINTER(ort_aim_out), _u]),
     "ort_fan_f64": (_i, [_p, _p, _i, C.POINTER(ort_fan_in), _i, _i, _p, _p, _u]),
     "ort_first_order_f64": (_i, [_p, _i, _i, _p, _p, _p, _p, _p, _p, C.c_double, C.POINTER(ort_first_order), _u]),

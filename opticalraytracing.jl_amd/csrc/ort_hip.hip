@@ -72,6 +72,15 @@ constexpr size_t kZeroCopyBytes = (size_t)1 << 20;   // spot pipelines whose pac
 #ifndef ORT_WALK_TARGET
 #define ORT_WALK_TARGET 16384
 #endif
+#ifndef ORT_FUSE_MARGIN
+#define ORT_FUSE_MARGIN 4096
+#endif
+#ifndef ORT_FUSE_SCAN_LAG
+#define ORT_FUSE_SCAN_LAG 1024
+#endif
+constexpr int kFuseMargin = ORT_FUSE_MARGIN;     // fused full_trace: workgroups between a bundle's last tile and the first placement of its tiles
+constexpr int kFuseScanLag = ORT_FUSE_SCAN_LAG;  // ... and the workgroup that runs the bundle's scan (every tile's workgroup has long been dispatched by then)
+static_assert(kFuseScanLag <= kFuseMargin, "the scan runs ahead of the placements");
 constexpr int64_t kWalkTargetGroups = ORT_WALK_TARGET;   // statistics-only walk route: workgroups a launch is cut into when it has that many spans
                                                // (~8 per resident slot of the chip); fewer spans: one workgroup per span
 constexpr int kSmallPairs = 256;    // spot pipelines of at most this many (system, field) pairs prepare in one launch (k_small_prepare)
@@ -81,7 +90,7 @@ enum { SL_IN0 = 0, SL_IN1, SL_IN2, SL_IN3, SL_OUT0, SL_OUT1, SL_OUT2, SL_OUT3, S
        SL_BUNDLES, SL_AXES, SL_WEX, SL_WEY, SL_WR, SL_WTH, SL_TCNT, SL_TSX, SL_TSY, SL_TRM,
        SL_TOFF, SL_TSQ, SL_AGG, SL_RES0, SL_RES1, SL_TAB0, SL_TAB1, SL_TAB2, SL_TAB3,
        SL_SB_FO, SL_SB_REC, SL_SB_MF, SL_SB_MR, SL_SB_TLF, SL_SB_TLR, SL_SB_AIN, SL_SB_AOUT, SL_SB_ENDS, SL_SB_FLAG,
-       SL_SB_FIELDS, SL_SB_A, SL_SB_HP, SL_SB_PACK, SL_SB_CEXT, SL_SB_CREV, SL_FTSTATE, SL_FTTICKET, SL_FTERR, SL_DOMAIN, SL_RBSLOPES, SL_COUNT };
+       SL_SB_FIELDS, SL_SB_A, SL_SB_HP, SL_SB_PACK, SL_SB_CEXT, SL_SB_CREV, SL_FTSTATE, SL_FTTICKET, SL_FTERR, SL_FTDONE, SL_FTREADY, SL_DOMAIN, SL_RBSLOPES, SL_COUNT };
 
 }  // namespace
 
@@ -96,6 +105,8 @@ struct ort_ctx {
     size_t pin_cap = 0;
     // full_trace look-back (k_trace<FT_FULL>): words of earlier launches are told apart by the epoch, tickets by the base
     size_t ft_state_cap = 0;                   // capacity of SL_FTSTATE the zero fill was done for
+    size_t ft_ready_cap = 0;                   // the same for SL_FTREADY (fused route)
+    bool test_fused_no_scan = false;           // ort_ctx_test_fused_no_scan
     unsigned ft_epoch = 0;
     unsigned long long ft_ticket_base = 0;
     std::vector<struct ort_comm*> comms;       // live communicators of this context (their streams may hold buffers in flight)
@@ -506,7 +517,7 @@ int run_full_trace(ort_ctx* ctx, TraceParams<T>& p, int nb, T* ex, T* ey, T* rho
         return ORT_OK;
     }
     double* chunk_sq; FtBundleAgg* agg; int* ft_err = nullptr; bool fused_finish = false;
-    rc = dev_out<double>(ctx, SL_TSQ, (size_t)tiles, &chunk_sq); if (rc) return rc;
+    rc = dev_out<double>(ctx, SL_TSQ, (size_t)tiles * (kBlock / 64), &chunk_sq); if (rc) return rc;   // (fused route: a partial per wave)
     rc = dev_out<FtBundleAgg>(ctx, SL_AGG, (size_t)nb, &agg); if (rc) return rc;
     T *dex = ex, *dey = ey, *drho = rho, *dth = theta;
     if (!devp) {
@@ -526,9 +537,43 @@ int run_full_trace(ort_ctx* ctx, TraceParams<T>& p, int nb, T* ex, T* ey, T* rho
         rc = dev_out<T>(ctx, SL_WTH, nw, &wth); if (rc) return rc;
         rc = dev_out<int64_t>(ctx, SL_TOFF, (size_t)tiles, &tile_off); if (rc) return rc;
         p.out_ex = wex; p.out_ey = wey; p.out_r = wr; p.out_th = wth;
+        const bool fused = (flags & ORT_FT_FUSED) && nb >= 2 && p.tiles_per_bundle > kSmallTiles && !small_f64;
+        if (fused) {
+            // the second pass inside the trace launch (k_trace, FT_FUSED): workgroup i traces tile i and places tile i - lag
+            rc = dev_out<int>(ctx, SL_FTDONE, (size_t)nb + 4, &p.ft_done); if (rc) return rc;
+            HIP_TRY(hipMemsetAsync(p.ft_done, 0, ((size_t)nb * sizeof(int) + 15) & ~(size_t)15, ctx->stream));   // arrivals are counted within the call
+            rc = dev_out<unsigned>(ctx, SL_FTREADY, (size_t)nb, &p.ft_ready); if (rc) return rc;
+            if (ctx->slot[SL_FTREADY].cap != ctx->ft_ready_cap) {
+                HIP_TRY(hipMemsetAsync(p.ft_ready, 0, ctx->slot[SL_FTREADY].cap, ctx->stream));
+                ctx->ft_ready_cap = ctx->slot[SL_FTREADY].cap;
+            }
+            rc = dev_out<int>(ctx, SL_FTERR, 1, &p.ft_err); if (rc) return rc;
+            HIP_TRY(hipMemsetAsync(p.ft_err, 0, sizeof(int), ctx->stream));
+            ft_err = p.ft_err;
+            ctx->ft_epoch = (ctx->ft_epoch + 1) & 0x3fffffffu;
+            if (ctx->ft_epoch == 0) ctx->ft_epoch = 1;
+            p.ft_epoch = ctx->ft_epoch;
+            p.tile_off = tile_off; p.agg = agg; p.tile_sq = chunk_sq;
+            p.fin_ex = dex; p.fin_ey = dey; p.fin_rho = drho; p.fin_th = dth;
+            p.fuse_ntiles = (int)tiles;
+            p.fuse_lag = p.tiles_per_bundle + kFuseMargin;
+            p.fuse_scan_lag = kFuseScanLag;
+            p.fuse_spin_cap = 1 << 22;
+            if (ctx->test_fused_no_scan) {                           // testing aid: nobody runs the scans, the waits give up early
+                p.fuse_scan_lag = 0x3fffffff; p.fuse_spin_cap = 1 << 10;
+            }
+            if (tiles + p.fuse_lag > 0x7fffffffLL) return fail(ORT_EINVAL, "launch too large");
+            rc = launch_trace<T, true, false, false, FT_FUSED>(ctx, p, tiles + p.fuse_lag, flags); if (rc) return rc;
+        } else
         if (small_f64) rc = launch_trace<T, true, false, false, FT_FULL, sizeof(T) == 8 ? 1 : kRPT>(ctx, p, tiles, flags);
         else rc = launch_trace<T, true, false, false, FT_FULL>(ctx, p, tiles, flags);
         if (rc) return rc;
+        if (fused) {
+            hipLaunchKernelGGL((k_ft_finalize<kBlock / 64>), dim3((unsigned)nb), dim3(kBlock), 0, ctx->stream,
+                               chunk_sq, p.tiles_per_bundle, agg, dcount, drms, (const int*)ft_err);
+            HIP_TRY(hipGetLastError());
+            fused_finish = true;
+        } else
         if (p.tiles_per_bundle <= kSmallTiles && !(flags & ORT_NO_SMALL_PATH)) {
             // bundles of a few tiles (the reference's own call: 4): offsets, placement and sigma by one workgroup per bundle
             // in ONE launch, through the same bodies (k_ft_small_finish)
@@ -579,7 +624,7 @@ int run_full_trace(ort_ctx* ctx, TraceParams<T>& p, int nb, T* ex, T* ey, T* rho
         HIP_TRY(hipGetLastError());
     }
     if (!fused_finish) {
-        hipLaunchKernelGGL(k_ft_finalize, dim3((unsigned)nb), dim3(kBlock), 0, ctx->stream,
+        hipLaunchKernelGGL((k_ft_finalize<1>), dim3((unsigned)nb), dim3(kBlock), 0, ctx->stream,
                            chunk_sq, p.tiles_per_bundle, agg, dcount, drms, (const int*)ft_err);
         HIP_TRY(hipGetLastError());
     }
@@ -590,9 +635,9 @@ int run_full_trace(ort_ctx* ctx, TraceParams<T>& p, int nb, T* ex, T* ey, T* rho
         if (ft_err) { rc = from_device<int>(ctx, &herr, ft_err, 1); if (rc) return rc; }
         HIP_TRY(hipStreamSynchronize(ctx->stream));
         if (herr)
-            return fail(ORT_EHIP, "full_trace look-back fault (%s): the survivors' offsets are not trustworthy, nothing was returned",
+            return fail(ORT_EHIP, "full_trace in-launch hand-off fault (%s): the survivors' offsets are not trustworthy, nothing was returned",
                         (herr & 2) ? "tile tickets outside the launch: the context's ticket base and the device counter disagree"
-                                   : "a tile waited for a predecessor beyond the poll cap");
+                                   : "a workgroup waited for its predecessors beyond the poll cap");
         for (int b = 0; b < nb; ++b) {
             const size_t off = (size_t)b * 2 * rpb, cnt = (size_t)count[b];
             if (!cnt) continue;
@@ -783,7 +828,7 @@ int spot_batch_impl(ort_ctx* ctx, int nsys, int rows, const double* R, const dou
         if (ex && (flags & ORT_FT_LOOKBACK))
             for (int b = 0; b < na; ++b)
                 if (count[b] < 0)
-                    return fail(ORT_EHIP, "full_trace look-back fault: the survivors' offsets are not trustworthy, nothing was returned");
+                    return fail(ORT_EHIP, "full_trace in-launch hand-off fault: the survivors' offsets are not trustworthy, nothing was returned");
         if (ex) {
             const T* hv = reinterpret_cast<const T*>(hpin + o_vec);
             for (int b = 0; b < na; ++b) {                           // the valid entries of every slab
@@ -961,6 +1006,13 @@ int ort_ctx_test_skew_tickets(ort_ctx* ctx, int64_t delta)
 {
     int rc = check_ctx(ctx); if (rc) return rc;
     ctx->ft_ticket_base += (unsigned long long)delta;
+    return ORT_OK;
+}
+
+int ort_ctx_test_fused_no_scan(ort_ctx* ctx, int on)
+{
+    int rc = check_ctx(ctx); if (rc) return rc;
+    ctx->test_fused_no_scan = on != 0;
     return ORT_OK;
 }
 

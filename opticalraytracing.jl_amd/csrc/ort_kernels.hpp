@@ -120,6 +120,14 @@ struct TraceParams {
     double* tile_m2x; double* tile_m2y;     // FT_WALK: a partial's sums of squared deviations about its means
     int walk_spans;                         // FT_WALK / FT_WALK1: spans (of kWalkTiles tiles / of one tile) per bundle
     int walk_group;                         //          consecutive spans of one bundle a workgroup walks (launch shape only: no result depends on it)
+    // FT_FUSED: the second pass inside the trace launch (workgroup i traces tile i and places tile i - fuse_lag)
+    int64_t* tile_off; struct FtBundleAgg* agg; double* tile_sq;
+    T* fin_ex; T* fin_ey; T* fin_rho; T* fin_th;       // the caller's ex / ey / rho / theta [nb][2*rpb]
+    int* ft_done;                           // [nb] tiles of the bundle traced so far (back to 0 once its scan has run)
+    unsigned* ft_ready;                     // [nb] = ft_epoch once the bundle's offsets and aggregates are published
+    int fuse_ntiles, fuse_lag;              // nb * tiles_per_bundle; tiles_per_bundle + margin
+    int fuse_scan_lag;                      // the workgroup fuse_scan_lag - 1 past a bundle's last tile runs that bundle's scan (< margin)
+    int fuse_spin_cap;                      // polls before a waiting workgroup gives up and raises the fault word
 };
 
 // Two adjacent rays of one lane: one 2*sizeof(T) streaming store when the address allows.
@@ -191,12 +199,370 @@ __device__ __forceinline__ double readlane_f64(double v, int lane)
     return __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
 }
 
+// ------------------------------------------------------------------------------------
+// Data handed from one workgroup to another INSIDE a launch (the fused full_trace route, FT_FUSED).  The XCDs' L2s are not
+// coherent with each other and a CU's vector L1 is never refreshed by another CU's stores: every such byte is stored
+// write-through (`sc1`) and drained by its wave (`s_waitcnt vmcnt(0)`) ahead of the workgroup's barrier and the ONE lane that
+// signals (an agent-scope atomic), and every load of it is an `sc1` load (past the L1) behind the poll / the returned add —
+// no fence anywhere (`__threadfence()` per workgroup ran this route 10 x slower: it writes back and invalidates whole caches).
+// 16-byte accesses go through raw buffer instructions (aux 16 = sc1) off a wave-uniform base, words through relaxed
+// agent-scope atomics (the same instructions with sc1).
+typedef unsigned uvec4_t __attribute__((ext_vector_type(4)));
+typedef unsigned uvec2_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t pub_rsrc(const void* base)
+{
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, 0x7fffffff, 0x00020000);
+}
+template <typename V> __device__ __forceinline__ void pub_store16(__amdgpu_buffer_rsrc_t r, int byte_off, V v)
+{
+    static_assert(sizeof(V) == 16, "16-byte vectors");
+    uvec4_t u; __builtin_memcpy(&u, &v, 16);
+    __builtin_amdgcn_raw_buffer_store_b128(u, r, byte_off, 0, 16);
+}
+template <typename V> __device__ __forceinline__ V pub_load16(__amdgpu_buffer_rsrc_t r, int byte_off)
+{
+    static_assert(sizeof(V) == 16, "16-byte vectors");
+    const uvec4_t u = __builtin_amdgcn_raw_buffer_load_b128(r, byte_off, 0, 16);
+    V v; __builtin_memcpy(&v, &u, 16); return v;
+}
+template <typename T> __device__ __forceinline__ T pub_load1(__amdgpu_buffer_rsrc_t r, int byte_off)
+{
+    T v;
+    if constexpr (sizeof(T) == 8) { const uvec2_t u = __builtin_amdgcn_raw_buffer_load_b64(r, byte_off, 0, 16); __builtin_memcpy(&v, &u, 8); }
+    else { const unsigned u = __builtin_amdgcn_raw_buffer_load_b32(r, byte_off, 0, 16); __builtin_memcpy(&v, &u, 4); }
+    return v;
+}
+__device__ __forceinline__ void pub_drain() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+__device__ __forceinline__ int32_t pub_get(const int32_t* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ int64_t pub_get(const int64_t* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ double pub_get(const double* p)
+{
+    return __longlong_as_double(__hip_atomic_load(reinterpret_cast<const long long*>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+}
+__device__ __forceinline__ void pub_put(int32_t* p, int32_t v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void pub_put(int64_t* p, int64_t v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void pub_put(double* p, double v)
+{
+    __hip_atomic_store(reinterpret_cast<long long*>(p), __double_as_longlong(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
 __device__ __forceinline__ double dev_tan(double a) { return ::tan(a); }
 __device__ __forceinline__ float dev_tan(float a) { return ::tanf(a); }
 __device__ __forceinline__ double dev_hypot(double a, double b) { return ::hypot(a, b); }
 __device__ __forceinline__ float dev_hypot(float a, float b) { return ::hypotf(a, b); }
 __device__ __forceinline__ double dev_atan2(double a, double b) { return ::atan2(a, b); }
 __device__ __forceinline__ float dev_atan2(float a, float b) { return ::atan2f(a, b); }
+
+// ------------------------------------------------------------------------------------
+// full_trace, stage B: per bundle, exclusive scan of the tile survivor counts (tile_off, FT_FULL route; may be
+// null) and the bundle aggregates (count, centroid, max radius).  One workgroup per bundle; fixed shapes:
+// bitwise reproducible.
+// ------------------------------------------------------------------------------------
+struct FtBundleAgg {
+    int64_t m;        // survivors (first half)
+    double mux, muy;  // centroid of the mirrored set  (PupilSampling.jl:171)
+    double rmax;      // maximum(r)                    (:142)
+    double sq;        // sum of squared deviations (filled by k_ft_finalize)
+};
+
+struct FtScanShared { int64_t w[kBlock / 64]; double rx[kBlock], ry[kBlock], rm[kBlock]; };
+
+// bundle b, by kBlock threads tid = 0 .. kBlock-1 of a workgroup (also the first stage of k_ft_small_finish, where the
+// workgroup holds more threads: those pass active = false and only keep the barriers company)
+// PUB: inside the fused launch — the tile words were published by other workgroups of this launch, and the offsets and the
+// aggregates written here are read by others: every access a pub_get / pub_put (the caller drains and signals)
+template <bool PUB = false>
+__device__ __forceinline__ void ft_scan_body(int b, const int32_t* tile_cnt, const double* tile_sx, const double* tile_sy,
+                                             const double* tile_rmax, int tiles_per_bundle,
+                                             int64_t* tile_off, FtBundleAgg* agg, FtScanShared& sh, int tid, bool active)
+{
+    auto get = [](auto* q) { if constexpr (PUB) return pub_get(q); else return *q; };
+    // thread t owns the contiguous chunk of `per` tiles [t per, (t+1) per): a serial pass for its total, ONE block
+    // scan of the 256 totals, a serial pass writing the offsets — two passes and one scan whatever the tile count
+    // (8192 tiles per bundle at 2048^2: 32 per thread), where a block-wide scan per 256 tiles took 32 rounds
+    int64_t* s_w = sh.w; double* s_rx = sh.rx; double* s_ry = sh.ry; double* s_rm = sh.rm;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int64_t base = (int64_t)b * tiles_per_bundle;
+    const int per = (tiles_per_bundle + kBlock - 1) / kBlock;
+    const int t0 = tid * per, t1 = active ? min(tiles_per_bundle, t0 + per) : t0;
+    int64_t mine = 0;
+    double ax = 0.0, ay = 0.0, mx = -1.0;
+    for (int t = t0; t < t1; ++t) {
+        mine += get(tile_cnt + base + t);
+        ax += get(tile_sx + base + t); ay += get(tile_sy + base + t); mx = fmax(mx, get(tile_rmax + base + t));
+    }
+    int64_t v = mine;                                            // inclusive wave scan of the per-thread totals
+    for (int off = 1; off < 64; off <<= 1) {
+        const int64_t nbv = __shfl_up(v, off);
+        if (lane >= off) v += nbv;
+    }
+    if (active) {
+        if (lane == 63) s_w[wave] = v;
+        s_rx[tid] = ax; s_ry[tid] = ay; s_rm[tid] = mx;
+    }
+    __syncthreads();
+    int64_t woff = 0, total = 0;
+    for (int w = 0; w < kBlock / 64; ++w) { woff += (w < wave) ? s_w[w] : 0; total += s_w[w]; }
+    if (tile_off) {
+        int64_t o = woff + v - mine;                             // exclusive offset of this thread's first tile
+        for (int t = t0; t < t1; ++t) {
+            if constexpr (PUB) pub_put(tile_off + base + t, o); else tile_off[base + t] = o;
+            o += get(tile_cnt + base + t);
+        }
+    }
+    // deterministic tree over the 256 per-thread partials
+    for (int off = kBlock / 2; off > 0; off >>= 1) {
+        if (active && tid < off) { s_rx[tid] += s_rx[tid + off]; s_ry[tid] += s_ry[tid + off]; s_rm[tid] = fmax(s_rm[tid], s_rm[tid + off]); }
+        __syncthreads();
+    }
+    if (active && tid == 0) {
+        const int64_t m = total;
+        FtBundleAgg a;
+        a.m = m;
+        // mean of [ex; -ex] and of [ey; ey] over n = 2m entries
+        a.mux = m ? (s_rx[0] + (-s_rx[0])) / (double)(2 * m) : 0.0;
+        a.muy = m ? (s_ry[0] + s_ry[0]) / (double)(2 * m) : 0.0;
+        a.rmax = s_rm[0];
+        a.sq = 0.0;
+        if constexpr (PUB) {
+            pub_put(&agg[b].m, a.m); pub_put(&agg[b].mux, a.mux); pub_put(&agg[b].muy, a.muy); pub_put(&agg[b].rmax, a.rmax);
+            pub_put(&agg[b].sq, a.sq);
+        } else agg[b] = a;
+    }
+}
+
+__global__ __launch_bounds__(kBlock) void k_ft_scan(const int32_t* __restrict__ tile_cnt, const double* __restrict__ tile_sx,
+                                                    const double* __restrict__ tile_sy, const double* __restrict__ tile_rmax,
+                                                    int tiles_per_bundle, int64_t* __restrict__ tile_off, FtBundleAgg* __restrict__ agg)
+{
+    __shared__ FtScanShared sh;
+    ft_scan_body(blockIdx.x, tile_cnt, tile_sx, tile_sy, tile_rmax, tiles_per_bundle, tile_off, agg, sh, threadIdx.x, true);
+}
+
+// ------------------------------------------------------------------------------------
+// full_trace, stage C of the FT_FULL route: one workgroup per tile moves the tile's compacted survivors from its
+// workspace slot to both halves of the bundle's output slab — first half at the tile's exclusive offset (ray
+// order, :134-137), mirror [-ex; ey; rho; pi - theta] at offset m (:139-144), rho = r / maximum(r) (:142) — and
+// sums the squared deviations about the centroid (two-pass sigma, :169-173).  32 B per survivor read (16-byte loads
+// from the 16-byte-aligned slot), staged in LDS, 64 B written as aligned 16-byte streaming stores whatever the parity of
+// the tile's offset and of m (stream_out): the kernel is bound by HBM, and 8-byte accesses ran it at half the store rate.
+// ------------------------------------------------------------------------------------
+template <typename T> struct FtPlaceShared { double wsq[kBlock / 64]; };
+
+// x / d with r = 1 / d (correctly rounded) given: the quotient, its exact remainder, one correction — the correctly
+// rounded quotient (Markstein), three operations per element instead of a division sequence each.
+__device__ __forceinline__ double place_div(double x, double d, double r) { return ieee_div_nofix(x, d, r); }
+__device__ __forceinline__ float place_div(float x, float d, float) { return x / d; }
+
+// One half of a tile's placement: c compacted entries of the four workspace arrays at element `src` go to element `dst` of
+// the four outputs.  The DESTINATION decides the chunking, and at the granularity the memory system writes in: `head`
+// single elements up to the destination's first 128-byte line boundary, then 16-byte non-temporal stores of which every
+// wave-wide instruction covers 8 WHOLE lines, then a tail.  Cut at 16-byte boundaries only, every wave store left a
+// partial line at each end — completed later by its neighbour's partial line — and the pass ran 35 % slower per byte
+// than with every slot full and aligned (ORT_PLACE_DEBUG A/Bs, profiles/r03_place_ab.log: 700 -> 477 us once each tile
+// started on a line).  The loads take whatever alignment that leaves them (the slot is L2-resident: a misaligned 16-byte
+// load costs one extra line per wave).  No staging buffer, no barrier.  FIRST half: also the squared deviations of the
+// mirrored pair about the centroid (:169-173); MIRROR: [-ex; ey; rho; pi - theta] (:139-144).
+template <typename T, bool MIRROR, bool PUB = false>
+__device__ __forceinline__ double place_half(const T* __restrict__ w_ex, const T* __restrict__ w_ey, const T* __restrict__ w_r,
+                                             const T* __restrict__ w_th, int64_t src, T* __restrict__ ex, T* __restrict__ ey,
+                                             T* __restrict__ rho, T* __restrict__ theta, int64_t dst, int c, int tid,
+                                             const FtBundleAgg& a, T rmax, T rinv)
+{
+    constexpr int V = 16 / (int)sizeof(T), L = 128 / (int)sizeof(T);
+    typedef T vec_t __attribute__((ext_vector_type(V)));
+    double sq = 0.0;
+    // PUB (the fused launch): the slot was written by another workgroup of this launch — sc1 loads off the slot's base
+    const __amdgpu_buffer_rsrc_t rx = pub_rsrc(PUB ? w_ex + src : nullptr), ry = pub_rsrc(PUB ? w_ey + src : nullptr),
+                                 rr = pub_rsrc(PUB ? w_r + src : nullptr), rt = pub_rsrc(PUB ? w_th + src : nullptr);
+    auto one = [&](int j) {
+        T vx, vy, vr, vt;
+        if constexpr (PUB) {
+            vx = pub_load1<T>(rx, j * (int)sizeof(T)); vy = pub_load1<T>(ry, j * (int)sizeof(T));
+            vr = pub_load1<T>(rr, j * (int)sizeof(T)); vt = pub_load1<T>(rt, j * (int)sizeof(T));
+        } else { vx = w_ex[src + j]; vy = w_ey[src + j]; vr = w_r[src + j]; vt = w_th[src + j]; }
+        if (!MIRROR) {
+            const double dx1 = (double)vx - a.mux, dx2 = -(double)vx - a.mux, dy = (double)vy - a.muy;
+            sq += (dx1 * dx1 + dx2 * dx2) + (dy * dy + dy * dy);
+        }
+        __builtin_nontemporal_store(MIRROR ? -vx : vx, ex + dst + j);                                   // :141
+        __builtin_nontemporal_store(vy, ey + dst + j);                                                  // :140
+        __builtin_nontemporal_store(place_div(vr, rmax, rinv), rho + dst + j);                          // :142,143
+        __builtin_nontemporal_store(MIRROR ? (T)3.141592653589793 - vt : vt, theta + dst + j);          // :144
+    };
+    // vector stores need the four outputs equally placed inside a 16-byte word (they sit at the same element offset of
+    // equally aligned arrays unless the caller passed odd pointers); the line cut is taken from ex
+    const unsigned mis16 = (unsigned)(reinterpret_cast<uintptr_t>(ex + dst) & 15);
+    const bool same = (reinterpret_cast<uintptr_t>(ey + dst) & 15) == mis16 && (reinterpret_cast<uintptr_t>(rho + dst) & 15) == mis16 &&
+                      (reinterpret_cast<uintptr_t>(theta + dst) & 15) == mis16 && mis16 % sizeof(T) == 0;
+    if (!same) {
+        for (int j = tid; j < c; j += kBlock) one(j);
+        return sq;
+    }
+    const int mis = (int)((reinterpret_cast<uintptr_t>(ex + dst) & 127) / sizeof(T));     // elements past a 128-byte line
+    const int head = min(c, mis ? L - mis : 0);
+    const int nvec = (c - head) / V;
+    if (tid < head) one(tid);
+    for (int g = tid; g < nvec; g += kBlock) {                                            // a wave: 1 KiB from a line boundary
+        const int j = head + g * V;
+        vec_t vx, vy, vr, vt;
+        if constexpr (PUB) {
+            vx = pub_load16<vec_t>(rx, j * (int)sizeof(T)); vy = pub_load16<vec_t>(ry, j * (int)sizeof(T));
+            vr = pub_load16<vec_t>(rr, j * (int)sizeof(T)); vt = pub_load16<vec_t>(rt, j * (int)sizeof(T));
+        } else {
+            __builtin_memcpy(&vx, w_ex + src + j, sizeof(vec_t)); __builtin_memcpy(&vy, w_ey + src + j, sizeof(vec_t));
+            __builtin_memcpy(&vr, w_r + src + j, sizeof(vec_t));  __builtin_memcpy(&vt, w_th + src + j, sizeof(vec_t));
+        }
+        vec_t ox, orr, ot;
+#pragma unroll
+        for (int q = 0; q < V; ++q) {
+            if (!MIRROR) {
+                const double dx1 = (double)vx[q] - a.mux, dx2 = -(double)vx[q] - a.mux, dy = (double)vy[q] - a.muy;
+                sq += (dx1 * dx1 + dx2 * dx2) + (dy * dy + dy * dy);
+            }
+            ox[q] = MIRROR ? -vx[q] : vx[q];
+            orr[q] = place_div(vr[q], rmax, rinv);
+            ot[q] = MIRROR ? (T)3.141592653589793 - vt[q] : vt[q];
+        }
+        __builtin_nontemporal_store(ox, reinterpret_cast<vec_t*>(ex + dst + j));
+        __builtin_nontemporal_store(vy, reinterpret_cast<vec_t*>(ey + dst + j));
+        __builtin_nontemporal_store(orr, reinterpret_cast<vec_t*>(rho + dst + j));
+        __builtin_nontemporal_store(ot, reinterpret_cast<vec_t*>(theta + dst + j));
+    }
+    const int jt = head + nvec * V + tid;                                                 // < V - 1 elements left
+    if (jt < c) one(jt);
+    return sq;
+}
+
+// One tile's placement by kBlock threads: `c` survivors of slot `bid` to element `dst` of the bundle's first half and to
+// dst + m of its mirror half.  Returns this thread's share of the tile's squared deviations.
+template <typename T, bool PUB = false>
+__device__ __forceinline__ double ft_place_tile(int bid, int c, int64_t dst, const FtBundleAgg& a,
+                                                const T* __restrict__ w_ex, const T* __restrict__ w_ey,
+                                                const T* __restrict__ w_r, const T* __restrict__ w_th,
+                                                T* __restrict__ ex, T* __restrict__ ey, T* __restrict__ rho, T* __restrict__ theta,
+                                                int tid)
+{
+    const int64_t src = (int64_t)bid * kTile;                                     // the tile's slot: 16-byte aligned, kTile entries
+    const T rmax = (T)a.rmax, rinv = T(1) / rmax;                                 // r ./ maximum(r)  (:142)
+    const double sq = place_half<T, false, PUB>(w_ex, w_ey, w_r, w_th, src, ex, ey, rho, theta, dst, c, tid, a, rmax, rinv);
+    place_half<T, true, PUB>(w_ex, w_ey, w_r, w_th, src, ex, ey, rho, theta, dst + a.m, c, tid, a, rmax, rinv);
+    return sq;
+}
+
+// The fused launch's placement of one tile (FT_FUSED): what ft_place_tile<T, true> does, element for element and sum for
+// sum, laid out for LATENCY — the workgroup that runs it holds a trace kernel's registers while it waits.  EVERY load of
+// both halves goes out first (a thread owns at most one head element, one 16-byte vector and one tail element per half:
+// kTile / V <= kBlock), then `between()` runs (the caller's publish of its own tile: its wait covers these loads too), then
+// the arithmetic and all the stores; nothing waits for a store.
+template <typename T, typename F>
+__device__ __forceinline__ double ft_place_tile_pub(int bid, int c, int64_t dst, const FtBundleAgg& a,
+                                                    const T* w_ex, const T* w_ey, const T* w_r, const T* w_th,
+                                                    T* __restrict__ ex, T* __restrict__ ey, T* __restrict__ rho, T* __restrict__ theta,
+                                                    int tid, F between)
+{
+    constexpr int V = 16 / (int)sizeof(T), L = 128 / (int)sizeof(T), B = (int)sizeof(T);
+    static_assert(kTile / V <= kBlock, "one vector per thread and half");
+    typedef T vec_t __attribute__((ext_vector_type(V)));
+    const int64_t src = (int64_t)bid * kTile;
+    const T rmax = (T)a.rmax, rinv = T(1) / rmax;                                 // r ./ maximum(r)  (:142)
+    bool same = true;
+    int head[2], nvec[2];
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+        const int64_t d = dst + (q ? a.m : 0);
+        const unsigned mis16 = (unsigned)(reinterpret_cast<uintptr_t>(ex + d) & 15);
+        same = same && (reinterpret_cast<uintptr_t>(ey + d) & 15) == mis16 && (reinterpret_cast<uintptr_t>(rho + d) & 15) == mis16 &&
+               (reinterpret_cast<uintptr_t>(theta + d) & 15) == mis16 && mis16 % sizeof(T) == 0;
+        const int mis = (int)((reinterpret_cast<uintptr_t>(ex + d) & 127) / sizeof(T));
+        head[q] = min(c, mis ? L - mis : 0);
+        nvec[q] = (c - head[q]) / V;
+    }
+    if (!same) {                                                 // odd output pointers: the element-wise path
+        between();
+        return ft_place_tile<T, true>(bid, c, dst, a, w_ex, w_ey, w_r, w_th, ex, ey, rho, theta, tid);
+    }
+    const __amdgpu_buffer_rsrc_t rx = pub_rsrc(w_ex + src), ry = pub_rsrc(w_ey + src), rr = pub_rsrc(w_r + src), rt = pub_rsrc(w_th + src);
+    T hx[2], hy[2], hr[2], ht[2], tx[2], ty[2], tr[2], tt[2];
+    vec_t vx[2], vy[2], vr[2], vt[2];
+    int jv[2], jt[2];
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+        hx[q] = hy[q] = hr[q] = ht[q] = tx[q] = ty[q] = tr[q] = tt[q] = T(0);
+        vx[q] = vy[q] = vr[q] = vt[q] = vec_t(T(0));
+        jv[q] = head[q] + tid * V; jt[q] = head[q] + nvec[q] * V + tid;
+        if (tid < head[q]) { hx[q] = pub_load1<T>(rx, tid * B); hy[q] = pub_load1<T>(ry, tid * B); hr[q] = pub_load1<T>(rr, tid * B); ht[q] = pub_load1<T>(rt, tid * B); }
+        if (tid < nvec[q]) {
+            vx[q] = pub_load16<vec_t>(rx, jv[q] * B); vy[q] = pub_load16<vec_t>(ry, jv[q] * B);
+            vr[q] = pub_load16<vec_t>(rr, jv[q] * B); vt[q] = pub_load16<vec_t>(rt, jv[q] * B);
+        }
+        if (jt[q] < c) { tx[q] = pub_load1<T>(rx, jt[q] * B); ty[q] = pub_load1<T>(ry, jt[q] * B); tr[q] = pub_load1<T>(rr, jt[q] * B); tt[q] = pub_load1<T>(rt, jt[q] * B); }
+    }
+    between();
+    double sq = 0.0;
+    auto dev2 = [&](T x, T y) {                                  // the mirrored pair about the centroid (:169-173), as place_half takes it
+        const double dx1 = (double)x - a.mux, dx2 = -(double)x - a.mux, dy = (double)y - a.muy;
+        sq += (dx1 * dx1 + dx2 * dx2) + (dy * dy + dy * dy);
+    };
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+        const int64_t d = dst + (q ? a.m : 0);
+        const bool mir = q == 1;
+        auto one = [&](int j, T x, T y, T r, T t) {
+            if (!mir) dev2(x, y);
+            __builtin_nontemporal_store(mir ? -x : x, ex + d + j);                                      // :141
+            __builtin_nontemporal_store(y, ey + d + j);                                                 // :140
+            __builtin_nontemporal_store(place_div(r, rmax, rinv), rho + d + j);                         // :142,143
+            __builtin_nontemporal_store(mir ? (T)3.141592653589793 - t : t, theta + d + j);             // :144
+        };
+        if (tid < head[q]) one(tid, hx[q], hy[q], hr[q], ht[q]);
+        if (tid < nvec[q]) {
+            vec_t ox, orr, ot;
+#pragma unroll
+            for (int e = 0; e < V; ++e) {
+                if (!mir) dev2(vx[q][e], vy[q][e]);
+                ox[e] = mir ? -vx[q][e] : vx[q][e];
+                orr[e] = place_div(vr[q][e], rmax, rinv);
+                ot[e] = mir ? (T)3.141592653589793 - vt[q][e] : vt[q][e];
+            }
+            __builtin_nontemporal_store(ox, reinterpret_cast<vec_t*>(ex + d + jv[q]));
+            __builtin_nontemporal_store(vy[q], reinterpret_cast<vec_t*>(ey + d + jv[q]));
+            __builtin_nontemporal_store(orr, reinterpret_cast<vec_t*>(rho + d + jv[q]));
+            __builtin_nontemporal_store(ot, reinterpret_cast<vec_t*>(theta + d + jv[q]));
+        }
+        if (jt[q] < c) one(jt[q], tx[q], ty[q], tr[q], tt[q]);
+    }
+    return sq;
+}
+
+// tile `bid` (= bundle * tiles_per_bundle + tile), by kBlock threads tid = 0 .. kBlock-1 of a workgroup: the second stage of
+// k_ft_small_finish, whose workgroup places four tiles at a time; active = false: no tile for this group
+template <typename T>
+__device__ __forceinline__ void ft_place_body(int bid, const T* __restrict__ w_ex, const T* __restrict__ w_ey,
+                                              const T* __restrict__ w_r, const T* __restrict__ w_th,
+                                              int64_t rpb, int tiles_per_bundle,
+                                              const int32_t* __restrict__ tile_cnt, const int64_t* __restrict__ tile_off,
+                                              const FtBundleAgg* __restrict__ agg,
+                                              T* __restrict__ ex, T* __restrict__ ey,
+                                              T* __restrict__ rho, T* __restrict__ theta,
+                                              double* __restrict__ tile_sq, FtPlaceShared<T>& sh, int tid, bool active)
+{
+    double* s_wsq = sh.wsq;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int b = active ? bid / tiles_per_bundle : 0;
+    const int c = active ? tile_cnt[bid] : 0;
+    const FtBundleAgg a = agg[b];
+    const int64_t dst = (int64_t)b * 2 * rpb + (active ? tile_off[bid] : 0);
+    double sq = ft_place_tile<T>(bid, c, dst, a, w_ex, w_ey, w_r, w_th, ex, ey, rho, theta, tid);
+    for (int off = 32; off > 0; off >>= 1) sq += __shfl_down(sq, off);
+    if (lane == 0) s_wsq[wave] = sq;
+    __syncthreads();
+    if (active && tid == 0) {
+        double t = 0.0;
+        for (int w = 0; w < kBlock / 64; ++w) t += s_wsq[w];
+        tile_sq[bid] = t;
+    }
+}
 
 // ------------------------------------------------------------------------------------
 // The hot kernel.  GRID: rays generated from bundle axes; otherwise read from lists.
@@ -221,7 +587,7 @@ __device__ __forceinline__ float dev_atan2(float a, float b) { return ::atan2f(a
 //                chip full) nor on what else is in the launch.  Per workgroup — not per tile — is what a one-tile-per-
 //                workgroup route pays: staging + three dependent round trips before the first ray moves, 1.28 M times on
 //                BASELINE config 5 (profiles/r04_ab_walk_tiles_per_workgroup.log).
-enum { FT_NONE = 0, FT_FULL = 1, FT_WALK1 = 2, FT_LOOKBACK = 3, FT_WALK = 4 };   // FT_WALK1: FT_WALK with spans of ONE tile (compile-time: the
+enum { FT_NONE = 0, FT_FULL = 1, FT_WALK1 = 2, FT_LOOKBACK = 3, FT_WALK = 4, FT_FUSED = 5 };   // FT_WALK1: FT_WALK with spans of ONE tile (compile-time: the
                                                                                // span test of the long-span kernel stays a constant)
 #ifndef ORT_WALK_TILES
 #define ORT_WALK_TILES 8     // tiles per span of the FT_WALK route for bundles of more than kSmallTiles tiles (a power of two)
@@ -258,14 +624,18 @@ void k_trace(TraceParams<T> p)   // both outputs, look-back epilogue, Float64 ru
     __shared__ int s_wcnt[NT / 64];
     __shared__ double s_wsx[kSumWaves], s_wsy[kSumWaves], s_wmax[NT / 64];
     __shared__ double s_px[RPT == 1 ? NT / 64 : 1][32], s_py[RPT == 1 ? NT / 64 : 1][32];   // RPT = 1: pair sums (tile_sum2)
+    __shared__ __attribute__((aligned(16))) T s_c[4][(FT == FT_FULL || FT == FT_LOOKBACK || FT == FT_FUSED) ? kTile : 1];   // a tile's compacted survivors
 
     const int tid = threadIdx.x;
     const int S = p.S;
     ORT_PHASE(8);
     // FT_LOOKBACK: the tile index is a TICKET, not blockIdx — the look-back below waits on tiles with lower indices,
     // and a ticket order guarantees they are running or done whatever order the hardware dispatches blocks in
-    constexpr bool kCompact = FT == FT_FULL || FT == FT_LOOKBACK;
+    constexpr bool FUSED = FT == FT_FUSED;
+    constexpr bool kCompact = FT == FT_FULL || FT == FT_LOOKBACK || FUSED;
     __shared__ unsigned s_bid;
+    __shared__ int s_arrive;                                     // FT_FUSED: waves of this workgroup whose stores have left
+    if (FUSED && tid == 0) s_arrive = 0;                         // (read after the table's barrier at the earliest)
     if (FT == FT_LOOKBACK) {
         if (tid == 0) {
 #if ORT_FT_DEBUG & 2            /* A/B only: blockIdx order instead of tickets (no progress guarantee) */
@@ -286,6 +656,16 @@ void k_trace(TraceParams<T> p)   // both outputs, look-back epilogue, Float64 ru
         __syncthreads();
     }
     const unsigned bid = (FT == FT_LOOKBACK) ? s_bid : blockIdx.x;
+    // FT_FUSED: the launch holds fuse_lag workgroups past the last tile; they trace nothing and place the last tiles
+    const bool tracing = !FUSED || bid < (unsigned)p.fuse_ntiles;
+    // FT_FUSED: the tile this workgroup places once it has traced its own (pj), and — read beside the bundle record and the
+    // table, in their round trips — whether that tile's bundle is published yet and, if so, the tile's count and offset and
+    // the bundle's aggregates (wave-uniform: kept in scalar registers across the trace)
+    const int64_t pj = FUSED ? (int64_t)bid - p.fuse_lag : -1;
+    const bool placing = FUSED && pj >= 0 && pj < p.fuse_ntiles;
+    const int pb = placing ? (int)(pj / p.tiles_per_bundle) : 0;
+    unsigned pf_rdy = 0;
+    if constexpr (FUSED) if (placing) pf_rdy = __hip_atomic_load(p.ft_ready + pb, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     int sysid, b = 0;
     int64_t j0;          // first ray of this thread inside its bundle / list
     int64_t gbase;       // global index of ray j0
@@ -306,9 +686,11 @@ void k_trace(TraceParams<T> p)   // both outputs, look-back epilogue, Float64 ru
             b = bid / groups;
             tile = (bid - b * groups) * p.walk_group;
             walk_n = min(p.walk_group, p.tiles_per_bundle - tile);
-        } else {
+        } else if (tracing) {
             b = bid / p.tiles_per_bundle;
             tile = bid - b * p.tiles_per_bundle;
+        } else {
+            b = 0; tile = 0; walk_n = 0;
         }
         tile_base = (unsigned)tile * (unsigned)kTile;
         sysid = p.bundles[b].system;
@@ -327,7 +709,28 @@ void k_trace(TraceParams<T> p)   // both outputs, look-back epilogue, Float64 ru
     typedef const __attribute__((address_space(4))) T* CApPtr;  // wave-uniform address: scalar loads
     const CApPtr gap2 = (ORT_APERTURES && (SUMM || FT) && p.apert2) ? (CApPtr)(uintptr_t)(p.apert2 + (int64_t)sysid * S) : (CApPtr)0;
 
-    {
+    bool pf_ok = false;
+    int pf_c = 0; int64_t pf_off = 0, pf_m = 0; double pf_mux = 0.0, pf_muy = 0.0, pf_rmax = 0.0;
+    auto fetch_placement = [&]() {                               // behind a ready word that matched: sc1 loads
+        pf_c = pub_get(p.tile_cnt + pj); pf_off = pub_get(p.tile_off + pj);
+        pf_m = pub_get(&p.agg[pb].m); pf_mux = pub_get(&p.agg[pb].mux); pf_muy = pub_get(&p.agg[pb].muy); pf_rmax = pub_get(&p.agg[pb].rmax);
+    };
+    auto uniform_placement = [&]() {                             // the same value in every lane -> scalar registers
+        auto u64 = [](unsigned long long v) {
+            const unsigned lo = (unsigned)__builtin_amdgcn_readfirstlane((int)(v & 0xffffffffull)), hi = (unsigned)__builtin_amdgcn_readfirstlane((int)(v >> 32));
+            return ((unsigned long long)hi << 32) | lo;
+        };
+        pf_c = __builtin_amdgcn_readfirstlane(pf_c);
+        pf_off = (int64_t)u64((unsigned long long)pf_off); pf_m = (int64_t)u64((unsigned long long)pf_m);
+        pf_mux = __longlong_as_double((long long)u64((unsigned long long)__double_as_longlong(pf_mux)));
+        pf_muy = __longlong_as_double((long long)u64((unsigned long long)__double_as_longlong(pf_muy)));
+        pf_rmax = __longlong_as_double((long long)u64((unsigned long long)__double_as_longlong(pf_rmax)));
+    };
+    if constexpr (FUSED) {
+        pf_ok = placing && pf_rdy == p.ft_epoch;
+        if (pf_ok) fetch_placement();
+    }
+    if (tracing) {                                               // (workgroup-uniform)
         // stage this system's table: S records of sizeof(SurfRec<T>) bytes, as 16-B words
         constexpr int kW = sizeof(SurfRec<T>) / 16;
         const uint4* src = reinterpret_cast<const uint4*>(grec);
@@ -343,6 +746,7 @@ void k_trace(TraceParams<T> p)   // both outputs, look-back epilogue, Float64 ru
         }
         __syncthreads();
     }
+    if constexpr (FUSED) if (pf_ok) uniform_placement();
 
     // FT_WALK: this lane's survivors so far — their number and the sums of (ex - Kx), (ey - Ky) and of their squares, (Kx, Ky) =
     // the FIRST survivor its wave meets (wave-uniform: scalar registers): every term is of the size of the spot, so nothing
@@ -652,7 +1056,7 @@ void k_trace(TraceParams<T> p)   // both outputs, look-back epilogue, Float64 ru
             tile_sum2(sx, sy);
             __syncthreads();
             if (kCompact) {
-                __shared__ __attribute__((aligned(16))) T s_cx[kCompact ? kTile : 1], s_cy[kCompact ? kTile : 1], s_cr[kCompact ? kTile : 1], s_ct[kCompact ? kTile : 1];
+                T* const s_cx = s_c[0]; T* const s_cy = s_c[1]; T* const s_cr = s_c[2]; T* const s_ct = s_c[3];
                 __shared__ long long s_base;
                 int woff = 0, c = 0;
                 for (int w = 0; w < NT / 64; ++w) { woff += (w < wave) ? s_wcnt[w] : 0; c += s_wcnt[w]; }
@@ -661,12 +1065,15 @@ void k_trace(TraceParams<T> p)   // both outputs, look-back epilogue, Float64 ru
                 for (int r = 0; r < RPT; ++r)
                     if (keep[r]) { s_cx[k] = exv[r]; s_cy[k] = eyv[r]; s_cr[k] = rv[r]; s_ct[k] = thv[r]; ++k; }
                 const int tile = (int)(bid - (unsigned)b * (unsigned)p.tiles_per_bundle);
-                if (FT == FT_FULL) {
+                if (FT == FT_FULL || FUSED) {
                     if (tid == 0) {
                         double ax = 0.0, ay = 0.0, mx = -1.0;
                         for (int w = 0; w < kSumWaves; ++w) { ax += s_wsx[w]; ay += s_wsy[w]; }
                         for (int w = 0; w < NT / 64; ++w) mx = fmax(mx, s_wmax[w]);
-                        p.tile_cnt[bid] = c; p.tile_sx[bid] = ax; p.tile_sy[bid] = ay; p.tile_rmax[bid] = mx;
+                        if constexpr (FUSED) {                       // read by another workgroup of this launch (the bundle's scan)
+                            pub_put(p.tile_cnt + bid, (int32_t)c); pub_put(p.tile_sx + bid, ax); pub_put(p.tile_sy + bid, ay);
+                            pub_put(p.tile_rmax + bid, mx);
+                        } else { p.tile_cnt[bid] = c; p.tile_sx[bid] = ax; p.tile_sy[bid] = ay; p.tile_rmax[bid] = mx; }
                     }
                 } else if (wave == 0) {
                     // Exclusive offset of this tile among its bundle's survivors: decoupled look-back (Merrill & Garland) over
@@ -731,12 +1138,22 @@ void k_trace(TraceParams<T> p)   // both outputs, look-back epilogue, Float64 ru
                     }
                 }
                 __syncthreads();
-                if (FT == FT_FULL) {
+                if (FT == FT_FULL || FUSED) {
                     // the tile's own slot of the workspace [tiles][kTile]: 16-byte aligned, so whole vectors go out (the
                     // entries past c inside the slot are never read)
                     constexpr int V = 16 / (int)sizeof(T);
                     typedef T vec_t __attribute__((ext_vector_type(V)));
                     const int64_t o0 = (int64_t)bid * kTile;
+                    if constexpr (FUSED) {                           // write-through: another workgroup of this launch places the slot
+                        const __amdgpu_buffer_rsrc_t rx = pub_rsrc(p.out_ex + o0), ry = pub_rsrc(p.out_ey + o0),
+                                                     rr = pub_rsrc(p.out_r + o0), rt = pub_rsrc(p.out_th + o0);
+                        for (int j = tid * V; j < c; j += NT * V) {
+                            pub_store16(rx, j * (int)sizeof(T), *reinterpret_cast<const vec_t*>(s_cx + j));
+                            pub_store16(ry, j * (int)sizeof(T), *reinterpret_cast<const vec_t*>(s_cy + j));
+                            pub_store16(rr, j * (int)sizeof(T), *reinterpret_cast<const vec_t*>(s_cr + j));
+                            pub_store16(rt, j * (int)sizeof(T), *reinterpret_cast<const vec_t*>(s_ct + j));
+                        }
+                    } else
                     for (int j = tid * V; j < c; j += NT * V) {
                         *reinterpret_cast<vec_t*>(p.out_ex + o0 + j) = *reinterpret_cast<const vec_t*>(s_cx + j);
                         *reinterpret_cast<vec_t*>(p.out_ey + o0 + j) = *reinterpret_cast<const vec_t*>(s_cy + j);
@@ -750,6 +1167,96 @@ void k_trace(TraceParams<T> p)   // both outputs, look-back epilogue, Float64 ru
                     stream_out<T>(p.out_ex + o0, s_cx, c, tid, same); stream_out<T>(p.out_ey + o0, s_cy, c, tid, same);
                     stream_out<T>(p.out_r + o0, s_cr, c, tid, same);  stream_out<T>(p.out_th + o0, s_ct, c, tid, same);
                 }
+            }
+        }
+    }
+    if constexpr (FUSED) {
+        // FT_FUSED: the second pass (HBM-bound) inside the trace launch (FP64-issue-bound).  Workgroup i has traced tile i into
+        // its workspace slot; it now (1) publishes the tile — the workgroup that completes a bundle runs k_ft_scan's body for it
+        // and raises the bundle's ready word — and (2) places tile i - fuse_lag, fuse_lag = tiles_per_bundle + a margin: that
+        // tile's bundle was complete `margin` workgroups ago, so the wait below is a safety net, not a queue.  A workgroup only
+        // ever waits for workgroups with LOWER indices (dispatched before it): no cycle; the poll cap raises the fault word
+        // and the call returns an error instead of hanging.  Same bodies as k_ft_scan / k_ft_place: same bits.
+        static_assert(!FUSED || RPT == kRPT, "FT_FUSED: kBlock threads per workgroup");
+        __shared__ int s_go;
+        const int tpb = p.tiles_per_bundle;
+        const int lane = tid & 63, wave = tid >> 6;
+        // (1) publish this workgroup's own tile, wave by wave: a wave whose sc1 stores have left (its wait covers the placement's
+        // loads below too) counts itself in, and the wave that comes last adds the tile to its bundle's count — nobody waits
+        // for an answer, and no barrier holds a wave that is done
+        auto publish = [&]() {
+            if (!tracing) return;
+            pub_drain();
+            if (lane == 0 && atomicAdd(&s_arrive, 1) == kBlock / 64 - 1)
+                __hip_atomic_fetch_add(p.ft_done + b, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        };
+        // (2) place tile pj
+        bool published = false;
+        if (placing) {                                           // (workgroup-uniform)
+            // each wave read the ready word for itself when the workgroup started: only the workgroup's barrier makes one answer
+            __shared__ int s_ok[kBlock / 64];
+            if (lane == 0) s_ok[wave] = pf_ok;
+            __syncthreads();
+            bool all_ok = true;
+            for (int w = 0; w < kBlock / 64; ++w) all_ok = all_ok && s_ok[w] != 0;
+            if (!all_ok) {                                       // (workgroup-uniform) not published when some wave looked
+                publish(); published = true;                     // (its own tile first: the wait below may be long)
+                if (tid == 0) {
+                    bool got = false;
+                    for (int spin = 0; spin < p.fuse_spin_cap && !got; ++spin) {
+                        got = __hip_atomic_load(p.ft_ready + pb, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == p.ft_epoch;
+                        if (!got) {
+                            if ((spin & 255) == 255 && __hip_atomic_load(p.ft_err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) break;
+                            __builtin_amdgcn_s_sleep(4);
+                        }
+                    }
+                    if (!got) atomicOr(p.ft_err, 1);
+                    s_go = got;
+                }
+                __syncthreads();
+                if (s_go != 0 && !pf_ok) {                       // (per wave) the waves that have not read the tile's words yet
+                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");      // (no instruction: the loads below stay below the poll)
+                    fetch_placement(); uniform_placement();
+                }
+                pf_ok = s_go != 0;
+            }
+            if (pf_ok) {
+                FtBundleAgg a;
+                a.m = pf_m; a.mux = pf_mux; a.muy = pf_muy; a.rmax = pf_rmax; a.sq = 0.0;
+                const int64_t dst = (int64_t)pb * 2 * p.rpb + pf_off;
+                double sq = ft_place_tile_pub<T>((int)pj, pf_c, dst, a, p.out_ex, p.out_ey, p.out_r, p.out_th,
+                                                 p.fin_ex, p.fin_ey, p.fin_rho, p.fin_th, tid,
+                                                 [&]() { if (!published) { publish(); published = true; } });
+                for (int o = 32; o > 0; o >>= 1) sq += __shfl_down(sq, o);
+                if (lane == 0) p.tile_sq[pj * (kBlock / 64) + wave] = sq;       // k_ft_finalize<kBlock / 64> folds the waves in order
+            }
+        }
+        if (!published) publish();
+        // (3) the workgroup fuse_scan_lag - 1 past the last tile of a bundle runs that bundle's scan (k_ft_scan's body) once the
+        // bundle's count is complete, and raises its ready word
+        const int64_t sq0 = (int64_t)bid - (p.fuse_scan_lag - 1);                // = (bundle + 1) * tpb for such a workgroup
+        if (sq0 > 0 && sq0 % tpb == 0 && sq0 <= p.fuse_ntiles) {                 // (workgroup-uniform)
+            const int sb = (int)(sq0 / tpb) - 1;
+            if (tid == 0) {
+                bool got = false;
+                for (int spin = 0; spin < p.fuse_spin_cap && !got; ++spin) {
+                    got = pub_get(p.ft_done + sb) == tpb;
+                    if (!got) {
+                        if ((spin & 255) == 255 && __hip_atomic_load(p.ft_err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) break;
+                        __builtin_amdgcn_s_sleep(4);
+                    }
+                }
+                if (!got) atomicOr(p.ft_err, 1);
+                s_go = got;
+            }
+            __syncthreads();
+            if (s_go) {
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                ft_scan_body<true>(sb, p.tile_cnt, p.tile_sx, p.tile_sy, p.tile_rmax, tpb, p.tile_off, p.agg,
+                                   *reinterpret_cast<FtScanShared*>(&s_c[0][0]), tid, true);
+                pub_drain();
+                __syncthreads();
+                if (tid == 0) __hip_atomic_store(p.ft_ready + sb, p.ft_epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
         }
     }
@@ -835,214 +1342,6 @@ __global__ __launch_bounds__(kBlock) void k_ft_stats_reduce_wave(const int32_t* 
     if (lane == 0) {
         count[b] = 2 * (int64_t)m.n;
         rms[b] = m.n > 0.0 ? sqrt(((m.qx + m.n * m.mx * m.mx) + m.qy) / m.n) : __builtin_nan("");
-    }
-}
-
-// ------------------------------------------------------------------------------------
-// full_trace, stage B: per bundle, exclusive scan of the tile survivor counts (tile_off, FT_FULL route; may be
-// null) and the bundle aggregates (count, centroid, max radius).  One workgroup per bundle; fixed shapes:
-// bitwise reproducible.
-// ------------------------------------------------------------------------------------
-struct FtBundleAgg {
-    int64_t m;        // survivors (first half)
-    double mux, muy;  // centroid of the mirrored set  (PupilSampling.jl:171)
-    double rmax;      // maximum(r)                    (:142)
-    double sq;        // sum of squared deviations (filled by k_ft_finalize)
-};
-
-struct FtScanShared { int64_t w[kBlock / 64]; double rx[kBlock], ry[kBlock], rm[kBlock]; };
-
-// bundle b, by kBlock threads tid = 0 .. kBlock-1 of a workgroup (also the first stage of k_ft_small_finish, where the
-// workgroup holds more threads: those pass active = false and only keep the barriers company)
-__device__ __forceinline__ void ft_scan_body(int b, const int32_t* __restrict__ tile_cnt,
-                                             const double* __restrict__ tile_sx,
-                                             const double* __restrict__ tile_sy,
-                                             const double* __restrict__ tile_rmax,
-                                             int tiles_per_bundle,
-                                             int64_t* __restrict__ tile_off,
-                                             FtBundleAgg* __restrict__ agg, FtScanShared& sh, int tid, bool active)
-{
-    // thread t owns the contiguous chunk of `per` tiles [t per, (t+1) per): a serial pass for its total, ONE block
-    // scan of the 256 totals, a serial pass writing the offsets — two passes and one scan whatever the tile count
-    // (8192 tiles per bundle at 2048^2: 32 per thread), where a block-wide scan per 256 tiles took 32 rounds
-    int64_t* s_w = sh.w; double* s_rx = sh.rx; double* s_ry = sh.ry; double* s_rm = sh.rm;
-    const int lane = tid & 63, wave = tid >> 6;
-    const int64_t base = (int64_t)b * tiles_per_bundle;
-    const int per = (tiles_per_bundle + kBlock - 1) / kBlock;
-    const int t0 = tid * per, t1 = active ? min(tiles_per_bundle, t0 + per) : t0;
-    int64_t mine = 0;
-    double ax = 0.0, ay = 0.0, mx = -1.0;
-    for (int t = t0; t < t1; ++t) {
-        mine += tile_cnt[base + t];
-        ax += tile_sx[base + t]; ay += tile_sy[base + t]; mx = fmax(mx, tile_rmax[base + t]);
-    }
-    int64_t v = mine;                                            // inclusive wave scan of the per-thread totals
-    for (int off = 1; off < 64; off <<= 1) {
-        const int64_t nbv = __shfl_up(v, off);
-        if (lane >= off) v += nbv;
-    }
-    if (active) {
-        if (lane == 63) s_w[wave] = v;
-        s_rx[tid] = ax; s_ry[tid] = ay; s_rm[tid] = mx;
-    }
-    __syncthreads();
-    int64_t woff = 0, total = 0;
-    for (int w = 0; w < kBlock / 64; ++w) { woff += (w < wave) ? s_w[w] : 0; total += s_w[w]; }
-    if (tile_off) {
-        int64_t o = woff + v - mine;                             // exclusive offset of this thread's first tile
-        for (int t = t0; t < t1; ++t) { tile_off[base + t] = o; o += tile_cnt[base + t]; }
-    }
-    // deterministic tree over the 256 per-thread partials
-    for (int off = kBlock / 2; off > 0; off >>= 1) {
-        if (active && tid < off) { s_rx[tid] += s_rx[tid + off]; s_ry[tid] += s_ry[tid + off]; s_rm[tid] = fmax(s_rm[tid], s_rm[tid + off]); }
-        __syncthreads();
-    }
-    if (active && tid == 0) {
-        const int64_t m = total;
-        FtBundleAgg a;
-        a.m = m;
-        // mean of [ex; -ex] and of [ey; ey] over n = 2m entries
-        a.mux = m ? (s_rx[0] + (-s_rx[0])) / (double)(2 * m) : 0.0;
-        a.muy = m ? (s_ry[0] + s_ry[0]) / (double)(2 * m) : 0.0;
-        a.rmax = s_rm[0];
-        a.sq = 0.0;
-        agg[b] = a;
-    }
-}
-
-__global__ __launch_bounds__(kBlock) void k_ft_scan(const int32_t* __restrict__ tile_cnt, const double* __restrict__ tile_sx,
-                                                    const double* __restrict__ tile_sy, const double* __restrict__ tile_rmax,
-                                                    int tiles_per_bundle, int64_t* __restrict__ tile_off, FtBundleAgg* __restrict__ agg)
-{
-    __shared__ FtScanShared sh;
-    ft_scan_body(blockIdx.x, tile_cnt, tile_sx, tile_sy, tile_rmax, tiles_per_bundle, tile_off, agg, sh, threadIdx.x, true);
-}
-
-// ------------------------------------------------------------------------------------
-// full_trace, stage C of the FT_FULL route: one workgroup per tile moves the tile's compacted survivors from its
-// workspace slot to both halves of the bundle's output slab — first half at the tile's exclusive offset (ray
-// order, :134-137), mirror [-ex; ey; rho; pi - theta] at offset m (:139-144), rho = r / maximum(r) (:142) — and
-// sums the squared deviations about the centroid (two-pass sigma, :169-173).  32 B per survivor read (16-byte loads
-// from the 16-byte-aligned slot), staged in LDS, 64 B written as aligned 16-byte streaming stores whatever the parity of
-// the tile's offset and of m (stream_out): the kernel is bound by HBM, and 8-byte accesses ran it at half the store rate.
-// ------------------------------------------------------------------------------------
-template <typename T> struct FtPlaceShared { double wsq[kBlock / 64]; };
-
-// x / d with r = 1 / d (correctly rounded) given: the quotient, its exact remainder, one correction — the correctly
-// rounded quotient (Markstein), three operations per element instead of a division sequence each.
-__device__ __forceinline__ double place_div(double x, double d, double r) { return ieee_div_nofix(x, d, r); }
-__device__ __forceinline__ float place_div(float x, float d, float) { return x / d; }
-
-// One half of a tile's placement: c compacted entries of the four workspace arrays at element `src` go to element `dst` of
-// the four outputs.  The DESTINATION decides the chunking, and at the granularity the memory system writes in: `head`
-// single elements up to the destination's first 128-byte line boundary, then 16-byte non-temporal stores of which every
-// wave-wide instruction covers 8 WHOLE lines, then a tail.  Cut at 16-byte boundaries only, every wave store left a
-// partial line at each end — completed later by its neighbour's partial line — and the pass ran 35 % slower per byte
-// than with every slot full and aligned (ORT_PLACE_DEBUG A/Bs, profiles/r03_place_ab.log: 700 -> 477 us once each tile
-// started on a line).  The loads take whatever alignment that leaves them (the slot is L2-resident: a misaligned 16-byte
-// load costs one extra line per wave).  No staging buffer, no barrier.  FIRST half: also the squared deviations of the
-// mirrored pair about the centroid (:169-173); MIRROR: [-ex; ey; rho; pi - theta] (:139-144).
-template <typename T, bool MIRROR>
-__device__ __forceinline__ double place_half(const T* __restrict__ w_ex, const T* __restrict__ w_ey, const T* __restrict__ w_r,
-                                             const T* __restrict__ w_th, int64_t src, T* __restrict__ ex, T* __restrict__ ey,
-                                             T* __restrict__ rho, T* __restrict__ theta, int64_t dst, int c, int tid,
-                                             const FtBundleAgg& a, T rmax, T rinv)
-{
-    constexpr int V = 16 / (int)sizeof(T), L = 128 / (int)sizeof(T);
-    typedef T vec_t __attribute__((ext_vector_type(V)));
-    double sq = 0.0;
-    auto one = [&](int j) {
-        const T vx = w_ex[src + j], vy = w_ey[src + j], vr = w_r[src + j], vt = w_th[src + j];
-        if (!MIRROR) {
-            const double dx1 = (double)vx - a.mux, dx2 = -(double)vx - a.mux, dy = (double)vy - a.muy;
-            sq += (dx1 * dx1 + dx2 * dx2) + (dy * dy + dy * dy);
-        }
-        __builtin_nontemporal_store(MIRROR ? -vx : vx, ex + dst + j);                                   // :141
-        __builtin_nontemporal_store(vy, ey + dst + j);                                                  // :140
-        __builtin_nontemporal_store(place_div(vr, rmax, rinv), rho + dst + j);                          // :142,143
-        __builtin_nontemporal_store(MIRROR ? (T)3.141592653589793 - vt : vt, theta + dst + j);          // :144
-    };
-    // vector stores need the four outputs equally placed inside a 16-byte word (they sit at the same element offset of
-    // equally aligned arrays unless the caller passed odd pointers); the line cut is taken from ex
-    const unsigned mis16 = (unsigned)(reinterpret_cast<uintptr_t>(ex + dst) & 15);
-    const bool same = (reinterpret_cast<uintptr_t>(ey + dst) & 15) == mis16 && (reinterpret_cast<uintptr_t>(rho + dst) & 15) == mis16 &&
-                      (reinterpret_cast<uintptr_t>(theta + dst) & 15) == mis16 && mis16 % sizeof(T) == 0;
-    if (!same) {
-        for (int j = tid; j < c; j += kBlock) one(j);
-        return sq;
-    }
-    const int mis = (int)((reinterpret_cast<uintptr_t>(ex + dst) & 127) / sizeof(T));     // elements past a 128-byte line
-    const int head = min(c, mis ? L - mis : 0);
-    const int nvec = (c - head) / V;
-    if (tid < head) one(tid);
-    for (int g = tid; g < nvec; g += kBlock) {                                            // a wave: 1 KiB from a line boundary
-        const int j = head + g * V;
-        vec_t vx, vy, vr, vt;
-        __builtin_memcpy(&vx, w_ex + src + j, sizeof(vec_t)); __builtin_memcpy(&vy, w_ey + src + j, sizeof(vec_t));
-        __builtin_memcpy(&vr, w_r + src + j, sizeof(vec_t));  __builtin_memcpy(&vt, w_th + src + j, sizeof(vec_t));
-        vec_t ox, orr, ot;
-#pragma unroll
-        for (int q = 0; q < V; ++q) {
-            if (!MIRROR) {
-                const double dx1 = (double)vx[q] - a.mux, dx2 = -(double)vx[q] - a.mux, dy = (double)vy[q] - a.muy;
-                sq += (dx1 * dx1 + dx2 * dx2) + (dy * dy + dy * dy);
-            }
-            ox[q] = MIRROR ? -vx[q] : vx[q];
-            orr[q] = place_div(vr[q], rmax, rinv);
-            ot[q] = MIRROR ? (T)3.141592653589793 - vt[q] : vt[q];
-        }
-        __builtin_nontemporal_store(ox, reinterpret_cast<vec_t*>(ex + dst + j));
-        __builtin_nontemporal_store(vy, reinterpret_cast<vec_t*>(ey + dst + j));
-        __builtin_nontemporal_store(orr, reinterpret_cast<vec_t*>(rho + dst + j));
-        __builtin_nontemporal_store(ot, reinterpret_cast<vec_t*>(theta + dst + j));
-    }
-    const int jt = head + nvec * V + tid;                                                 // < V - 1 elements left
-    if (jt < c) one(jt);
-    return sq;
-}
-
-// One tile's placement by kBlock threads: `c` survivors of slot `bid` to element `dst` of the bundle's first half and to
-// dst + m of its mirror half.  Returns this thread's share of the tile's squared deviations.
-template <typename T>
-__device__ __forceinline__ double ft_place_tile(int bid, int c, int64_t dst, const FtBundleAgg& a,
-                                                const T* __restrict__ w_ex, const T* __restrict__ w_ey,
-                                                const T* __restrict__ w_r, const T* __restrict__ w_th,
-                                                T* __restrict__ ex, T* __restrict__ ey, T* __restrict__ rho, T* __restrict__ theta,
-                                                int tid)
-{
-    const int64_t src = (int64_t)bid * kTile;                                     // the tile's slot: 16-byte aligned, kTile entries
-    const T rmax = (T)a.rmax, rinv = T(1) / rmax;                                 // r ./ maximum(r)  (:142)
-    const double sq = place_half<T, false>(w_ex, w_ey, w_r, w_th, src, ex, ey, rho, theta, dst, c, tid, a, rmax, rinv);
-    place_half<T, true>(w_ex, w_ey, w_r, w_th, src, ex, ey, rho, theta, dst + a.m, c, tid, a, rmax, rinv);
-    return sq;
-}
-
-// tile `bid` (= bundle * tiles_per_bundle + tile), by kBlock threads tid = 0 .. kBlock-1 of a workgroup: the second stage of
-// k_ft_small_finish, whose workgroup places four tiles at a time; active = false: no tile for this group
-template <typename T>
-__device__ __forceinline__ void ft_place_body(int bid, const T* __restrict__ w_ex, const T* __restrict__ w_ey,
-                                              const T* __restrict__ w_r, const T* __restrict__ w_th,
-                                              int64_t rpb, int tiles_per_bundle,
-                                              const int32_t* __restrict__ tile_cnt, const int64_t* __restrict__ tile_off,
-                                              const FtBundleAgg* __restrict__ agg,
-                                              T* __restrict__ ex, T* __restrict__ ey,
-                                              T* __restrict__ rho, T* __restrict__ theta,
-                                              double* __restrict__ tile_sq, FtPlaceShared<T>& sh, int tid, bool active)
-{
-    double* s_wsq = sh.wsq;
-    const int lane = tid & 63, wave = tid >> 6;
-    const int b = active ? bid / tiles_per_bundle : 0;
-    const int c = active ? tile_cnt[bid] : 0;
-    const FtBundleAgg a = agg[b];
-    const int64_t dst = (int64_t)b * 2 * rpb + (active ? tile_off[bid] : 0);
-    double sq = ft_place_tile<T>(bid, c, dst, a, w_ex, w_ey, w_r, w_th, ex, ey, rho, theta, tid);
-    for (int off = 32; off > 0; off >>= 1) sq += __shfl_down(sq, off);
-    if (lane == 0) s_wsq[wave] = sq;
-    __syncthreads();
-    if (active && tid == 0) {
-        double t = 0.0;
-        for (int w = 0; w < kBlock / 64; ++w) t += s_wsq[w];
-        tile_sq[bid] = t;
     }
 }
 
@@ -1164,6 +1463,7 @@ __global__ __launch_bounds__(kBlock) void k_ft_mirror(int64_t rpb, int chunks_pe
 // full_trace, stage D: sigma per bundle (PupilSampling.jl:169-173).
 // ft_err (look-back route, else null): a faulted look-back leaves count = -1, rms = NaN — what a device-pointer caller sees.
 // bundle b, by kBlock threads tid = 0 .. kBlock-1 of a workgroup (also the last stage of k_ft_small_finish); s_r: kBlock doubles of LDS.
+template <int PARTS = 1>   // PARTS = kBlock / 64: the fused launch left a tile's sum as its waves' partials — folded here in k_ft_place's order
 __device__ __forceinline__ void ft_finalize_body(int b, const double* __restrict__ tile_sq, int tiles_per_bundle,
                                                  const FtBundleAgg* __restrict__ agg,
                                                  int64_t* __restrict__ count, double* __restrict__ rms,
@@ -1171,7 +1471,12 @@ __device__ __forceinline__ void ft_finalize_body(int b, const double* __restrict
 {
     double acc = 0.0;
     if (active) {
-        for (int t = tid; t < tiles_per_bundle; t += kBlock) acc += tile_sq[(int64_t)b * tiles_per_bundle + t];
+        for (int t = tid; t < tiles_per_bundle; t += kBlock) {
+            const double* q = tile_sq + ((int64_t)b * tiles_per_bundle + t) * PARTS;
+            double ts = 0.0;
+            for (int w = 0; w < PARTS; ++w) ts += q[w];
+            acc += ts;
+        }
         s_r[tid] = acc;
     }
     __syncthreads();
@@ -1187,13 +1492,14 @@ __device__ __forceinline__ void ft_finalize_body(int b, const double* __restrict
     }
 }
 
+template <int PARTS = 1>
 __global__ __launch_bounds__(kBlock) void k_ft_finalize(const double* __restrict__ tile_sq, int tiles_per_bundle,
                                                         const FtBundleAgg* __restrict__ agg,
                                                         int64_t* __restrict__ count, double* __restrict__ rms,
                                                         const int* __restrict__ ft_err)
 {
     __shared__ double s_r[kBlock];
-    ft_finalize_body(blockIdx.x, tile_sq, tiles_per_bundle, agg, count, rms, ft_err, s_r, threadIdx.x, true);
+    ft_finalize_body<PARTS>(blockIdx.x, tile_sq, tiles_per_bundle, agg, count, rms, ft_err, s_r, threadIdx.x, true);
 }
 
 // full_trace of SMALL bundles (a few tiles each: the reference's own call is 4): stages B, C and D — tile offsets and bundle

@@ -155,9 +155,10 @@ class HipEngine:
     # ---- full_trace grid stage: PupilSampling.jl:121-146,169-173 -------------------------
     def full_trace_grid(self, pres: Prescription, bundles: Sequence[dict], axes, ny: int, nx: int,
                         raybasis: bool = False, stats_only: bool = False, dtype=np.float64,
-                        lookback: bool = False) -> List[dict]:
+                        lookback: bool = False, fused: bool = False) -> List[dict]:
         """dtype = np.float32 traces the grid in binary32 (`ort_full_trace_f32`; statistics stay binary64).
-        lookback = True takes the ORT_FT_LOOKBACK route (the trace kernel writes the first half at its final place)."""
+        lookback = True takes the ORT_FT_LOOKBACK route (the trace kernel writes the first half at its final place);
+        fused = True the ORT_FT_FUSED route (the second pass inside the trace launch)."""
         dtype = np.dtype(dtype)
         if dtype not in (np.dtype(np.float64), np.dtype(np.float32)):
             raise TypeError("full_trace_grid: dtype must be float64 or float32")
@@ -167,7 +168,7 @@ class HipEngine:
         cap = 2 * ny * nx
         count = np.zeros(nb, dtype=np.int64); rms = np.zeros(nb)
         barr = _capi.make_bundles(bundles)
-        flags = self.base_flags | (_capi.ORT_RAYBASIS if raybasis else 0) | (_capi.ORT_FT_LOOKBACK if lookback else 0)
+        flags = self.base_flags | (_capi.ORT_RAYBASIS if raybasis else 0) | (_capi.ORT_FT_LOOKBACK if lookback else 0) | (_capi.ORT_FT_FUSED if fused else 0)
         sysd = self.system(pres)
         if stats_only:      # one pass, nothing ray-sized leaves (or is even written on) the device
             check(fn(self.ctx.h, sysd.h, nb, barr, ptr(axes), axes.size, ny, nx,

@@ -2,7 +2,7 @@
 """One workload through the C ABI, a fixed number of times — the thing rocprofv3 wraps (scripts/pmc_sq.sh) and the
 thing interleaved A/B timings call.  Prints one JSON line.
 
-  python scripts/run_workload.py config3 --mode stats|full|lookback [--policy fast|ieee] [--pupil 2048] [--reps 5]
+  python scripts/run_workload.py config3 --mode stats|full|lookback|fused [--policy fast|ieee] [--pupil 2048] [--reps 5]
   python scripts/run_workload.py config2 --mode summary|history|stats|full
   python scripts/run_workload.py config1 --mode full|stats [--field 1.0]      (one-call pipeline, host buffers)
   python scripts/run_workload.py config5 --mode stats|hits [--dtype f32|f64] [--instances 10000] [--retrace]
@@ -149,12 +149,15 @@ def main():
         if a.mode == "stats":
             ptrs = (None, None, None, None)
         else:
-            vec = [torch.empty((nb, 2 * rpb), dtype=torch.float64, device=dev) for _ in range(4)]
+            vec = [torch.zeros((nb, 2 * rpb), dtype=torch.float64, device=dev) for _ in range(4)]
             ptrs = tuple(v.data_ptr() for v in vec)
-        ffl = fl | (_capi.ORT_FT_LOOKBACK if a.mode == "lookback" else 0)
+        ffl = fl | (_capi.ORT_FT_LOOKBACK if a.mode == "lookback" else 0) | (_capi.ORT_FT_FUSED if a.mode == "fused" else 0)
         ms = timed(lambda: _capi.check(lib.ort_full_trace_f64(h, sysd.h, nb, barr, d_axes.data_ptr(), axes.size, k, k, *ptrs,
                                                               cnt.data_ptr(), rms.data_ptr(), ffl)))
         res.update(survivors=int(cnt.sum().item()) // 2, mean_rms=float(rms.mean().item()))
+        if a.mode != "stats":      # bit-level checksum of the four slabs (unwritten entries are zero): routes must agree
+            res.update(checksum=[int(v.view(torch.int64).sum().item()) for v in vec],
+                       rms_bits=int(rms.view(torch.int64).sum().item()))
     res.update(ms=ms, intersections_per_s=N * S / (ms * 1e-3))
     print(json.dumps(res), flush=True)
 

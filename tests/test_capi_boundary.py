@@ -24,7 +24,7 @@ def test_header_symbols_exported():
     for n in names:
         assert hasattr(lib, n), f"libort_hip.so does not export {n}"
     assert sorted(_capi.SIGNATURES) == names
-    assert lib.ort_version() == 400
+    assert lib.ort_version() == 401
 
 
 def test_no_torch_types_in_abi():

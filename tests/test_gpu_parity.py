@@ -1976,7 +1976,7 @@ def test_lookback_fault_is_reported(oracle_engine):
     _capi.check(lib.ort_ctx_test_skew_tickets(h, 1 << 40))
     with pytest.raises(_capi.OrtError) as e:
         eng.full_trace_grid(pres, bundles, axes, 40, 40, lookback=True)
-    assert e.value.code == -3 and "look-back" in str(e.value)
+    assert e.value.code == -3 and "hand-off fault" in str(e.value)
     # device-pointer (asynchronous) caller: poisoned results
     dev = torch.device("cuda:0")
     nb, cap = len(bundles), 2 * 40 * 40
@@ -2001,7 +2001,7 @@ def test_lookback_fault_is_reported(oracle_engine):
     call = lambda: lib.ort_full_trace_batch_f64(h, 1, mats.shape[1], _capi.ptr(R), _capi.ptr(t), _capi.ptr(n), _capi.ptr(aa), _capi.ptr(hh),
                                                 1, _capi.ptr(ff), 64, fo, _capi.ptr(bex), _capi.ptr(bey), _capi.ptr(brho), _capi.ptr(bth),
                                                 _capi.ptr(bc), _capi.ptr(br), _capi.ORT_FT_LOOKBACK)
-    assert call() == -3 and b"look-back" in lib.ort_last_error()
+    assert call() == -3 and b"hand-off fault" in lib.ort_last_error()
     _capi.check(lib.ort_ctx_test_skew_tickets(h, -(1 << 40)))
     assert call() == 0 and bc[0] > 0 and np.isfinite(br[0])
     again = eng.full_trace_grid(pres, bundles, axes, 40, 40, lookback=True)
@@ -2072,7 +2072,7 @@ def test_small_problem_path_is_bit_identical_to_the_general_route(hip_engine):
 def test_four_host_threads_four_contexts():
     """include/ort.h: "one ctx per (host thread, GPU)", `ort_last_error` per thread.  Four host threads, each with its OWN
     context (own stream, own scratch, own look-back words and tickets) on GPU 0, run concurrently for a few hundred calls
-    each: `ort_full_trace_f64` on the default route, with ORT_FT_LOOKBACK and statistics-only (the walk route), and
+    each: `ort_full_trace_f64` on the default route, with ORT_FT_LOOKBACK, with ORT_FT_FUSED and statistics-only (the walk route), and
     `ort_spot_batch_f64` — every result bit-identical to the serial run of the same call; then all four fail a call at the
     same moment with their own argument and each must read ITS message back."""
     import threading
@@ -2084,10 +2084,11 @@ def test_four_host_threads_four_contexts():
     def work(eng):
         full = eng.full_trace_grid(pres, bundles, axes, k, k)
         look = eng.full_trace_grid(pres, bundles, axes, k, k, lookback=True)
+        fuse = eng.full_trace_grid(pres, bundles, axes, k, k, fused=True)
         stat = eng.full_trace_grid(pres, bundles, axes, k, k, stats_only=True)
         sb = batch.spot_batch(mats, cm.DG_A, cm.DG_H, (0.0, 1.0), 64, engine=eng)
         key = []
-        for r in full + look:
+        for r in full + look + fuse:
             key += [r["ex"].tobytes(), r["ey"].tobytes(), r["rho"].tobytes(), r["theta"].tobytes(), r["count"], r["rms"]]
         key += [(r["count"], r["rms"]) for r in stat]
         key += [sb["rms"].tobytes(), sb["count"].tobytes(), sb["W040"].tobytes()]
@@ -2129,7 +2130,7 @@ def test_four_host_threads_four_contexts():
     assert not fails, fails[:3]
     for i, (rc, msg) in enumerate(msgs):
         assert rc == -1 and f"system index {1000 + i} " in msg, (i, rc, msg)
-    cm.report(f"thread safety: {nthreads} host threads x {iters} rounds x 4 calls (full_trace default / look-back / statistics-only, "
+    cm.report(f"thread safety: {nthreads} host threads x {iters} rounds x 5 calls (full_trace default / look-back / fused / statistics-only, "
               f"spot_batch), own context each, all bit-identical to the serial run; ort_last_error per thread")
 
 
@@ -2219,3 +2220,74 @@ def test_deep_prescriptions_other_kernels(hip_engine, oracle_engine, rows, units
     for key in ("f", "EBFD", "W040", "W131", "W222", "W311", "H"):     # (8 units: the chain ends collimated, f = -inf on both sides)
         assert fo[key][0] == ref[key] or abs(fo[key][0] - ref[key]) <= 1e-12 * max(1.0, abs(ref[key])), (key, fo[key][0], ref[key])
     assert int(fo["stop"][0]) == int(ref["stop"])
+
+
+@pytest.mark.parametrize("policy", ["ieee", "fast"])
+def test_full_trace_fused_route_is_bit_identical(policy):
+    """ORT_FT_FUSED (include/ort.h): the second pass of full_trace (tile offsets, placement of both halves, squared deviations)
+    runs inside the trace launch — workgroup i traces tile i and places tile i - (tiles per bundle + margin).  Same device
+    functions as the default route: every output bit-identical — on a launch small enough that the trailing workgroups do all
+    the placing (4 bundles of 50 tiles), on one where placements run beside traces (config 3's systems at 768^2: 9 bundles of
+    1,152 tiles, lag 3,200), in Float32, with one bundle (falls back to the default route) and on repeated calls of different
+    shapes through one context (the ready words are told apart by the epoch, the counters return to zero)."""
+    from opticalraytracing_jl_amd import api, workloads
+    eng = _engine(policy)
+
+    def same(a, b):
+        assert len(a) == len(b)
+        for ra, rb in zip(a, b):
+            assert ra["count"] == rb["count"] and ra["count"] > 0
+            assert np.float64(ra["rms"]).tobytes() == np.float64(rb["rms"]).tobytes()
+            for key in ("ex", "ey", "rho", "theta"):
+                assert ra[key].tobytes() == rb[key].tobytes(), key
+
+    pres, bundles, axes = _dg_bundles(ort.default_engine(), 160, fields=(0.0, 1.0), lines=(0, 2))
+    ref_small = eng.full_trace_grid(pres, bundles, axes, 160, 160)
+    # a second launch of the same shape with other contents: the same workspace slots, offsets and aggregates hold other
+    # values on alternating calls — a line kept by a cache from the call before would show
+    presb, bundlesb, axesb = _dg_bundles(ort.default_engine(), 160, fields=(0.7, 0.3), lines=(1, 0))
+    ref_smallb = eng.full_trace_grid(presb, bundlesb, axesb, 160, 160)
+    assert any(x["count"] != y["count"] for x, y in zip(ref_small, ref_smallb))
+    for _ in range(6):
+        same(eng.full_trace_grid(pres, bundles, axes, 160, 160, fused=True), ref_small)
+        same(eng.full_trace_grid(presb, bundlesb, axesb, 160, 160, fused=True), ref_smallb)
+    pres3, bundles3, axes3 = workloads.config3(api, 768, engine=ort.default_engine())
+    ref_big = eng.full_trace_grid(pres3, bundles3, axes3, 768, 768)
+    for _ in range(2):
+        same(eng.full_trace_grid(pres, bundles, axes, 160, 160, fused=True), ref_small)
+        same(eng.full_trace_grid(pres3, bundles3, axes3, 768, 768, fused=True), ref_big)
+    same(eng.full_trace_grid(pres, bundles[:1], axes, 160, 160, fused=True), ref_small[:1])
+    ref32 = eng.full_trace_grid(pres, bundles, axes, 160, 160, dtype=np.float32)
+    same(eng.full_trace_grid(pres, bundles, axes, 160, 160, dtype=np.float32, fused=True), ref32)
+
+
+def test_fused_route_fault_is_reported():
+    """ORT_FT_FUSED: a workgroup that waits for a bundle's offsets beyond its poll cap raises the fault word; the call returns
+    ORT_EHIP to a host caller and count = -1 / rms = NaN to a device-pointer caller, never misplaced survivors.  Forced with the
+    testing aid ort_ctx_test_fused_no_scan (no workgroup runs the scans); the same context then runs the same call correctly."""
+    import torch
+    from opticalraytracing_jl_amd import _capi
+    eng = ort.HipEngine(0)
+    lib, h = eng.ctx.lib, eng.ctx.h
+    pres, bundles, axes = _dg_bundles(ort.default_engine(), 160, fields=(0.0, 1.0), lines=(0, 2))
+    good = eng.full_trace_grid(pres, bundles, axes, 160, 160)
+    _capi.check(lib.ort_ctx_test_fused_no_scan(h, 1))
+    with pytest.raises(_capi.OrtError, match="hand-off fault"):
+        eng.full_trace_grid(pres, bundles, axes, 160, 160, fused=True)
+    dev = torch.device("cuda", 0)
+    nb, rpb = len(bundles), 160 * 160
+    d_axes = torch.from_numpy(axes).to(dev)
+    vec = [torch.zeros((nb, 2 * rpb), dtype=torch.float64, device=dev) for _ in range(4)]
+    cnt = torch.zeros(nb, dtype=torch.int64, device=dev); rms = torch.zeros(nb, dtype=torch.float64, device=dev)
+    torch.cuda.synchronize(dev)
+    _capi.check(lib.ort_full_trace_f64(h, eng.system(pres).h, nb, _capi.make_bundles(bundles), d_axes.data_ptr(), axes.size, 160, 160,
+                                       *(v.data_ptr() for v in vec), cnt.data_ptr(), rms.data_ptr(),
+                                       _capi.ORT_DEVICE_PTRS | _capi.ORT_FT_FUSED))
+    eng.ctx.synchronize()
+    assert (cnt.cpu().numpy() == -1).all() and np.isnan(rms.cpu().numpy()).all()
+    _capi.check(lib.ort_ctx_test_fused_no_scan(h, 0))
+    again = eng.full_trace_grid(pres, bundles, axes, 160, 160, fused=True)
+    for a, b in zip(again, good):
+        assert a["count"] == b["count"] and a["rms"] == b["rms"]
+        for key in ("ex", "ey", "rho", "theta"):
+            assert a[key].tobytes() == b[key].tobytes()
