@@ -218,7 +218,7 @@ def bench_single(args, torch, rank, world, local_rank, emit=True):
         def step():
             _capi.check(lib.ort_full_trace_f64(h, sysd.h, nb, barr, d_axes.data_ptr(), axes.size, k, k,
                                                ex.data_ptr(), ey.data_ptr(), rho.data_ptr(), th.data_ptr(),
-                                               cnt.data_ptr(), rms.data_ptr(), fl | (_capi.ORT_FT_LOOKBACK if args.ft_lookback else 0)))
+                                               cnt.data_ptr(), rms.data_ptr(), fl | (_capi.ORT_FT_LOOKBACK if args.ft_lookback else 0) | (_capi.ORT_FT_FUSED if args.ft_fused else 0)))
 
     step(); torch.cuda.synchronize(dev)                     # first launch: allocations, code load
     if algo_bytes is None:
@@ -528,6 +528,9 @@ def bench_single(args, torch, rank, world, local_rank, emit=True):
         cols5 = batch.split_columns(mats5)
         call5(tuple(c[:64] for c in cols5))                          # allocations
         call5(cols5)                                                 # ... at full size
+        t_end = time.perf_counter() + 0.25                           # sustained clocks first (timed_launches, preroll_s)
+        while time.perf_counter() < t_end:
+            call5(cols5)
         walls5, devs5 = [], []
         for _ in range(5):
             eng.ctx.timer_start()
@@ -1149,6 +1152,7 @@ def main():
     ap.add_argument("--sustain-s", type=float, default=1.0, help="seconds of back-to-back launches for the sustained figure (0 = off)")
     ap.add_argument("--mode", default="history", choices=["history", "summary", "full_trace"])
     ap.add_argument("--ft-lookback", action="store_true", help="--mode full_trace: the ORT_FT_LOOKBACK route")
+    ap.add_argument("--ft-fused", action="store_true", help="--mode full_trace: the ORT_FT_FUSED route")
     ap.add_argument("--workload", default="auto", choices=["auto", "config2", "config4", "config5"],
                     help="auto: config 2 at N = 1, config 4 (sharded + all-gather) at N > 1; config5: the Float32 hit payload of the "
                          "Monte-Carlo run, sharded + all-gathered the same way")

@@ -42,3 +42,17 @@ for m in full fused stats; do
   grep '"ms"' $OUT/loop_$m.log | python3 -c "import sys,json; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('$m', 'loop ms', round(d['ms'],4))" >> $OUT/power.log
 done
 cat $OUT/power.log
+# clock the sustained loops ran at, if a call's kernels take the same cycles there as under the profiler (issue-bound kernels do):
+# sum over the call's kernels of (profiled time x profiled clock) / sustained time per call
+python3 - $OUT <<'PY'
+import json, re, sys
+out = sys.argv[1]
+res = json.load(open(out + "/summary.json"))
+loops = dict(re.findall(r"^(\w+) loop ms ([\d.]+)", open(out + "/power.log").read(), re.M))
+for mode, ks in res.items():
+    cyc = sum(v["kernel_ms"] * 1e-3 * v["clock_GHz"] * 1e9 for k, v in ks.items() if "paraxial" not in k)
+    prof_ms = sum(v["kernel_ms"] for k, v in ks.items() if "paraxial" not in k)
+    if mode in loops:
+        print(f"{mode}: kernels under the profiler {prof_ms:.4f} ms ({cyc / 1e6:.3f} M cycles per XCD); sustained loop {float(loops[mode]):.4f} ms per call"
+              f" -> {cyc / (float(loops[mode]) * 1e-3) / 1e9:.3f} GHz if the cycles are the same")
+PY

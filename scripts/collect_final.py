@@ -37,7 +37,7 @@ for pol in ("fast", "ieee"):
 json.dump(traffic, open(os.path.join(P, "pmc_traffic.json"), "w"), indent=1)
 # full_trace routes: bytes per kernel and per ray (config 2: 9,437,184 rays)
 ft = {}
-for route in ("place", "lookback"):
+for route in ("place", "lookback", "fused"):
     per = {}
     for ctr, name, mul in (("ft_fetch", "FETCH_SIZE", 2.0), ("ft_write", "WRITE_SIZE", 1.0)):
         for k, d in counters(f"{ctr}_{route}").items():

@@ -14,8 +14,8 @@ for pol in fast ieee; do
   timeout -k 10 300 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/fetch_$pol -- python3 /root/repo/bench.py $Q --policy $pol > $OUT/fetch_$pol.log 2>&1 || exit 1
   timeout -k 10 300 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/write_$pol -- python3 /root/repo/bench.py $Q --policy $pol > $OUT/write_$pol.log 2>&1 || exit 1
 done
-for route in place lookback; do
-  extra=""; [ $route = lookback ] && extra="--ft-lookback"
+for route in place lookback fused; do
+  extra=""; [ $route = lookback ] && extra="--ft-lookback"; [ $route = fused ] && extra="--ft-fused"
   timeout -k 10 300 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/ft_fetch_$route -- python3 /root/repo/bench.py $Q --mode full_trace $extra > $OUT/ft_fetch_$route.log 2>&1 || exit 1
   timeout -k 10 300 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/ft_write_$route -- python3 /root/repo/bench.py $Q --mode full_trace $extra > $OUT/ft_write_$route.log 2>&1 || exit 1
 done
@@ -30,6 +30,7 @@ bash scripts/config1_kernels.sh > gpurun_out/${T}_c1k.log 2>&1; cp gpurun_out/${
 gcc -O2 -Wall -Iinclude examples/cooke_full_trace.c -o build/cooke_full_trace -Lopticalraytracing.jl_amd/csrc -lort_hip -Wl,-rpath,$PWD/opticalraytracing.jl_amd/csrc -Wl,-rpath,/opt/rocm/lib -Wl,-rpath-link,/opt/rocm/lib -lm
 [ -x build/cooke_full_trace ] && (./build/cooke_full_trace --time 0.0; ./build/cooke_full_trace --time 1.0; ./build/cooke_full_trace --time 0.0 fast; ./build/cooke_full_trace --time 1.0 fast) > gpurun_out/${T}_c1_cabi.log 2>&1
 bash scripts/clock_config3.sh ${T}_clk > gpurun_out/${T}_clk.log 2>&1
+bash scripts/clock_fused.sh ${T}_clock_fused > gpurun_out/${T}_clock_fused.log 2>&1     # default / fused / statistics-only: kernel times, clocks, board power
 cd /root/repo
 ORT_BENCH_BACKEND=gloo timeout -k 10 600 python bench.py --gpus 2 --steps 5 --warmup 2 > gpurun_out/${T}_n2_gloo.json 2> gpurun_out/${T}_n2_gloo.err || echo "n2 rehearsal rc=$?"
 # round 4: counter + clock pass of the Float32 kernels of config 5 (statistics kernel and summary kernel), the kernel statistics of
