@@ -576,6 +576,11 @@ __device__ __forceinline__ void ft_place_body(int bid, const T* __restrict__ w_e
 //                bundle's earlier tiles (tiles taken in ticket order); k_ft_mirror adds the second half — least
 //                HBM traffic (84 vs 103 B/ray measured), but every tile waits for its predecessors' counts and the kernel holds
 //                4 waves per SIMD instead of 5 (ORT_FT_LOOKBACK; 5 % slower);
+//   FT_FUSED     (ORT_FT_FUSED, two or more bundles) FT_FULL with the second pass INSIDE the launch: the workgroup that has traced
+//                tile i into its slot then places tile i - lag (lag = tiles per bundle + a margin: a tile of a bundle complete
+//                long ago) through k_ft_place's body, designated workgroups run the bundles' scans, the launch ends with `lag`
+//                workgroups that only place — the HBM-bound pass overlaps the issue-bound one (config 3: -13 % at sustained
+//                clocks, bit-identical).  Hand-offs: sc1 stores / sc1 loads, no fence (pub_* above);
 //   FT_WALK, FT_WALK1   the statistics-only route: nothing ray-sized is written.  A workgroup WALKS consecutive tiles of its bundle
 //                with the table staged once and no barrier after that; every lane carries (n, sum d, sum d^2) of its
 //                survivors about the first survivor its wave met, and every SPAN of kSpan tiles each wave folds its lanes
@@ -1172,11 +1177,11 @@ void k_trace(TraceParams<T> p)   // both outputs, look-back epilogue, Float64 ru
     }
     if constexpr (FUSED) {
         // FT_FUSED: the second pass (HBM-bound) inside the trace launch (FP64-issue-bound).  Workgroup i has traced tile i into
-        // its workspace slot; it now (1) publishes the tile — the workgroup that completes a bundle runs k_ft_scan's body for it
-        // and raises the bundle's ready word — and (2) places tile i - fuse_lag, fuse_lag = tiles_per_bundle + a margin: that
-        // tile's bundle was complete `margin` workgroups ago, so the wait below is a safety net, not a queue.  A workgroup only
-        // ever waits for workgroups with LOWER indices (dispatched before it): no cycle; the poll cap raises the fault word
-        // and the call returns an error instead of hanging.  Same bodies as k_ft_scan / k_ft_place: same bits.
+        // its workspace slot (sc1 stores); below it (1) publishes the tile, (2) places tile pj = i - fuse_lag — a tile of a bundle that
+        // was complete `margin` workgroups ago, so its wait is a safety net, not a queue — and (3), if it is the one named for
+        // it, runs a bundle's scan and raises that bundle's ready word.  A workgroup only ever waits for workgroups with LOWER
+        // indices (dispatched before it): no cycle; a poll cap raises the fault word and the call returns an error instead of
+        // hanging.  Same bodies as k_ft_scan / k_ft_place: same bits.
         static_assert(!FUSED || RPT == kRPT, "FT_FUSED: kBlock threads per workgroup");
         __shared__ int s_go;
         const int tpb = p.tiles_per_bundle;
