@@ -40,5 +40,6 @@ bash scripts/clock_config5.sh ${T}_clk5 > gpurun_out/${T}_clk5.log 2>&1; cp gpur
 cp $(ls -t gpurun_out/${T}_c5_kstats/*/*kernel_stats.csv | head -1) profiles/${T}_config5_kernel_stats.csv 2>/dev/null
 python -m pytest tests -m gpu -q > gpurun_out/${T}_gpu_suite.log 2>&1; cp gpurun_out/${T}_gpu_suite.log profiles/${T}_gpu_suite_parity_report.log
 timeout -k 10 600 python scripts/soak_parity.py 900 4242 > gpurun_out/${T}_soak_parity_seed4242.log 2>&1; cp gpurun_out/${T}_soak_parity_seed4242.log profiles/
+timeout -k 10 300 python scripts/soak_fused.py 60 7 > gpurun_out/${T}_soak_fused_seed7.log 2>&1
 # the exchange leg alone with the native RCCL communicator of the C ABI (ort_comm_*), one rank: the code path the N > 1 line takes
 timeout -k 10 300 python bench.py --workload config4 --steps 5 --warmup 2 > gpurun_out/${T}_config4_world1_native_rccl.json 2> gpurun_out/${T}_config4_world1.err || echo "config4 world1 rc=$?"
