@@ -454,6 +454,15 @@ int trace_list_impl(ort_ctx* ctx, const ort_system* sys, int isys, int64_t nrays
     return ORT_OK;
 }
 
+// The launch number that tells this launch's look-back / ready words from older ones (30 bits).  When it wraps, the words are
+// zero-filled again before the launch (the capacities the fills were done for are forgotten).
+static unsigned next_ft_epoch(ort_ctx* ctx)
+{
+    ctx->ft_epoch = (ctx->ft_epoch + 1) & 0x3fffffffu;
+    if (ctx->ft_epoch == 0) { ctx->ft_epoch = 1; ctx->ft_state_cap = 0; ctx->ft_ready_cap = 0; }
+    return ctx->ft_epoch;
+}
+
 // The full_trace stages on a prepared TraceParams (recs / coefs / bundles / axes / grid shape set by the
 // caller): tile buffers, trace with the FT epilogue, scan + scatter + finalize (or the statistics-only
 // merge), results to the caller.  ex == NULL selects statistics only.
@@ -542,6 +551,7 @@ int run_full_trace(ort_ctx* ctx, TraceParams<T>& p, int nb, T* ex, T* ey, T* rho
             // the second pass inside the trace launch (k_trace, FT_FUSED): workgroup i traces tile i and places tile i - lag
             rc = dev_out<int>(ctx, SL_FTDONE, (size_t)nb + 4, &p.ft_done); if (rc) return rc;
             HIP_TRY(hipMemsetAsync(p.ft_done, 0, ((size_t)nb * sizeof(int) + 15) & ~(size_t)15, ctx->stream));   // arrivals are counted within the call
+            p.ft_epoch = next_ft_epoch(ctx);
             rc = dev_out<unsigned>(ctx, SL_FTREADY, (size_t)nb, &p.ft_ready); if (rc) return rc;
             if (ctx->slot[SL_FTREADY].cap != ctx->ft_ready_cap) {
                 HIP_TRY(hipMemsetAsync(p.ft_ready, 0, ctx->slot[SL_FTREADY].cap, ctx->stream));
@@ -550,9 +560,6 @@ int run_full_trace(ort_ctx* ctx, TraceParams<T>& p, int nb, T* ex, T* ey, T* rho
             rc = dev_out<int>(ctx, SL_FTERR, 1, &p.ft_err); if (rc) return rc;
             HIP_TRY(hipMemsetAsync(p.ft_err, 0, sizeof(int), ctx->stream));
             ft_err = p.ft_err;
-            ctx->ft_epoch = (ctx->ft_epoch + 1) & 0x3fffffffu;
-            if (ctx->ft_epoch == 0) ctx->ft_epoch = 1;
-            p.ft_epoch = ctx->ft_epoch;
             p.tile_off = tile_off; p.agg = agg; p.tile_sq = chunk_sq;
             p.fin_ex = dex; p.fin_ey = dey; p.fin_rho = drho; p.fin_th = dth;
             p.fuse_ntiles = (int)tiles;
@@ -595,6 +602,7 @@ int run_full_trace(ort_ctx* ctx, TraceParams<T>& p, int nb, T* ex, T* ey, T* rho
         // ORT_FT_LOOKBACK: the trace kernel writes the first half itself.  Look-back state: one 8-byte word per tile +
         // the ticket counter; zero-filled when (re)allocated only — the epoch tells the words of this launch from
         // older ones, the base does the same for tickets
+        p.ft_epoch = next_ft_epoch(ctx);
         rc = dev_out<unsigned long long>(ctx, SL_FTSTATE, (size_t)tiles, &p.ft_state); if (rc) return rc;
         if (ctx->slot[SL_FTSTATE].cap != ctx->ft_state_cap) {
             HIP_TRY(hipMemsetAsync(p.ft_state, 0, ctx->slot[SL_FTSTATE].cap, ctx->stream));
@@ -609,9 +617,6 @@ int run_full_trace(ort_ctx* ctx, TraceParams<T>& p, int nb, T* ex, T* ey, T* rho
         rc = dev_out<int>(ctx, SL_FTERR, 1, &p.ft_err); if (rc) return rc;
         HIP_TRY(hipMemsetAsync(p.ft_err, 0, sizeof(int), ctx->stream));
         ft_err = p.ft_err;
-        ctx->ft_epoch = (ctx->ft_epoch + 1) & 0x3fffffffu;
-        if (ctx->ft_epoch == 0) ctx->ft_epoch = 1;
-        p.ft_epoch = ctx->ft_epoch;
         p.ft_ticket_base = ctx->ft_ticket_base;
         p.out_ex = dex; p.out_ey = dey; p.out_r = drho; p.out_th = dth;
         rc = launch_trace<T, true, false, false, FT_LOOKBACK>(ctx, p, tiles, flags); if (rc) return rc;
