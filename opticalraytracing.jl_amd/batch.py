@@ -221,13 +221,14 @@ def spot_batch(mats: np.ndarray, a, hprime, fields: Sequence[float] = (0.0,), k_
 
 
 def full_trace_systems(mats: np.ndarray, a, hprime, fields: Sequence[float] = (0.0,), k_rays: int = SPOT_RAYS,
-                       engine=None, coef=None):
+                       engine=None, coef=None, flags: int = 0):
     """`[full_trace(solve(M, a, h′), H, k_rays) for M in mats, H in fields]` as ONE C call: the spot pipeline of
     `spot_batch` with the error vectors returned.  mats : [ninst][rows][3] = [R t n] (`ort_full_trace_batch_f64`)
     or [ninst][rows][4] = [R t n K] and / or coef : [ninst][rows][ncoef] power-series coefficients of p — the
     reference's Layout(R, t, n, K, p) (`ort_full_trace_layout_batch_f64`).
     Returns (first-order dict of [ninst] arrays, list over (instance, field) of dicts with ex, ey, rho,
-    theta, rms, count, H — the fields of RealRayError, src/Types.jl:184-192)."""
+    theta, rms, count, H — the fields of RealRayError, src/Types.jl:184-192).  flags: further ORT_* flags of the call
+    (`_capi.ORT_FT_FUSED`, `_capi.ORT_FT_LOOKBACK`: the route of the full_trace stage; same results)."""
     eng = _eng(engine)
     mats = np.ascontiguousarray(mats, dtype=np.float64)
     if mats.ndim == 2:
@@ -251,13 +252,13 @@ def full_trace_systems(mats: np.ndarray, a, hprime, fields: Sequence[float] = (0
         rc = lib.ort_full_trace_batch_f64(h, ninst, rows, _capi.ptr(R), _capi.ptr(t), _capi.ptr(n),
                                           _capi.ptr(a_arr), _capi.ptr(hp), nf, _capi.ptr(fields), int(k_rays), fo,
                                           _capi.ptr(ex), _capi.ptr(ey), _capi.ptr(rho), _capi.ptr(th),
-                                          _capi.ptr(count), _capi.ptr(rms), eng.base_flags)
+                                          _capi.ptr(count), _capi.ptr(rms), eng.base_flags | int(flags))
     else:
         rc = lib.ort_full_trace_layout_batch_f64(h, ninst, rows, _capi.ptr(R), _capi.ptr(t), _capi.ptr(n), _capi.ptr(K),
                                                  _capi.ptr(coef), 0 if coef is None else coef.shape[2],
                                                  _capi.ptr(a_arr), _capi.ptr(hp), nf, _capi.ptr(fields), int(k_rays), fo,
                                                  _capi.ptr(ex), _capi.ptr(ey), _capi.ptr(rho), _capi.ptr(th),
-                                                 _capi.ptr(count), _capi.ptr(rms), eng.base_flags)
+                                                 _capi.ptr(count), _capi.ptr(rms), eng.base_flags | int(flags))
     if rc == _capi.ORT_EDOMAIN:
         raise DomainError(lib.ort_last_error().decode('utf-8', 'replace'))
     _capi.check(rc)

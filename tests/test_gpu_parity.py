@@ -2259,6 +2259,18 @@ def test_full_trace_fused_route_is_bit_identical(policy):
     same(eng.full_trace_grid(pres, bundles[:1], axes, 160, 160, fused=True), ref_small[:1])
     ref32 = eng.full_trace_grid(pres, bundles, axes, 160, 160, dtype=np.float32)
     same(eng.full_trace_grid(pres, bundles, axes, 160, 160, dtype=np.float32, fused=True), ref32)
+    # through the one-call pipelines (solve -> aiming -> axes -> full_trace on the device): 3 prescriptions x 2 fields, 512 x 256
+    # half pupils (256 tiles per bundle), the plain and the Layout (conic + polynomial) entry points
+    from opticalraytracing_jl_amd import _capi, batch
+    mats = workloads.config5(None, ninst=3)
+    r0 = batch.full_trace_systems(mats, cm.DG_A, cm.DG_H, (0.0, 1.0), 512, engine=eng)[1]
+    r1 = batch.full_trace_systems(mats, cm.DG_A, cm.DG_H, (0.0, 1.0), 512, engine=eng, flags=_capi.ORT_FT_FUSED)[1]
+    same(r1, r0)
+    M4, coef = cm.double_gauss_aspheric()
+    l0 = batch.full_trace_systems(M4[None], cm.DG_A, cm.DG_H, (0.0, 0.7, 1.0), 512, engine=eng, coef=np.asarray(coef)[None])[1]
+    l1 = batch.full_trace_systems(M4[None], cm.DG_A, cm.DG_H, (0.0, 0.7, 1.0), 512, engine=eng, coef=np.asarray(coef)[None],
+                                  flags=_capi.ORT_FT_FUSED)[1]
+    same(l1, l0)
 
 
 def test_fused_route_fault_is_reported():
