@@ -88,7 +88,12 @@ extern "C" {
 #define ORT_FT_FUSED      (1u << 10) /* full_trace, two or more bundles: the second pass (offsets, placement in both halves, squared
                                         deviations) runs INSIDE the trace launch — a workgroup that has traced its tile places a tile of
                                         an earlier, complete bundle — so the HBM-bound pass overlaps the issue-bound one.  Same device
-                                        functions: bit-identical results */
+                                        functions: bit-identical results (BASELINE config 3: 1.50 instead of 1.67-1.73 ms).  Bundles
+                                        of <= 32 tiles and single-bundle calls take the default route under this flag too.  Opt-in: the
+                                        workgroups hand data to each other inside the launch (write-through stores, cache-bypassing
+                                        loads, no fence) and wait only for workgroups with lower indices — properties observed on
+                                        gfx950 / ROCm 7.2, not promised by HIP; a wait that outlasts its poll cap fails the call
+                                        (ORT_EHIP; device-pointer callers: count = -1, rms = NaN), it never misplaces survivors */
 #define ORT_FT_LOOKBACK   (1u << 7) /* full_trace: the trace kernel writes the survivors' first half at its final place
                                        (decoupled look-back over the bundle's tiles) instead of staging compacted tiles in
                                        a workspace: 82 instead of 100 B/ray of HBM traffic, but tiles wait for their
