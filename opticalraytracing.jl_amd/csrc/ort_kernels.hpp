@@ -450,12 +450,13 @@ __device__ __forceinline__ double ft_place_tile(int bid, int c, int64_t dst, con
     return sq;
 }
 
-// The fused launch's placement of one tile (FT_FUSED): what ft_place_tile<T, true> does, element for element and sum for
-// sum, laid out for LATENCY — the workgroup that runs it holds a trace kernel's registers while it waits.  EVERY load of
+// One tile's placement laid out for LATENCY (the fused launch, FT_FUSED, PUB = true: the workgroup that runs it holds a trace
+// kernel's registers while it waits; k_ft_place, PUB = false): what ft_place_tile<T, PUB> does, element for element and sum
+// for sum.  EVERY load of
 // both halves goes out first (a thread owns at most one head element, one 16-byte vector and one tail element per half:
 // kTile / V <= kBlock), then `between()` runs (the caller's publish of its own tile: its wait covers these loads too), then
 // the arithmetic and all the stores; nothing waits for a store.
-template <typename T, typename F>
+template <typename T, bool PUB = true, typename F>
 __device__ __forceinline__ double ft_place_tile_pub(int bid, int c, int64_t dst, const FtBundleAgg& a,
                                                     const T* w_ex, const T* w_ey, const T* w_r, const T* w_th,
                                                     T* __restrict__ ex, T* __restrict__ ey, T* __restrict__ rho, T* __restrict__ theta,
@@ -480,9 +481,18 @@ __device__ __forceinline__ double ft_place_tile_pub(int bid, int c, int64_t dst,
     }
     if (!same) {                                                 // odd output pointers: the element-wise path
         between();
-        return ft_place_tile<T, true>(bid, c, dst, a, w_ex, w_ey, w_r, w_th, ex, ey, rho, theta, tid);
+        return ft_place_tile<T, PUB>(bid, c, dst, a, w_ex, w_ey, w_r, w_th, ex, ey, rho, theta, tid);
     }
-    const __amdgpu_buffer_rsrc_t rx = pub_rsrc(w_ex + src), ry = pub_rsrc(w_ey + src), rr = pub_rsrc(w_r + src), rt = pub_rsrc(w_th + src);
+    // PUB: the slot was written by another workgroup of this launch (sc1 loads); else by an earlier launch (plain loads)
+    const __amdgpu_buffer_rsrc_t rx = pub_rsrc(PUB ? w_ex + src : nullptr), ry = pub_rsrc(PUB ? w_ey + src : nullptr),
+                                 rr = pub_rsrc(PUB ? w_r + src : nullptr), rt = pub_rsrc(PUB ? w_th + src : nullptr);
+    auto ld1 = [&](const T* w, __amdgpu_buffer_rsrc_t r, int j) -> T {
+        if constexpr (PUB) return pub_load1<T>(r, j * B); else return w[src + j];
+    };
+    auto ld16 = [&](const T* w, __amdgpu_buffer_rsrc_t r, int j) -> vec_t {
+        if constexpr (PUB) return pub_load16<vec_t>(r, j * B);
+        else { vec_t v; __builtin_memcpy(&v, w + src + j, sizeof(vec_t)); return v; }
+    };
     T hx[2], hy[2], hr[2], ht[2], tx[2], ty[2], tr[2], tt[2];
     vec_t vx[2], vy[2], vr[2], vt[2];
     int jv[2], jt[2];
@@ -491,12 +501,12 @@ __device__ __forceinline__ double ft_place_tile_pub(int bid, int c, int64_t dst,
         hx[q] = hy[q] = hr[q] = ht[q] = tx[q] = ty[q] = tr[q] = tt[q] = T(0);
         vx[q] = vy[q] = vr[q] = vt[q] = vec_t(T(0));
         jv[q] = head[q] + tid * V; jt[q] = head[q] + nvec[q] * V + tid;
-        if (tid < head[q]) { hx[q] = pub_load1<T>(rx, tid * B); hy[q] = pub_load1<T>(ry, tid * B); hr[q] = pub_load1<T>(rr, tid * B); ht[q] = pub_load1<T>(rt, tid * B); }
+        if (tid < head[q]) { hx[q] = ld1(w_ex, rx, tid); hy[q] = ld1(w_ey, ry, tid); hr[q] = ld1(w_r, rr, tid); ht[q] = ld1(w_th, rt, tid); }
         if (tid < nvec[q]) {
-            vx[q] = pub_load16<vec_t>(rx, jv[q] * B); vy[q] = pub_load16<vec_t>(ry, jv[q] * B);
-            vr[q] = pub_load16<vec_t>(rr, jv[q] * B); vt[q] = pub_load16<vec_t>(rt, jv[q] * B);
+            vx[q] = ld16(w_ex, rx, jv[q]); vy[q] = ld16(w_ey, ry, jv[q]);
+            vr[q] = ld16(w_r, rr, jv[q]); vt[q] = ld16(w_th, rt, jv[q]);
         }
-        if (jt[q] < c) { tx[q] = pub_load1<T>(rx, jt[q] * B); ty[q] = pub_load1<T>(ry, jt[q] * B); tr[q] = pub_load1<T>(rr, jt[q] * B); tt[q] = pub_load1<T>(rt, jt[q] * B); }
+        if (jt[q] < c) { tx[q] = ld1(w_ex, rx, jt[q]); ty[q] = ld1(w_ey, ry, jt[q]); tr[q] = ld1(w_r, rr, jt[q]); tt[q] = ld1(w_th, rt, jt[q]); }
     }
     between();
     double sq = 0.0;
@@ -1380,8 +1390,10 @@ __global__ __launch_bounds__(kBlock) void k_ft_place(const T* __restrict__ w_ex,
     }
 #pragma unroll
     for (int q = 0; q < kPlaceTiles; ++q) {
-        double sq = ft_place_tile<T>(b * tiles_per_bundle + t0 + q, c[q], (int64_t)b * 2 * rpb + off[q], a, w_ex, w_ey, w_r, w_th,
-                                     ex, ey, rho, theta, tid);
+        // (every load of both halves ahead of the stores: the same sums in the same order as ft_place_tile, one dependent round
+        // trip per tile less — 583 -> 576 us on BASELINE config 3, profiles/r04_ab_place_loads_first.log)
+        double sq = ft_place_tile_pub<T, false>(b * tiles_per_bundle + t0 + q, c[q], (int64_t)b * 2 * rpb + off[q], a, w_ex, w_ey, w_r, w_th,
+                                                ex, ey, rho, theta, tid, []() {});
         for (int o = 32; o > 0; o >>= 1) sq += __shfl_down(sq, o);
         if (lane == 0) s_wsq[q][wave] = sq;
     }
