@@ -743,7 +743,10 @@ void k_trace(TraceParams<T> p)   // both outputs, look-back epilogue, Float64 ru
     };
     if constexpr (FUSED) {
         pf_ok = placing && pf_rdy == p.ft_epoch;
-        if (pf_ok) fetch_placement();
+        if (pf_ok) {
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");   // (no instruction: the loads below stay below the ready word's)
+            fetch_placement();
+        }
     }
     if (tracing) {                                               // (workgroup-uniform)
         // stage this system's table: S records of sizeof(SurfRec<T>) bytes, as 16-B words
