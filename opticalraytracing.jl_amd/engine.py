@@ -69,9 +69,11 @@ class Prescription:
 class HipEngine:
     name = "hip"
 
-    def __init__(self, device: int = 0, stream: Optional[int] = None, fast_math: bool = False):
+    def __init__(self, device: int = 0, stream: Optional[int] = None, fast_math: bool = False, fused_full_trace: bool = False):
+        """fast_math: ORT_FAST_MATH on every call of this engine.  fused_full_trace: ORT_FT_FUSED on every call (full_trace's second
+        pass inside the trace launch for launches of two or more bundles; bit-identical results, include/ort.h)."""
         self.ctx = Context(device, stream)
-        self.base_flags = _capi.ORT_FAST_MATH if fast_math else 0
+        self.base_flags = (_capi.ORT_FAST_MATH if fast_math else 0) | (_capi.ORT_FT_FUSED if fused_full_trace else 0)
         self._systems = OrderedDict()
         self.last_domain_error = None
         self.cache_size = 32

@@ -2271,6 +2271,10 @@ def test_full_trace_fused_route_is_bit_identical(policy):
     l1 = batch.full_trace_systems(M4[None], cm.DG_A, cm.DG_H, (0.0, 0.7, 1.0), 512, engine=eng, coef=np.asarray(coef)[None],
                                   flags=_capi.ORT_FT_FUSED)[1]
     same(l1, l0)
+    # ... and as an engine-wide choice: every pipeline of the engine takes the route
+    engf = ort.HipEngine(0, fast_math=(policy == "fast"), fused_full_trace=True)
+    same(batch.full_trace_systems(mats, cm.DG_A, cm.DG_H, (0.0, 1.0), 512, engine=engf)[1], r0)
+    same(engf.full_trace_grid(pres3, bundles3, axes3, 768, 768), ref_big)
 
 
 def test_fused_route_fault_is_reported():
