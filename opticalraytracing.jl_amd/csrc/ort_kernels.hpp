@@ -604,6 +604,9 @@ __device__ __forceinline__ void ft_place_body(int bid, const T* __restrict__ w_e
 //                BASELINE config 5 (profiles/r04_ab_walk_tiles_per_workgroup.log).
 enum { FT_NONE = 0, FT_FULL = 1, FT_WALK1 = 2, FT_LOOKBACK = 3, FT_WALK = 4, FT_FUSED = 5 };   // FT_WALK1: FT_WALK with spans of ONE tile (compile-time: the
                                                                                // span test of the long-span kernel stays a constant)
+#ifndef ORT_STOP_EXIT
+#define ORT_STOP_EXIT 1       // full_trace kernels: a wave whose rays are all outside the stop ends its surface loop there (A/B: 0 = none, 3 = every kernel)
+#endif
 #ifndef ORT_WALK_TILES
 #define ORT_WALK_TILES 8     // tiles per span of the FT_WALK route for bundles of more than kSmallTiles tiles (a power of two)
 #endif
@@ -854,7 +857,8 @@ void k_trace(TraceParams<T> p)   // both outputs, look-back epilogue, Float64 ru
                     odd = odd || t_class(ray[r].x, kClassNonFinite) || t_class(ray[r].y, kClassNonFinite) ||
                           t_class(ray[r].k0 + ray[r].k1, kClassNonFinite);
             }
-            for (int i = 0; i < S; ++i) {
+            int s_lim = S;                                           // (drops to the stop row for a wave that lies outside the stop)
+            for (int i = 0; i < s_lim; ++i) {
                 const SurfRec<T>& rec = s_rec[i];
                 const int cls = __builtin_amdgcn_readfirstlane(rec.cls);     // wave-uniform -> scalar branch
                 // the staged block is laid out for the kernel's own policy; the (cold) MATH_IEEE retrace of a MATH_FAST kernel
@@ -872,12 +876,27 @@ void k_trace(TraceParams<T> p)   // both outputs, look-back epilogue, Float64 ru
                     }
                     if (i == stop_u) {
                         const T a2 = a_stop * a_stop, alim = (T)Near<T>::thr * a2;
+                        // full_trace keeps only the rays inside the stop (:131-132): a wave whose rays are ALL outside it — by more
+                        // than the margin inside which the reference's hypot decides, in either policy — has nothing left to
+                        // contribute: the surface loop's bound drops to this row (a square pupil around a round stop: ~15 % of the
+                        // waves of a 2048^2 bundle, at about half of their rows: BASELINE config 3 statistics-only -7 %, fused -1.3 %).
+                        // As a `break` the exit changes how the compiler lays the loop out (Float32: 2,056 -> 1,541 instructions, yet
+                        // ort_spot_batch_f32 8.15 -> 9.18 ms); as a bound it still costs the Float32 kernels 4 % (config 5's waves are
+                        // whole pupil rows, never all outside) and the plain-sphere Float64 compaction kernel 3 %, so it is taken by
+                        // the Float64 statistics kernels and the polynomial builds only (profiles/r04_ab_stop_exit.log;
+                        // -DORT_STOP_EXIT=3: every full_trace kernel, =0: none)
+                        constexpr bool kStopExit = ORT_STOP_EXIT && FT != FT_NONE && !SUMM && !HIST &&
+                                                   (ORT_STOP_EXIT == 3 || (sizeof(T) == 8 && (WALK || POLY)));      // (which kernels: see below)
+                        bool out_all = kStopExit && a_stop >= T(0);
 #pragma unroll
                         for (int r = 0; r < RPT; ++r) {
                             xs_[r] = ray[r].x; ys_[r] = ray[r].y;
+                            const T e = t_fma<T>(xs_[r], xs_[r], t_fma<T>(ys_[r], ys_[r], -a2));     // r^2 - a_stop^2
                             // within kNear of the stop's edge the filter r > a_stop (:132) is decided by the reference sequence
-                            if (M == MATH_FAST) odd = odd || near_zero<T>(t_fma<T>(xs_[r], xs_[r], t_fma<T>(ys_[r], ys_[r], -a2)), alim);
+                            if (M == MATH_FAST) odd = odd || near_zero<T>(e, alim);
+                            if (kStopExit) out_all = out_all && (!live[r] || e > alim);              // (NaN: not outside)
                         }
+                        if (kStopExit && __all(out_all)) s_lim = i + 1;
                     }
                     if (gap2) {                                          // scalar branch: one s_cbranch when off
                         const T a2 = gap2[i];
