@@ -604,6 +604,9 @@ __device__ __forceinline__ void ft_place_body(int bid, const T* __restrict__ w_e
 //                BASELINE config 5 (profiles/r04_ab_walk_tiles_per_workgroup.log).
 enum { FT_NONE = 0, FT_FULL = 1, FT_WALK1 = 2, FT_LOOKBACK = 3, FT_WALK = 4, FT_FUSED = 5 };   // FT_WALK1: FT_WALK with spans of ONE tile (compile-time: the
                                                                                // span test of the long-span kernel stays a constant)
+#ifndef ORT_STATUS_ON_DEMAND
+#define ORT_STATUS_ON_DEMAND 1   // summary kernels count the per-surface status only when the caller passed a status array (A/B: 0)
+#endif
 #ifndef ORT_STOP_EXIT
 #define ORT_STOP_EXIT 1       // full_trace kernels: a wave whose rays are all outside the stop ends its surface loop there (A/B: 0 = none, 3 = every kernel)
 #endif
@@ -846,6 +849,7 @@ void k_trace(TraceParams<T> p)   // both outputs, look-back epilogue, Float64 ru
         }
 
         const int stop_u = __builtin_amdgcn_readfirstlane(stopi);    // bundle-uniform: the stop capture is a scalar branch
+        const bool want_status = p.status != nullptr;                // (kernel argument: scalar)
         // The surface loop in arithmetic policy M.  MATH_FAST returns whether a ray of this lane left the domain of
         // the fast forms (`odd`, ort_device.hpp).
         auto trace_surfaces = [&](auto math) -> bool {
@@ -866,7 +870,8 @@ void k_trace(TraceParams<T> p)   // both outputs, look-back epilogue, Float64 ru
                 const T* cf = (M == MATH) ? (s_poly + i * kPolyLds) : (gpoly ? gpoly + i * kPolyRec : nullptr);
                 surface_step_n<T, M, RPT, ARMS>(ray, rec, cf, cls, i == S - 1, odd);
                 if (SUMM || FT) {
-                    if (SUMM) {                                          // the full_trace epilogue reads the final NaN-ness only: no count
+                    if (SUMM && (!ORT_STATUS_ON_DEMAND || want_status)) {  // the full_trace epilogue reads the final NaN-ness only: no count;
+                                                                         // nor does a summary call that asks for hits without status (scalar branch)
 #pragma unroll
                         for (int r = 0; r < RPT; ++r) {
                             // NaN is sticky (every later transfer propagates it), so the 1-based index of the first
