@@ -141,3 +141,23 @@ def test_wavegrad_is_the_references_two_operations(oracle_engine):
     assert np.allclose(wx2 * 500e-6, wx * 587.5618e-6, rtol=1e-15)
     # a 1 um transverse error at n'u' = -0.2 is 0.34 waves at the d line
     assert abs(1e-3 * -0.2 / 587.5618e-6 + 0.340390) < 1e-6
+
+
+def test_best_placed_keeps_the_fastest_candidate():
+    """opticalraytracing_jl_amd/placement.py: candidates are all alive while they are timed, the fastest is returned, the report
+    lists every candidate's time; one candidate = no probing."""
+    from opticalraytracing_jl_amd.placement import best_placed
+    made, alive_when_timed = [], []
+    times = {0: 3.0, 1: 1.5, 2: 2.0, 3: 1.75}
+
+    def make():
+        made.append(len(made)); return made[-1]
+
+    def time_ms(b):
+        alive_when_timed.append(len(made)); return times[b]
+    chosen, rep = best_placed(make, time_ms, candidates=4)
+    assert chosen == 1 and rep["chosen"] == 1 and rep["candidates_ms"] == [3.0, 1.5, 2.0, 1.75]
+    assert alive_when_timed == [4, 4, 4, 4]                       # every candidate existed before the first was timed
+    made.clear()
+    chosen, rep = best_placed(make, time_ms, candidates=1)
+    assert chosen == 0 and rep["candidates_ms"] == [] and len(made) == 1
