@@ -52,5 +52,27 @@ int main()
     for (long gap : gaps)
         printf("  gap %9ld: %7.1f\n", gap, rate((double*)big, (double*)(big + bytes + gap), n, S, 0.4));
     CK(hipFree(big));
+    // (c) the ROW STRIDE: 24 rows are written at once per tile, ld * 8 B apart (72 MiB at ld = n); does a padded leading
+    // dimension (the ABI's ld >= n) spread them better over the channels, whatever the place?
+    printf("(c) six pairs, rows padded by `pad` elements (ld = n + pad), GB/s:\n");
+    const long pads[] = {0, 32, 512, 544, 8192, 8192 + 512, 131072 + 512, 1 << 20};
+    const long maxpad = 1 << 20;
+    const size_t pbytes = sizeof(double) * (n + maxpad) * S;
+    double* qx[6]; double* qy[6];
+    for (int k = 0; k < 6; ++k) { CK(hipMalloc(&qx[k], pbytes)); CK(hipMalloc(&qy[k], pbytes)); }
+    for (long pad : pads) {
+        printf("  pad %8ld:", pad);
+        for (int k = 0; k < 6; ++k) {
+            hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+            const dim3 g((unsigned)(n / 512)), blk(256);
+            for (int i = 0; i < 20; ++i) hipLaunchKernelGGL(k_hist, g, blk, 0, 0, qx[k], qy[k], n, S, n + pad);
+            CK(hipEventRecord(e0));
+            for (int i = 0; i < 400; ++i) hipLaunchKernelGGL(k_hist, g, blk, 0, 0, qx[k], qy[k], n, S, n + pad);
+            CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
+            float ms; CK(hipEventElapsedTime(&ms, e0, e1));
+            printf(" %7.1f", 16.0 * n * S / (ms / 400 * 1e-3) / 1e9);
+        }
+        printf("\n");
+    }
     return 0;
 }
