@@ -404,20 +404,31 @@ def bench_single(args, torch, rank, world, local_rank, emit=True):
         N3, S3 = nb3 * rpb3, p3.rows - 1
         sys3 = eng.system(p3); barr3 = _capi.make_bundles(b3)
         d_a3 = torch.from_numpy(a3).to(dev)
-        ex = torch.empty((nb3, 2 * rpb3), dtype=torch.float64, device=dev); ey = torch.empty_like(ex)
-        rho = torch.empty_like(ex); th = torch.empty_like(ex)
         cnt = torch.empty(nb3, dtype=torch.int64, device=dev); rms = torch.empty(nb3, dtype=torch.float64, device=dev)
 
-        def ft(full, extra_flags=0):
+        def ft_on(bufs, full, extra_flags=0):
             def f():
                 _capi.check(lib.ort_full_trace_f64(h, sys3.h, nb3, barr3, d_a3.data_ptr(), a3.size, k3, k3,
-                                                   ex.data_ptr() if full else None, ey.data_ptr() if full else None,
-                                                   rho.data_ptr() if full else None, th.data_ptr() if full else None,
+                                                   *((b.data_ptr() for b in bufs) if full else (None, None, None, None)),
                                                    cnt.data_ptr(), rms.data_ptr(), fl | extra_flags))
             return f
         PRE3 = 0.25                                                     # seconds of back-to-back calls ahead of each config-3 timing
         reps3 = max(3, args.steps // 4)
-        ms_first = timed_launches(eng, ft(True), reps3, warmup=1)       # (rounds 1-3 quoted this: a few calls after an idle period)
+        # the four output slabs (4 x 604 MB) where they are written fastest: the placement pass is HBM-bound and the place of a
+        # large buffer decides its store rate — candidates timed through the default route, the best set kept
+        from opticalraytracing_jl_amd.placement import best_placed
+        mk3 = lambda: tuple(torch.empty((nb3, 2 * rpb3), dtype=torch.float64, device=dev) for _ in range(4))
+        first3 = mk3()
+        ms_first = timed_launches(eng, ft_on(first3, True), reps3, warmup=1)   # (rounds 1-3 quoted this: a few calls after an idle period,
+        del first3                                                             #  into the first allocation)
+        nc3 = max(1, min(5, args.placement_candidates))
+        if nc3 > 1:
+            warm3 = mk3(); timed_launches(eng, ft_on(warm3, True), 4, warmup=1, preroll_s=PRE3); del warm3
+        (ex, ey, rho, th), place3 = best_placed(mk3, lambda bufs: timed_launches(eng, ft_on(bufs, True), 8, warmup=2), nc3)
+        torch.cuda.empty_cache()
+
+        def ft(full, extra_flags=0):
+            return ft_on((ex, ey, rho, th), full, extra_flags)
         ms = timed_launches(eng, ft(True), 4 * reps3, warmup=0, preroll_s=PRE3)
         kept = int(cnt.sum().item()) // 2
         ab = 64.0 * kept
@@ -426,7 +437,7 @@ def bench_single(args, torch, rank, world, local_rank, emit=True):
                         f"columns, {k3}x{k3} pupil, Float64, full_trace: stop filter + order-preserving ballot / prefix-sum "
                         f"compaction + mirror + rho, theta + RMS, error vectors out; {args.policy} policy",
             "rays": N3, "intersections": N3 * S3, "survivors": kept, "pipeline_ms": ms, "value": N3 * S3 / (ms * 1e-3),
-            "pipeline_ms_first_calls": ms_first,
+            "pipeline_ms_first_calls": ms_first, "output_placement": place3,
             "timing": f"pipeline_ms: mean of {4 * reps3} calls behind {PRE3} s of the same call back to back (sustained clocks, as the "
                       f"headline); pipeline_ms_first_calls: {reps3} calls after one warm-up call (what rounds 1-3 quoted)",
             "algorithmic_bytes_per_call": ab, "algorithmic_bytes_note": "2 halves x 32 B (ex, ey, rho, theta) per survivor",
