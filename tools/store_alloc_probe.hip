@@ -52,6 +52,36 @@ int main()
     for (long gap : gaps)
         printf("  gap %9ld: %7.1f\n", gap, rate((double*)big, (double*)(big + bytes + gap), n, S, 0.4));
     CK(hipFree(big));
+    // (d) ONE arena of 48 GiB, the pair cut from it every GiB: is a place a region of the address space?
+    {
+        const size_t GiB = 1ull << 30;
+        char* arena; CK(hipMalloc(&arena, 48 * GiB));
+        printf("(d) one 48-GiB allocation, x at offset k GiB, y right behind it (+2 MiB), GB/s by k:\n ");
+        for (int k = 0; k + 2 < 48; ++k) {
+            double* x = (double*)(arena + k * GiB); double* y = (double*)(arena + k * GiB + bytes + (2 << 20));
+            printf(" %d:%.0f", k, rate(x, y, n, S, 0.15)); fflush(stdout);
+        }
+        printf("\n");
+        CK(hipFree(arena));
+    }
+    // (e) the DISTANCE between the two arrays inside one 72-GiB arena: x at offset X GiB, y at X + D GiB
+    {
+        const size_t GiB = 1ull << 30;
+        char* arena; CK(hipMalloc(&arena, 72 * GiB));
+        printf("(e) one 72-GiB allocation, x at X GiB, y at (X + D) GiB, GB/s:\n");
+        const int Xs[] = {0, 1, 5, 16};
+        const int Ds[] = {1, 2, 3, 4, 6, 8, 12, 16, 24, 31, 32, 33, 40, 48};
+        for (int X : Xs) {
+            printf("  X = %2d:", X);
+            for (int D : Ds) {
+                if (X + D + 1 > 72) { printf("  D%d:-", D); continue; }
+                printf("  D%d:%.0f", D, rate((double*)(arena + X * GiB), (double*)(arena + (X + D) * GiB), n, S, 0.12)); fflush(stdout);
+            }
+            printf("\n");
+        }
+        // x alone and y alone (one array, the other pointer the same array's second half is not possible: write x twice)
+        CK(hipFree(arena));
+    }
     // (c) the ROW STRIDE: 24 rows are written at once per tile, ld * 8 B apart (72 MiB at ld = n); does a padded leading
     // dimension (the ABI's ld >= n) spread them better over the channels, whatever the place?
     printf("(c) six pairs, rows padded by `pad` elements (ld = n + pad), GB/s:\n");
