@@ -198,7 +198,7 @@ def bench_single(args, torch, rank, world, local_rank, emit=True):
     placement = None
     if args.mode == "history":
         # Where the two 906-MB output arrays come to lie decides 0.71 .. 0.85 of the HBM spec for the SAME kernel (one process, one
-        # GPU: profiles/r04_history_placement_probe.log): ten candidate pairs are allocated (18 GB for a moment), the launch is timed into each and
+        # GPU: profiles/r04_history_placement_probe.log): sixteen candidate pairs are allocated (29 GB for a moment; about one place in five is a fast one), the launch is timed into each and
         # the best-placed pair is kept for the run (opticalraytracing_jl_amd/placement.py); every candidate's time is reported
         from opticalraytracing_jl_amd.placement import best_placed
 
@@ -1183,7 +1183,7 @@ def main():
     ap.add_argument("--no-ceiling", action="store_true", help="skip the layout store-ceiling measurement (tools/store_ceiling)")
     ap.add_argument("--sustain-s", type=float, default=1.0, help="seconds of back-to-back launches for the sustained figure (0 = off)")
     ap.add_argument("--mode", default="history", choices=["history", "summary", "full_trace"])
-    ap.add_argument("--placement-candidates", type=int, default=10,
+    ap.add_argument("--placement-candidates", type=int, default=16,
                     help="history mode: candidate pairs of output arrays to choose the best-placed from (1 = take the first allocation)")
     ap.add_argument("--ft-lookback", action="store_true", help="--mode full_trace: the ORT_FT_LOOKBACK route")
     ap.add_argument("--ft-fused", action="store_true", help="--mode full_trace: the ORT_FT_FUSED route")
